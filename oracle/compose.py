@@ -1,0 +1,123 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (second checker + the timed CPU baseline).
+
+The reference's hot loop re-composed from torch's own CPU ops at exactly the call sites the
+reference uses, so on any box with torch the *same third-party kernels* the reference would
+run (ATen affine_grid_generator / grid_sampler / SGD) act as arbiter:
+  affine_warp     <- ref:warpings.py:18-26  (F.affine_grid + F.grid_sample, align_corners=False)
+  flow_warp       <- ref:utils.py:350-365   (identity grid + flow, normalise, align_corners=True)
+  ncc_loss        <- ref:utils.py:197-205   (global NCC, EPSILON=1e-10, alpha=100)
+  pose_to_theta   <- ref:utils.py:287-310
+  sgd loops       <- ref:warpings.py:67-93, :138-159, :208-233 (best = first strict minimum)
+Validated against tests/golden/ in tests/test_oracle_golden.py.  This is what
+bench.py reports as cpu_baseline (kind "port": the reference itself cannot travel to the GPU box).
+"""
+import torch
+import torch.nn.functional as F
+
+EPSILON = 1e-10
+
+
+def affine_warp(theta, moving):
+    nd = moving.dim() - 2
+    theta = theta.reshape(-1, nd, nd + 1)
+    grid = F.affine_grid(theta, list(moving.shape), align_corners=False)
+    return F.grid_sample(moving, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
+def identity_grid(shape, dtype=torch.float32, device="cpu"):
+    axes = [torch.arange(0, s, dtype=dtype, device=device) for s in shape]
+    return torch.stack(torch.meshgrid(*axes, indexing="ij"))[None]
+
+
+def flow_warp(src, flow, grid=None):
+    shape = flow.shape[2:]
+    nd = len(shape)
+    if grid is None:
+        grid = identity_grid(shape, flow.dtype, flow.device)
+    loc = grid + flow
+    loc = torch.stack([2 * (loc[:, i] / (shape[i] - 1) - 0.5) for i in range(nd)], dim=1)
+    loc = loc.movedim(1, -1).flip(-1)  # channel-last, (x, y[, z]) order
+    return F.grid_sample(src, loc, mode="bilinear", padding_mode="zeros", align_corners=True)
+
+
+def ncc_loss(y, yp, alpha=100.0):
+    a = y - y.mean()
+    b = yp - yp.mean()
+    ncc = (a * b).sum() / ((a * a).sum() * (b * b).sum() + EPSILON) ** 0.5
+    return (1 - ncc) * alpha
+
+
+def mse_loss(y, yp):
+    return F.mse_loss(yp, y)
+
+
+def ssd_loss(y, yp, alpha=3.0):
+    return ((y - yp) ** 2).sum() * alpha
+
+
+def weighted_loss(y, yp, w_mse=0.0, w_ncc=0.0, ncc_alpha=100.0, w_ssd=0.0, ssd_alpha=3.0):
+    e = 0.0
+    if w_mse:
+        e = e + w_mse * mse_loss(y, yp)
+    if w_ncc:
+        e = e + w_ncc * ncc_loss(y, yp, ncc_alpha)
+    if w_ssd:
+        e = e + w_ssd * ssd_loss(y, yp, ssd_alpha)
+    return e
+
+
+def pose_to_theta(x, max_translate=0.25):
+    if x.numel() == 6:
+        psi, th, phi = x[0], x[1], x[2]
+        c, s = torch.cos, torch.sin
+        t = max_translate * torch.tanh(x[3:6])
+        rows = [c(psi) * c(th), s(phi) * s(psi) * c(th) - c(phi) * s(th), c(phi) * s(psi) * c(th) + s(phi) * s(th), t[0],
+                c(psi) * s(th), s(phi) * s(psi) * s(th) + c(phi) * c(th), c(phi) * s(psi) * s(th) - s(phi) * c(th), t[1],
+                -s(psi), s(phi) * c(psi), c(phi) * c(psi), t[2]]
+        return torch.stack(rows).view(1, 3, 4)
+    a = x[0]
+    return torch.stack([torch.cos(a), -torch.sin(a), x[1], torch.sin(a), torch.cos(a), x[2]]).view(1, 2, 3)
+
+
+def affine_loop(moving, target, lr, iters, pose0=None, optimizer="sgd", **loss_kw):
+    """SGD (or Adam, extension) on theta / pose; returns losses, thetas[iters+1], best idx."""
+    nd = moving.dim() - 2
+    dt = moving.dtype
+    if pose0 is not None:
+        p = pose0.clone().to(dt).requires_grad_()
+        make = lambda: pose_to_theta(p)  # noqa: E731
+    else:
+        p = torch.eye(nd, nd + 1, dtype=dt)[None].clone().requires_grad_()
+        make = lambda: p  # noqa: E731
+    opt = torch.optim.SGD([p], lr) if optimizer == "sgd" else torch.optim.Adam([p], lr)
+    losses, thetas, best, best_idx = [], [], None, -1
+    for t in range(iters):
+        opt.zero_grad()
+        th = make()
+        thetas.append(th.detach()[0].clone())
+        e = weighted_loss(target, affine_warp(th, moving), **loss_kw)
+        e.backward()
+        opt.step()
+        v = e.item()
+        losses.append(v)
+        if best is None or v < best:
+            best, best_idx = v, t
+    thetas.append(make().detach()[0].clone())
+    return dict(losses=torch.tensor(losses, dtype=torch.float64), thetas=torch.stack(thetas), best_idx=best_idx)
+
+
+def flow_loop(moving, target, lr, iters, optimizer="sgd", **loss_kw):
+    nd = moving.dim() - 2
+    shape = moving.shape[2:]
+    fl = torch.zeros(1, nd, *shape, dtype=moving.dtype, requires_grad=True)
+    grid = identity_grid(shape, moving.dtype)
+    opt = torch.optim.SGD([fl], lr) if optimizer == "sgd" else torch.optim.Adam([fl], lr)
+    losses = []
+    for _ in range(iters):
+        opt.zero_grad()
+        e = weighted_loss(target, flow_warp(moving, fl, grid), **loss_kw)
+        e.backward()
+        opt.step()
+        losses.append(e.item())
+    return dict(losses=torch.tensor(losses, dtype=torch.float64), flow=fl.detach(),
+                final_warped=flow_warp(moving, fl.detach(), grid))

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def single_step():
+    return dict(np.load(os.path.join(GOLDEN, "single_step.npz")))
+
+
+@pytest.fixture(scope="session")
+def trajectories():
+    return dict(np.load(os.path.join(GOLDEN, "trajectories.npz")))
+
+
+def bar(g32, g64, floor):
+    """Parity bar: max(stated floor, 2x the reference's own fp32-vs-fp64 gap)."""
+    return max(floor, 2.0 * float(np.max(np.abs(np.asarray(g32, dtype=np.float64) - np.asarray(g64, dtype=np.float64)))))

@@ -46,11 +46,13 @@ def flow_field(shape, amp=0.8, f=0.11, dtype=torch.float32):
 # theta constants used by fixtures / KATs
 THETA_A = [[0.9, 0.1, -0.05, 0.02], [-0.08, 1.05, 0.03, -0.04], [0.06, -0.02, 0.95, 0.01]]
 THETA_B = [[0.9, 0.1, 0.02], [-0.08, 1.05, -0.04]]
-# strongly out-of-bounds: zoom-out + shift so many corners fall outside the volume
-THETA_OOB3 = [[1.45, 0.2, -0.1, 0.35], [0.15, 1.3, 0.1, -0.3], [-0.2, 0.1, 1.5, 0.25]]
-THETA_OOB2 = [[1.4, 0.3, 0.3], [-0.25, 1.35, -0.35]]
+# strongly out-of-bounds: zoom-out + shift so many corners fall outside the volume.  Generic
+# (non-dyadic) entries: sample coordinates must not land exactly on integers, where the
+# trilinear derivative is one-sided and the side taken depends on last-bit rounding.
+THETA_OOB3 = [[1.437, 0.213, -0.118, 0.3531], [0.1519, 1.3127, 0.1093, -0.2977], [-0.2071, 0.1037, 1.4911, 0.2543]]
+THETA_OOB2 = [[1.4113, 0.3071, 0.2939], [-0.2531, 1.3517, -0.3467]]
 # rotation-like
-THETA_ROT3 = [[0.8, -0.55, 0.1, 0.05], [0.5, 0.82, -0.15, -0.02], [-0.05, 0.2, 0.97, 0.03]]
+THETA_ROT3 = [[0.8013, -0.5527, 0.1031, 0.0517], [0.5009, 0.8219, -0.1523, -0.0211], [-0.0507, 0.2017, 0.9713, 0.0307]]
 # ground-truth perturbations used to synthesise "moving" from "target" (Appendix A)
 THETA_STAR3 = [[0.95, -0.1, 0.02, 0.05], [0.1, 0.97, 0.0, -0.03], [0.0, 0.03, 1.02, 0.02]]
 THETA_STAR2 = [[0.98, -0.17, 0.05], [0.17, 0.98, -0.03]]
