@@ -1,0 +1,30 @@
+# Build the MI355X (gfx950) C-ABI library and the CPU oracle.
+#   make            -> torchregister_amd/lib/libtrx.so  (hipcc cross-compiles without a GPU)
+#   make oracle     -> oracle/liboracle.so              (test infrastructure only)
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := torchregister_amd/csrc
+SRCS    := $(CSRC)/api.hip $(CSRC)/affine.hip $(CSRC)/flow.hip
+HDRS    := $(CSRC)/trx_common.h include/trx.h
+OBJS    := $(SRCS:$(CSRC)/%.hip=build/%.o)
+LIB     := torchregister_amd/lib/libtrx.so
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=fast -Wall -Wno-unused-function
+
+all: $(LIB)
+
+build/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p torchregister_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,161 @@
+/*
+ * trx.h — C ABI of the MI355X-native TorchRegister hot path (libtrx.so).
+ *
+ * The reference (AgamChopra/TorchRegister v0.2.3, ref: = src/TorchRegister/) is pure Python and
+ * has NO plugin / operator / FFI interface; its hot path is a chain of ATen ops inside three
+ * Python loops.  These entry points are what a binding for that path would call instead; each
+ * one names the reference code it replaces.  All pointers are DEVICE pointers unless marked
+ * [host]; `stream` is a hipStream_t passed as void*.  No entry point allocates, synchronises
+ * or calls back into the host: everything is enqueued on `stream` and is graph-capturable.
+ * Return value: 0 (TRX_OK) or a negative trx_status; nothing throws.
+ * Thread-compatible: no global state, one host thread per GPU/stream may call concurrently.
+ *
+ * Data layout (fp32, contiguous): volumes [B][D][H][W] (2-D: D = 1, ndim = 2), pair p of a
+ * batch at base + p * stride elements (stride 0 = one volume shared by all pairs).
+ * theta: row-major [ndim][ndim+1] per pair, row 0 -> x (W axis), row 1 -> y (H), row 2 -> z (D),
+ * exactly F.affine_grid's convention; per-pair small vectors are padded to TRX_PSTRIDE floats.
+ * flow: [B][ndim][D][H][W], channel i displaces along spatial dim i in voxel units
+ * (ref:utils.py:343-351).
+ */
+#ifndef TRX_H
+#define TRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRX_VERSION 100 /* 0.1.0 */
+#define TRX_PSTRIDE 12  /* floats per pair in theta / param / adam / best_theta arrays */
+
+typedef enum {
+    TRX_OK = 0,
+    TRX_ERR_ARG = -1,       /* null pointer / non-positive size / bad enum */
+    TRX_ERR_NDIM = -2,      /* ndim not 2 or 3 (or D != 1 with ndim 2) */
+    TRX_ERR_WORKSPACE = -3, /* workspace too small: see trx_*_workspace_bytes */
+    TRX_ERR_HIP = -4,       /* a HIP launch failed (hipGetLastError) */
+    TRX_ERR_CAPACITY = -5   /* loss-curve buffer shorter than the requested iterations */
+} trx_status;
+
+/* A batch of B independent (moving, target) pairs. */
+typedef struct {
+    const float *moving;   /* [B][D][H][W] */
+    const float *target;   /* [B][D][H][W] (may be NULL for warp-only calls) */
+    size_t moving_stride;  /* elements between pairs */
+    size_t target_stride;
+    int ndim, B, D, H, W;
+    /* Optional base-coordinate tables of affine_grid(align_corners=False): xn[W], yn[H], zn[D] =
+     * fp32 linspace(-1,1,S)*(S-1)/S as ATen builds them.  NULL -> closed form (2i+1)/S-1. */
+    const float *xn, *yn, *zn;
+} trx_volumes;
+
+/* L = w_mse*MSE + w_ncc*ncc_alpha*(1-NCC) + w_ssd*ssd_alpha*SSD
+ * replaces nn.MSELoss call sites (ref:warpings.py:37,39,124,126,179), NCCLoss.forward
+ * (ref:utils.py:197-205, EPSILON=1e-10), SSDLoss.forward (ref:utils.py:218-221) and the weighted
+ * sum (ref:warpings.py:78-79,144-145,213-214).  Argument order (target, warped) as in the loops. */
+typedef struct {
+    float w_mse, w_ncc, ncc_alpha, w_ssd, ssd_alpha;
+} trx_loss_cfg;
+
+typedef enum { TRX_OPT_SGD = 0, TRX_OPT_ADAM = 1 } trx_opt_kind;
+/* SGD replaces torch.optim.SGD(params, lr) (ref:warpings.py:58,131,192); Adam is an extension
+ * (torch.optim.Adam defaults beta=(0.9,0.999), eps=1e-8, bias-corrected). */
+typedef struct {
+    int kind;
+    float lr, beta1, beta2, eps;
+} trx_opt_cfg;
+
+typedef enum { TRX_PARAM_AFFINE = 0, TRX_PARAM_RIGID = 1 } trx_param_mode;
+
+/* Per-pair optimisation state, all device memory, all [B][TRX_PSTRIDE] unless noted.
+ * AFFINE: param IS theta (ref:warpings.py:42-55,70-74: the regressor MLP is dead, theta == its
+ *         bias).  RIGID: param is the pose vector of Theta (ref:utils.py:287-310,
+ *         6 floats in 3-D, 3 in 2-D) and theta = Theta(param). */
+typedef struct {
+    int mode;           /* trx_param_mode */
+    float *param;       /* in/out: optimised parameters */
+    float *theta;       /* in/out: theta of the NEXT forward (caller initialises consistently) */
+    float *adam_m;      /* in/out, may be NULL for SGD */
+    float *adam_v;
+    float *best_theta;  /* out: theta of the first strict loss minimum (ref:warpings.py:85-93) */
+    float *best_loss;   /* [B] out */
+    int *best_idx;      /* [B] out */
+    float *losses;      /* [B][losses_capacity] out: L_t per iteration (ref:warpings.py:83) */
+    int losses_capacity;
+    int *step;          /* [B] in/out: iteration counter t (device-resident; 0 before the run) */
+    float *grad;        /* optional out [B][TRX_PSTRIDE]: dL/dparam of the last step (may be NULL) */
+} trx_affine_state;
+
+int trx_version(void);
+const char *trx_status_string(int status);
+
+/* Bytes of scratch the affine entry points need for this batch geometry. */
+size_t trx_affine_workspace_bytes(const trx_volumes *vol /*[host]*/);
+
+/* ONE optimiser iteration for all B pairs: fused forward warp + loss + analytic backward
+ * (single pass over moving/target), then loss/gradient/optimiser/best-tracking on device.
+ * Replaces one trip of the loop bodies ref:warpings.py:67-93 (affine) / :138-159 (rigid):
+ * get_affine_warp (ref:warpings.py:18-26) -> criterions -> error.backward() -> optimizer.step()
+ * -> losses_train.append(error.item()) -> best tracking. */
+int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
+                    const trx_affine_state *st, void *workspace, size_t workspace_bytes, void *stream);
+
+/* `iters` iterations enqueued back to back (no host sync in between; replaces the whole loop). */
+int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
+                   const trx_affine_state *st, int iters, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Loss only (forward), theta untouched: terms[B][4] = {total, MSE, NCC-loss, SSD-loss}. */
+int trx_affine_loss(const trx_volumes *vol, const trx_loss_cfg *loss, const float *theta, float *terms,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* get_affine_warp forward (ref:warpings.py:18-26; used by Register.__call__, ref:torchregister.py:123-128):
+ * out[B][C][D][H][W] = warp(moving[B][C][D][H][W], theta[B]); vol->moving_stride is the stride
+ * between BATCH items (C*D*H*W for a dense tensor); channels share theta. */
+int trx_affine_warp(const trx_volumes *vol, const float *theta, int channels, float *out, void *stream);
+
+/* Generic backward of the warp wrt theta: dtheta[B][TRX_PSTRIDE] = sum_p,c grad_out * d warp/d theta
+ * (grid_sampler backward + affine_grid backward of the autograd chain behind error.backward(),
+ * ref:warpings.py:80,146) — lets any torch loss drive the HIP warp. */
+int trx_affine_warp_backward(const trx_volumes *vol, const float *theta, int channels, const float *grad_out,
+                             float *dtheta, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ dense flow (SpatialTransformer) */
+typedef struct {
+    float *flow;        /* [B][ndim][D][H][W] in/out */
+    float *flow_tmp;    /* same size; required only when smooth_weight != 0 (double buffer) */
+    float *adam_m;      /* same size, Adam only */
+    float *adam_v;
+    float *losses;      /* [B][losses_capacity] */
+    int losses_capacity;
+    int *step;          /* [B] */
+    float smooth_weight; /* extension: lambda * mean squared forward differences of the flow */
+} trx_flow_state;
+
+size_t trx_flow_workspace_bytes(const trx_volumes *vol);
+
+/* SpatialTransformer.forward (ref:utils.py:350-365), C channels sharing the flow
+ * (flow_register.deform, ref:warpings.py:238-242; Register.__call__, ref:torchregister.py:123-126). */
+int trx_flow_warp(const trx_volumes *vol, const float *flow, int channels, float *out, void *stream);
+
+/* One iteration of direct flow-field optimisation (pass A moments, pass B gradient + optimiser):
+ * the warp + loss + backward + step span of ref:warpings.py:208-220 with the flow itself as parameter. */
+int trx_flow_step(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
+                  const trx_flow_state *st, void *workspace, size_t workspace_bytes, void *stream);
+int trx_flow_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
+                 const trx_flow_state *st, int iters, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Loss + dL/dflow for a given flow (the autograd.Function backward for U-Net-generated flows):
+ * terms[B][4]; dflow may be NULL (loss only). */
+int trx_flow_loss_grad(const trx_volumes *vol, const trx_loss_cfg *loss, const float *flow, float *terms,
+                       float *dflow, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Generic backward of the flow warp: dflow[B][ndim][...] = sum_c grad_out[B][c][...] * d warp/d flow. */
+int trx_flow_warp_backward(const trx_volumes *vol, const float *flow, int channels, const float *grad_out,
+                           float *dflow, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRX_H */

@@ -1,0 +1,220 @@
+"""GPU parity: the HIP affine/rigid path (through the C ABI) vs the oracle and the golden vectors.
+
+Tolerances (fp32 path): warped <= max(2e-6, 2x ref fp32-fp64 gap) abs; loss <=
+max(2e-5*|L|, 2x gap); gradient <= max(1e-4*max|g|, 2x gap); trajectories: loss <= max(1e-4*max|L|,
+2x gap), theta <= max(1e-4, 2x gap).  "gap" is the reference's own fp32-vs-fp64 difference stored in
+the golden fixtures.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import phantoms as ph
+from conftest import bar
+
+pytestmark = pytest.mark.gpu
+
+AFFINE_CASES = ["A3", "B2", "OOB3", "ROT3", "OOB2", "ID3", "ID2"]
+LOSSES = {"ncc": dict(w_ncc=1.0), "mse": dict(w_mse=1.0), "ssd": dict(w_ssd=1.0)}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torchregister_amd._engine as e
+    assert torch.cuda.is_available()
+    return e
+
+
+def _mt(shape):
+    return ph.vol(shape, 0.37, "sin"), ph.vol(shape, 0.23, "cos")
+
+
+@pytest.mark.parametrize("case", AFFINE_CASES)
+def test_affine_warp_vs_golden(eng, single_step, case):
+    g = single_step
+    shape = tuple(g[f"{case}/shape"])
+    mov, _ = _mt(shape)
+    th = torch.tensor(g[f"{case}/theta"], dtype=torch.float32)[None].cuda()
+    w = eng.affine_warp(th, mov.cuda()).cpu().numpy()
+    g32, g64 = g[f"{case}/warped32"], g[f"{case}/warped64"]
+    assert np.max(np.abs(w - g32)) <= bar(g32, g64, 2e-6)
+
+
+@pytest.mark.parametrize("case", AFFINE_CASES)
+@pytest.mark.parametrize("lname", ["ncc", "mse", "ssd"])
+def test_affine_step_loss_grad_vs_golden(eng, single_step, case, lname):
+    """One fused step: recorded loss and dL/dtheta against the reference's autograd values."""
+    g = single_step
+    shape = tuple(g[f"{case}/shape"])
+    nd = len(shape)
+    mov, tgt = _mt(shape)
+    th = torch.tensor(g[f"{case}/theta"], dtype=torch.float32)[None]
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**LOSSES[lname]), lr=0.0, init=th, capacity=2)
+    s.run(1)
+    torch.cuda.synchronize()
+    loss = s.losses[0, 0].item()
+    grad = s.grad[0, : nd * (nd + 1)].cpu().numpy().reshape(nd, nd + 1)
+    l32, l64 = float(g[f"{case}/{lname}32"]), float(g[f"{case}/{lname}64"])
+    d32, d64 = g[f"{case}/d{lname}32"], g[f"{case}/d{lname}64"]
+    assert abs(loss - l32) <= bar(l32, l64, 2e-5 * max(1.0, abs(l64)))
+    assert np.max(np.abs(grad - d32)) <= bar(d32, d64, 1e-4 * np.max(np.abs(d64)))
+    # lr = 0: parameters unchanged, best == this theta
+    assert torch.equal(s.current_theta.cpu(), th)
+    assert s.best_idx[0].item() == 0 and torch.equal(s.best.cpu(), th)
+    # loss-only entry point agrees with the step
+    terms = s.eval_loss(th.cuda()).cpu().numpy()[0]
+    assert abs(terms[0] - loss) <= 1e-6 * max(1.0, abs(loss))
+
+
+@pytest.mark.parametrize("case", ["A3", "B2", "OOB3", "ROT3", "OOB2"])
+def test_affine_step_vs_c_oracle_weighted_mix(eng, single_step, case):
+    """Weighted MSE+NCC+SSD mix against the C oracle (fp64 arbiter)."""
+    g = single_step
+    shape = tuple(g[f"{case}/shape"])
+    nd = len(shape)
+    mov, tgt = _mt(shape)
+    kw = dict(w_mse=0.4, w_ncc=0.7, ncc_alpha=50.0, w_ssd=0.01, ssd_alpha=2.0)
+    th = torch.tensor(g[f"{case}/theta"], dtype=torch.float32)[None]
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=2)
+    s.run(1)
+    torch.cuda.synchronize()
+    total, _, dth, _ = oracle.c_affine_loss_grad(mov[0, 0].double().numpy(), tgt[0, 0].double().numpy(), g[f"{case}/theta"],
+                                                 oracle.wts(**kw), oracle.base_tables(shape, np.float64))
+    assert abs(s.losses[0, 0].item() - total) <= 2e-5 * max(1.0, abs(total))
+    grad = s.grad[0, : nd * (nd + 1)].cpu().numpy().reshape(nd, nd + 1)
+    assert np.max(np.abs(grad - dth)) <= 2e-4 * np.max(np.abs(dth))
+
+
+@pytest.mark.parametrize("case", ["A3", "B2", "ROT3", "OOB2"])
+def test_affine_warp_backward_vs_oracle(eng, single_step, case):
+    g = single_step
+    shape = tuple(g[f"{case}/shape"])
+    mov, tgt = _mt(shape)
+    th = torch.tensor(g[f"{case}/theta"], dtype=torch.float32)[None]
+    # grad_out = dMSE/dwarped -> dtheta must equal the golden dMSE/dtheta
+    w = eng.affine_warp(th.cuda(), mov.cuda())
+    go = 2.0 * (w - tgt.cuda()) / w.numel()
+    dth = eng.affine_warp_backward(th.cuda(), mov.cuda(), go).cpu().numpy()[0]
+    d32, d64 = g[f"{case}/dmse32"], g[f"{case}/dmse64"]
+    assert np.max(np.abs(dth - d32)) <= bar(d32, d64, 1e-4 * np.max(np.abs(d64)))
+
+
+def _mov_tgt(g, name):
+    shape = tuple(g[f"{name}/shape"])
+    seed = int(g[f"{name}/meta"][2])
+    return torch.from_numpy(g[f"{name}/moving"]), ph.blobs(shape, 1000 + seed)
+
+
+@pytest.mark.parametrize("name", ["rigid2d_mse", "rigid3d_mse", "affine3d_mse", "affine2d_mse"])
+def test_driver_trajectories_vs_golden(eng, trajectories, name):
+    """Whole loops of ref rigid_register / affine_register (MSE, SGD, best tracking)."""
+    g = trajectories
+    lr, iters = float(g[f"{name}/meta"][0]), int(g[f"{name}/meta"][1])
+    mov, tgt = _mov_tgt(g, name)
+    rigid = f"{name}/init" in g
+    init = torch.from_numpy(g[f"{name}/init"])[None] if rigid else None
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="rigid" if rigid else "affine", loss=eng.LossSpec(w_mse=1.0), lr=lr,
+                         init=init, capacity=iters)
+    s.run(iters)
+    torch.cuda.synchronize()
+    losses = s.losses[0].cpu().numpy().astype(np.float64)
+    l32, l64 = g[f"{name}/losses"], g[f"{name}/losses64"]
+    assert np.max(np.abs(losses - l32)) <= bar(l32, l64, 1e-4 * np.max(np.abs(l64)))
+    tbar = bar(g[f"{name}/final_theta"][0], g[f"{name}/thetas64"][-1], 1e-4)
+    assert np.max(np.abs(s.current_theta[0].cpu().numpy() - g[f"{name}/final_theta"][0])) <= tbar
+    # best = first strict minimum of the recorded curve; theta of that forward
+    bi = s.best_idx[0].item()
+    assert bi == int(np.argmin(losses))
+    assert abs(s.best_loss[0].item() - losses[bi]) == 0.0
+    gold_bi = int(np.argmin(l32))
+    if bi == gold_bi:
+        assert np.max(np.abs(s.best[0].cpu().numpy() - g[f"{name}/best_theta"][0])) <= tbar
+
+
+@pytest.mark.parametrize("name,rigid", [("c_affine3d_ncc", False), ("c_affine2d_ncc", False), ("c_rigid3d_ncc", True)])
+def test_ncc_trajectories_vs_golden(eng, trajectories, name, rigid):
+    g = trajectories
+    lr, iters = float(g[f"{name}/meta"][0]), int(g[f"{name}/meta"][1])
+    mov, tgt = _mov_tgt(g, name)
+    init = torch.from_numpy(g[f"{name}/init"])[None] if rigid else None
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="rigid" if rigid else "affine", loss=eng.LossSpec(w_ncc=1.0), lr=lr,
+                         init=init, capacity=iters)
+    s.run(iters)
+    torch.cuda.synchronize()
+    losses = s.losses[0].cpu().numpy().astype(np.float64)
+    l32, l64 = g[f"{name}/losses32"], g[f"{name}/losses64"]
+    assert np.max(np.abs(losses - l32)) <= bar(l32, l64, 1e-4 * np.max(np.abs(l64)))
+    t32, t64 = g[f"{name}/thetas32"], g[f"{name}/thetas64"]
+    assert np.max(np.abs(s.current_theta[0].cpu().numpy() - t32[-1])) <= bar(t32, t64, 1e-4)
+
+
+def test_batch_equals_singles(eng):
+    """B pairs in one launch == the same pairs solved one by one (bitwise: fixed-order reductions)."""
+    shape = (20, 24, 28)
+    movs = torch.cat([ph.blobs(shape, 10 + i) for i in range(3)]).cuda()
+    tgts = torch.cat([ph.blobs(shape, 20 + i) for i in range(3)]).cuda()
+    sb = eng.AffineSolver(movs, tgts, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=1e-4, capacity=5)
+    sb.run(5)
+    for i in range(3):
+        s1 = eng.AffineSolver(movs[i:i + 1], tgts[i:i + 1], mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=1e-4, capacity=5)
+        s1.run(5)
+        torch.cuda.synchronize()
+        assert torch.allclose(sb.losses[i], s1.losses[0], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(sb.current_theta[i], s1.current_theta[0], rtol=0, atol=1e-6)
+
+
+def test_determinism(eng):
+    shape = (32, 32, 32)
+    mov, tgt = ph.blobs(shape, 1).cuda(), ph.blobs(shape, 2).cuda()
+    runs = []
+    for _ in range(2):
+        s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=1e-4, capacity=10)
+        s.run(10)
+        torch.cuda.synchronize()
+        runs.append((s.losses.clone(), s.theta.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+def test_adam_vs_torch_adam(eng):
+    """Adam extension: trajectory vs torch.optim.Adam on the oracle composition (CPU, fp64 arbiter bar)."""
+    from oracle import compose
+    shape = (16, 20, 24)
+    tgt = ph.blobs(shape, 1003)
+    mov = compose.affine_warp(torch.tensor(ph.THETA_STAR3)[None], tgt)
+    r32 = compose.affine_loop(mov, tgt, 1e-3, 25, optimizer="adam", w_ncc=1.0)
+    r64 = compose.affine_loop(mov.double(), tgt.double(), 1e-3, 25, optimizer="adam", w_ncc=1.0)
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(w_ncc=1.0), optimizer="adam", lr=1e-3, capacity=25)
+    s.run(25)
+    torch.cuda.synchronize()
+    l32, l64 = r32["losses"].numpy(), r64["losses"].numpy()
+    assert np.max(np.abs(s.losses[0].cpu().numpy() - l32)) <= bar(l32, l64, 1e-4 * np.max(np.abs(l64)))
+    assert np.max(np.abs(s.current_theta[0].cpu().numpy() - r32["thetas"][-1].numpy())) <= bar(r32["thetas"].numpy(), r64["thetas"].numpy(), 1e-4)
+
+
+def test_full_size_properties(eng):
+    """256^3 (BASELINE size): identity theta reproduces moving; NCC(x,x)=0; loss-only == step loss."""
+    shape = (256, 256, 256)
+    tgt = ph.blobs(shape, 1000).cuda()
+    ident = torch.eye(3, 4)[None].cuda()
+    w = eng.affine_warp(ident, tgt)
+    assert torch.max(torch.abs(w - tgt)).item() <= 1e-5
+    s = eng.AffineSolver(tgt, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0, w_mse=1.0), lr=0.0, capacity=1)
+    s.run(1)
+    torch.cuda.synchronize()
+    assert abs(s.losses[0, 0].item()) <= 1e-3
+    # linearity of the warp in the image: warp(a*x + b*y) == a*warp(x) + b*warp(y)
+    th = torch.tensor(ph.THETA_STAR3)[None].cuda()
+    other = ph.blobs(shape, 1001).cuda()
+    lhs = eng.affine_warp(th, 0.3 * tgt + 0.7 * other)
+    rhs = 0.3 * eng.affine_warp(th, tgt) + 0.7 * eng.affine_warp(th, other)
+    assert torch.max(torch.abs(lhs - rhs)).item() <= 1e-5
+    # fused loss at full size vs torch GPU ops on the HIP-warped volume (fp64 reduction)
+    s2 = eng.AffineSolver(eng.affine_warp(th, tgt), tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=0.0, capacity=1)
+    s2.run(1)
+    torch.cuda.synchronize()
+    wv = eng.affine_warp(ident, s2.batch.moving).double()
+    y = tgt.double()
+    a, b = y - y.mean(), wv - wv.mean()
+    ncc = 100.0 * (1 - (a * b).sum() / ((a * a).sum() * (b * b).sum() + 1e-10).sqrt())
+    assert abs(s2.losses[0, 0].item() - ncc.item()) <= 2e-4 * max(1.0, abs(ncc.item()))

@@ -1,0 +1,9 @@
+"""MI355X-native TorchRegister hot path (drop-in for AgamChopra/TorchRegister's Register API).
+
+`import torchregister_amd as tr` (or `import TorchRegister as tr` through the alias package)
+gives `tr.Register(mode=...).optim(moving, target, ...)` / `reg(moving)` backed by hand-written
+HIP kernels in lib/libtrx.so (C ABI: include/trx.h).  There is no CPU fallback.
+"""
+__version__ = "0.1.0"
+
+from ._engine import AffineSolver, FlowSolver, LossSpec  # noqa: F401

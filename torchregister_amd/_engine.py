@@ -1,0 +1,322 @@
+"""Host-side drivers over the C ABI: device state, workspaces and launch wrappers.
+
+PyTorch is used for device memory and streams only; all arithmetic of the hot path happens in
+libtrx.so.  Tensors must be fp32 CUDA(HIP) tensors; anything else raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import PSTRIDE
+
+
+class LossSpec:
+    """L = w_mse*MSE + w_ncc*alpha*(1-NCC) + w_ssd*alpha_ssd*SSD (include/trx.h trx_loss_cfg)."""
+
+    def __init__(self, w_mse=0.0, w_ncc=0.0, ncc_alpha=100.0, w_ssd=0.0, ssd_alpha=3.0):
+        self.w_mse, self.w_ncc, self.ncc_alpha, self.w_ssd, self.ssd_alpha = map(float, (w_mse, w_ncc, ncc_alpha, w_ssd, ssd_alpha))
+
+    def c(self):
+        return _lib.LossCfg(self.w_mse, self.w_ncc, self.ncc_alpha, self.w_ssd, self.ssd_alpha)
+
+    def __repr__(self):
+        return f"LossSpec(mse={self.w_mse}, ncc={self.w_ncc}*{self.ncc_alpha}, ssd={self.w_ssd}*{self.ssd_alpha})"
+
+
+def opt_cfg(optimizer, lr, betas=(0.9, 0.999), eps=1e-8):
+    kind = {"sgd": _lib.OPT_SGD, "adam": _lib.OPT_ADAM}.get(str(optimizer).lower())
+    if kind is None:
+        raise ValueError(f"optimizer must be 'sgd' or 'adam', got {optimizer!r}")
+    return _lib.OptCfg(kind, float(lr), float(betas[0]), float(betas[1]), float(eps))
+
+
+def _require_gpu(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise _lib.TrxError(f"{name} is on {t.device}: torchregister_amd runs only on an AMD GPU through its HIP "
+                            f"library (no CPU fallback). Move the tensors to 'cuda'.")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+
+
+def base_tables(spatial, device):
+    """affine_grid's base coordinates, built with ATen's own CPU expression (bit-exact), on device."""
+    return [(torch.linspace(-1, 1, int(s), dtype=torch.float32) * (int(s) - 1) / int(s)).to(device) for s in spatial]
+
+
+class _Batch:
+    """A batch of volumes [B, C, *spatial] described for the C ABI."""
+
+    def __init__(self, moving, target=None, tables=True):
+        _require_gpu(moving, "moving")
+        if moving.dim() not in (4, 5):
+            raise ValueError(f"expected [B,C,H,W] or [B,C,D,H,W], got {tuple(moving.shape)}")
+        self.moving = moving.contiguous()
+        self.nd = moving.dim() - 2
+        self.B, self.C = moving.shape[0], moving.shape[1]
+        self.spatial = tuple(moving.shape[2:])
+        self.nvox = 1
+        for s in self.spatial:
+            self.nvox *= s
+        self.device = moving.device
+        self.target = None
+        if target is not None:
+            _require_gpu(target, "target")
+            if target.shape[2:] != moving.shape[2:]:
+                raise ValueError(f"moving {tuple(moving.shape)} and target {tuple(target.shape)} differ in spatial size")
+            self.target = target.contiguous()
+        self.tables = base_tables(self.spatial, self.device) if tables else None
+
+    def vol(self, moving_stride=None, target_stride=None):
+        D, H, W = ((1,) + self.spatial) if self.nd == 2 else self.spatial
+        v = _lib.Volumes()
+        v.moving = self.moving.data_ptr()
+        v.target = self.target.data_ptr() if self.target is not None else None
+        v.moving_stride = self.C * self.nvox if moving_stride is None else moving_stride
+        v.target_stride = (self.target.shape[1] * self.nvox if self.target is not None else 0) if target_stride is None else target_stride
+        v.ndim, v.B, v.D, v.H, v.W = self.nd, self.B, D, H, W
+        if self.tables is not None:
+            if self.nd == 3:
+                v.zn, v.yn, v.xn = (t.data_ptr() for t in self.tables)
+            else:
+                v.zn = None
+                v.yn, v.xn = (t.data_ptr() for t in self.tables)
+        return v
+
+
+def pad_theta(theta, nd):
+    """[B, nd, nd+1] (or [B, nd*(nd+1)]) -> [B, PSTRIDE] contiguous fp32."""
+    B = theta.shape[0]
+    out = torch.zeros(B, PSTRIDE, dtype=torch.float32, device=theta.device)
+    out[:, : nd * (nd + 1)] = theta.reshape(B, -1).to(torch.float32)
+    return out
+
+
+def pose_to_theta(pose):
+    """Theta (ref:utils.py:287-310) in plain torch, used only to initialise the device state."""
+    if pose.shape[-1] == 6:
+        psi, th, phi = pose[..., 0], pose[..., 1], pose[..., 2]
+        c, s = torch.cos, torch.sin
+        t = 0.25 * torch.tanh(pose[..., 3:6])
+        rows = [c(psi) * c(th), s(phi) * s(psi) * c(th) - c(phi) * s(th), c(phi) * s(psi) * c(th) + s(phi) * s(th), t[..., 0],
+                c(psi) * s(th), s(phi) * s(psi) * s(th) + c(phi) * c(th), c(phi) * s(psi) * s(th) - s(phi) * c(th), t[..., 1],
+                -s(psi), s(phi) * c(psi), c(phi) * c(psi), t[..., 2]]
+        return torch.stack(rows, dim=-1)
+    a = pose[..., 0]
+    return torch.stack([torch.cos(a), -torch.sin(a), pose[..., 1], torch.sin(a), torch.cos(a), pose[..., 2]], dim=-1)
+
+
+class AffineSolver:
+    """Batched rigid/affine registration state living on the GPU.
+
+    moving, target: [B,1,*spatial] fp32 on the GPU (B independent pairs).
+    mode 'affine': parameters are theta, initialised to identity (or `init` [B,nd,nd+1]).
+    mode 'rigid' : parameters are the pose vector (init [B,6] / [B,3]), theta = Theta(pose).
+    """
+
+    def __init__(self, moving, target, mode="affine", loss=None, optimizer="sgd", lr=1e-5, init=None, capacity=1000,
+                 betas=(0.9, 0.999), eps=1e-8):
+        self.lib = _lib.load()
+        self.batch = _Batch(moving, target)
+        if self.batch.C != 1 or self.batch.target.shape[1] != 1:
+            raise ValueError("the optimiser path takes single-channel volumes [B,1,...]")
+        if self.batch.target.shape[0] != self.batch.B:
+            raise ValueError("moving and target batch sizes differ")
+        b, nd, dev = self.batch.B, self.batch.nd, self.batch.device
+        self.nd, self.mode = nd, mode
+        self.loss = loss or LossSpec(w_mse=1.0)
+        self.opt = opt_cfg(optimizer, lr, betas, eps)
+        nt = nd * (nd + 1)
+        if mode == "affine":
+            th0 = torch.eye(nd, nd + 1, device=dev).repeat(b, 1, 1) if init is None else init.to(dev).reshape(b, nd, nd + 1)
+            self.param = pad_theta(th0, nd)
+            self.theta = self.param.clone()
+        elif mode == "rigid":
+            npose = 6 if nd == 3 else 3
+            if init is None:
+                raise ValueError("rigid mode needs an initial pose (init=[B,%d])" % npose)
+            pose = init.to(device=dev, dtype=torch.float32).reshape(b, npose)
+            self.param = torch.zeros(b, PSTRIDE, device=dev)
+            self.param[:, :npose] = pose
+            self.theta = torch.zeros(b, PSTRIDE, device=dev)
+            # same fp32 -> fp64 -> fp32 chain as the device finalise kernel
+            self.theta[:, :nt] = pose_to_theta(pose.double()).float()
+        else:
+            raise ValueError(f"mode must be 'affine' or 'rigid', got {mode!r}")
+        self.capacity = int(capacity)
+        self.adam_m = torch.zeros(b, PSTRIDE, device=dev)
+        self.adam_v = torch.zeros(b, PSTRIDE, device=dev)
+        self.best_theta = torch.zeros(b, PSTRIDE, device=dev)
+        self.best_loss = torch.full((b,), float("inf"), device=dev)
+        self.best_idx = torch.full((b,), -1, dtype=torch.int32, device=dev)
+        self.losses = torch.full((b, self.capacity), float("nan"), device=dev)
+        self.step = torch.zeros(b, dtype=torch.int32, device=dev)
+        self.grad = torch.zeros(b, PSTRIDE, device=dev)
+        self.vol = self.batch.vol()
+        self.ws_bytes = self.lib.trx_affine_workspace_bytes(ctypes.byref(self.vol))
+        if self.ws_bytes == 0:
+            raise _lib.TrxError("trx_affine_workspace_bytes rejected the batch geometry")
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        st = _lib.AffineState()
+        st.mode = _lib.PARAM_AFFINE if mode == "affine" else _lib.PARAM_RIGID
+        st.param, st.theta = self.param.data_ptr(), self.theta.data_ptr()
+        st.adam_m, st.adam_v = self.adam_m.data_ptr(), self.adam_v.data_ptr()
+        st.best_theta, st.best_loss, st.best_idx = self.best_theta.data_ptr(), self.best_loss.data_ptr(), self.best_idx.data_ptr()
+        st.losses, st.losses_capacity = self.losses.data_ptr(), self.capacity
+        st.step, st.grad = self.step.data_ptr(), self.grad.data_ptr()
+        self.state = st
+        self.loss_c = self.loss.c()
+
+    def run(self, iters):
+        """Enqueue `iters` iterations on the current stream (no host sync)."""
+        with torch.cuda.device(self.batch.device):
+            rc = self.lib.trx_affine_run(ctypes.byref(self.vol), ctypes.byref(self.loss_c), ctypes.byref(self.opt),
+                                         ctypes.byref(self.state), int(iters), _lib.ptr(self.workspace), self.ws_bytes,
+                                         _lib.current_stream(self.batch.device))
+        _lib.check(rc, "trx_affine_run")
+
+    def eval_loss(self, theta=None):
+        """Loss terms [B,4] = (total, mse, ncc, ssd) at `theta` (default: current theta)."""
+        th = self.theta if theta is None else pad_theta(theta.reshape(self.batch.B, -1), self.nd)
+        terms = torch.empty(self.batch.B, 4, device=self.batch.device)
+        with torch.cuda.device(self.batch.device):
+            rc = self.lib.trx_affine_loss(ctypes.byref(self.vol), ctypes.byref(self.loss_c), _lib.ptr(th), _lib.ptr(terms),
+                                          _lib.ptr(self.workspace), self.ws_bytes, _lib.current_stream(self.batch.device))
+        _lib.check(rc, "trx_affine_loss")
+        return terms
+
+    def _unpad(self, t):
+        nd = self.nd
+        return t[:, : nd * (nd + 1)].reshape(-1, nd, nd + 1)
+
+    @property
+    def current_theta(self):
+        return self._unpad(self.theta).clone()
+
+    @property
+    def best(self):
+        return self._unpad(self.best_theta).clone()
+
+
+def affine_warp(theta, moving):
+    """get_affine_warp forward on the GPU: moving [B,C,*sp], theta [B,nd,nd+1] -> warped [B,C,*sp]."""
+    lib = _lib.load()
+    batch = _Batch(moving)
+    th = pad_theta(theta.detach().reshape(batch.B, -1), batch.nd)
+    out = torch.empty_like(batch.moving)
+    vol = batch.vol()
+    with torch.cuda.device(batch.device):
+        rc = lib.trx_affine_warp(ctypes.byref(vol), _lib.ptr(th), batch.C, _lib.ptr(out), _lib.current_stream(batch.device))
+    _lib.check(rc, "trx_affine_warp")
+    return out
+
+
+def affine_warp_backward(theta, moving, grad_out):
+    """d(sum grad_out*warped)/d theta -> [B,nd,nd+1]."""
+    lib = _lib.load()
+    batch = _Batch(moving)
+    _require_gpu(grad_out, "grad_out")
+    th = pad_theta(theta.detach().reshape(batch.B, -1), batch.nd)
+    go = grad_out.contiguous()
+    dth = torch.zeros(batch.B, PSTRIDE, device=batch.device)
+    vol = batch.vol()
+    ws_bytes = lib.trx_affine_workspace_bytes(ctypes.byref(vol))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=batch.device)
+    with torch.cuda.device(batch.device):
+        rc = lib.trx_affine_warp_backward(ctypes.byref(vol), _lib.ptr(th), batch.C, _lib.ptr(go), _lib.ptr(dth), _lib.ptr(ws),
+                                          ws_bytes, _lib.current_stream(batch.device))
+    _lib.check(rc, "trx_affine_warp_backward")
+    nd = batch.nd
+    return dth[:, : nd * (nd + 1)].reshape(batch.B, nd, nd + 1)
+
+
+class FlowSolver:
+    """Direct dense flow-field optimisation (the flow itself is the parameter), batched."""
+
+    def __init__(self, moving, target, loss=None, optimizer="sgd", lr=1e-3, init=None, capacity=1000, smooth_weight=0.0,
+                 betas=(0.9, 0.999), eps=1e-8):
+        self.lib = _lib.load()
+        self.batch = _Batch(moving, target, tables=False)
+        if self.batch.C != 1:
+            raise ValueError("the optimiser path takes single-channel volumes [B,1,...]")
+        b, nd, dev = self.batch.B, self.batch.nd, self.batch.device
+        self.nd = nd
+        self.loss = loss or LossSpec(w_mse=1.0)
+        self.loss_c = self.loss.c()
+        self.opt = opt_cfg(optimizer, lr, betas, eps)
+        shape = (b, nd) + self.batch.spatial
+        self.flow = torch.zeros(shape, device=dev) if init is None else init.to(device=dev, dtype=torch.float32).reshape(shape).contiguous().clone()
+        adam = self.opt.kind == _lib.OPT_ADAM
+        self.adam_m = torch.zeros(shape, device=dev) if adam else None
+        self.adam_v = torch.zeros(shape, device=dev) if adam else None
+        self.flow_tmp = torch.empty(shape, device=dev) if smooth_weight else None
+        self.capacity = int(capacity)
+        self.losses = torch.full((b, self.capacity), float("nan"), device=dev)
+        self.step = torch.zeros(b, dtype=torch.int32, device=dev)
+        self.vol = self.batch.vol()
+        self.ws_bytes = self.lib.trx_flow_workspace_bytes(ctypes.byref(self.vol))
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        st = _lib.FlowState()
+        st.flow = self.flow.data_ptr()
+        st.flow_tmp = self.flow_tmp.data_ptr() if self.flow_tmp is not None else None
+        st.adam_m = self.adam_m.data_ptr() if adam else None
+        st.adam_v = self.adam_v.data_ptr() if adam else None
+        st.losses, st.losses_capacity, st.step = self.losses.data_ptr(), self.capacity, self.step.data_ptr()
+        st.smooth_weight = float(smooth_weight)
+        self.state = st
+
+    def run(self, iters):
+        with torch.cuda.device(self.batch.device):
+            rc = self.lib.trx_flow_run(ctypes.byref(self.vol), ctypes.byref(self.loss_c), ctypes.byref(self.opt),
+                                       ctypes.byref(self.state), int(iters), _lib.ptr(self.workspace), self.ws_bytes,
+                                       _lib.current_stream(self.batch.device))
+        _lib.check(rc, "trx_flow_run")
+
+
+def flow_warp(moving, flow):
+    """SpatialTransformer forward: moving [B,C,*sp], flow [B,nd,*sp] -> [B,C,*sp]."""
+    lib = _lib.load()
+    batch = _Batch(moving, tables=False)
+    _require_gpu(flow, "flow")
+    fl = flow.detach().contiguous()
+    if fl.shape != (batch.B, batch.nd) + batch.spatial:
+        raise ValueError(f"flow shape {tuple(fl.shape)} does not match moving {tuple(moving.shape)}")
+    out = torch.empty_like(batch.moving)
+    vol = batch.vol()
+    with torch.cuda.device(batch.device):
+        rc = lib.trx_flow_warp(ctypes.byref(vol), _lib.ptr(fl), batch.C, _lib.ptr(out), _lib.current_stream(batch.device))
+    _lib.check(rc, "trx_flow_warp")
+    return out
+
+
+def flow_warp_backward(moving, flow, grad_out):
+    lib = _lib.load()
+    batch = _Batch(moving, tables=False)
+    fl, go = flow.detach().contiguous(), grad_out.contiguous()
+    dfl = torch.empty_like(fl)
+    vol = batch.vol()
+    with torch.cuda.device(batch.device):
+        rc = lib.trx_flow_warp_backward(ctypes.byref(vol), _lib.ptr(fl), batch.C, _lib.ptr(go), _lib.ptr(dfl),
+                                        _lib.current_stream(batch.device))
+    _lib.check(rc, "trx_flow_warp_backward")
+    return dfl
+
+
+def flow_loss_grad(moving, target, flow, loss, need_grad=True):
+    """Fused loss (+ dL/dflow) for a given flow: returns (terms [B,4], dflow or None)."""
+    lib = _lib.load()
+    batch = _Batch(moving, target, tables=False)
+    fl = flow.detach().contiguous()
+    terms = torch.empty(batch.B, 4, device=batch.device)
+    dfl = torch.empty_like(fl) if need_grad else None
+    vol = batch.vol()
+    ws_bytes = lib.trx_flow_workspace_bytes(ctypes.byref(vol))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=batch.device)
+    lc = loss.c()
+    with torch.cuda.device(batch.device):
+        rc = lib.trx_flow_loss_grad(ctypes.byref(vol), ctypes.byref(lc), _lib.ptr(fl), _lib.ptr(terms), _lib.ptr(dfl), _lib.ptr(ws),
+                                    ws_bytes, _lib.current_stream(batch.device))
+    _lib.check(rc, "trx_flow_loss_grad")
+    return terms, dfl

@@ -1,0 +1,418 @@
+// Dense flow-field hot path for gfx950 (SpatialTransformer semantics, ref:utils.py:339-365):
+// sample moving at voxel coordinate p + flow(p) (the reference's normalise + align_corners=True
+// un-normalise cancel exactly), zeros outside.  d out / d flow_c is the plain trilinear
+// derivative along spatial dim c.
+//
+// One optimiser iteration (F2) = two streaming passes + one tiny kernel:
+//   pass A  flow_moments_kernel : sample, accumulate {Sy,Sw,Syy,Sww,Syw} (+ smoothness sums)
+//   coef    flow_coef_kernel    : fp64 reduce -> loss, NCC/MSE/SSD gradient coefficients, Adam scalars
+//   pass B  flow_update_kernel  : re-sample + derivative, dL/dflow, SGD/Adam update in place
+// replacing SpatialTransformer.forward -> criterion -> backward -> optimizer.step of
+// ref:warpings.py:208-220 when the parameter is the flow itself.
+#include "trx_common.h"
+
+namespace trx {
+
+struct FlowCoef {   // per pair, written by flow_coef_kernel, read by pass B (wave-uniform)
+    float k1, k2, my, mw, q;   // dL/dw_p = k1*(y-my) + k2*(w-mw) + q*(w-y)
+    float step_size, inv_sqrt_bc2, sm[3];  // Adam scalars; smoothness gradient scale per dim
+};
+
+__device__ __forceinline__ void decode(size_t i, int H, int W, int &z, int &y, int &x)
+{
+    x = (int)(i % W);
+    const size_t r = i / W;
+    y = (int)(r % H);
+    z = (int)(r / H);
+}
+
+// sample at p + flow; returns value and derivative in flow-channel order (dim0, dim1[, dim2])
+template <int ND>
+__device__ __forceinline__ float flow_sample(const float *__restrict__ mov, const float *__restrict__ fl, size_t nvox,
+                                             size_t i, int D, int H, int W, int z, int y, int x, float *d)
+{
+    if constexpr (ND == 3) {
+        const float iz = (float)z + fl[i], iy = (float)y + fl[nvox + i], ix = (float)x + fl[2 * nvox + i];
+        Samp3 s = sample3(mov, D, H, W, ix, iy, iz);
+        d[0] = s.dz; d[1] = s.dy; d[2] = s.dx;
+        return s.v;
+    } else {
+        const float iy = (float)y + fl[i], ix = (float)x + fl[nvox + i];
+        Samp2 s = sample2(mov, H, W, ix, iy);
+        d[0] = s.dy; d[1] = s.dx;
+        return s.v;
+    }
+}
+
+constexpr int kFlowNP = 8;  // 5 moments + up to 3 smoothness sums
+
+template <int ND, bool SMOOTH>
+__global__ __launch_bounds__(TRX_BLOCK) void flow_moments_kernel(trx_volumes vol, const float *__restrict__ flow,
+                                                                 float *__restrict__ partials)
+{
+    const int b = blockIdx.y;
+    const int D = vol.D, H = vol.H, W = vol.W;
+    const size_t nvox = (size_t)D * H * W;
+    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
+    const float *__restrict__ tgt = vol.target + (size_t)b * vol.target_stride;
+    const float *__restrict__ fl = flow + (size_t)b * ND * nvox;
+    float vals[kFlowNP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t dstride[3] = {ND == 3 ? (size_t)H * W : (size_t)W, ND == 3 ? (size_t)W : 1, 1};
+    for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
+        int z, y, x;
+        decode(i, H, W, z, y, x);
+        float d[3];
+        const float w = flow_sample<ND>(mov, fl, nvox, i, D, H, W, z, y, x, d);
+        const float yv = tgt[i];
+        vals[0] += yv; vals[1] += w;
+        vals[2] = fmaf(yv, yv, vals[2]); vals[3] = fmaf(w, w, vals[3]); vals[4] = fmaf(yv, w, vals[4]);
+        if constexpr (SMOOTH) {
+            const int pos[3] = {ND == 3 ? z : y, ND == 3 ? y : x, x};
+            const int ext[3] = {ND == 3 ? D : H, ND == 3 ? H : W, W};
+#pragma unroll
+            for (int dd = 0; dd < ND; dd++)
+                if (pos[dd] + 1 < ext[dd]) {
+#pragma unroll
+                    for (int c = 0; c < ND; c++) {
+                        const float df = fl[c * nvox + i + dstride[dd]] - fl[c * nvox + i];
+                        vals[5 + dd] = fmaf(df, df, vals[5 + dd]);
+                    }
+                }
+        }
+    }
+    block_reduce_store<kFlowNP, 8>(vals, partials + ((size_t)b * gridDim.x + blockIdx.x) * kFlowNP);
+}
+
+__global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict__ partials, int nblk, int ndim, int D, int H,
+                                                         int W, trx_loss_cfg lc, trx_opt_cfg oc, float smooth_weight,
+                                                         float *__restrict__ losses, int losses_capacity, int *__restrict__ step,
+                                                         float *__restrict__ terms, FlowCoef *__restrict__ coef)
+{
+    __shared__ double acc[16][8];
+    const int b = blockIdx.x, tid = threadIdx.x, k = tid & 7, grp = tid >> 3;  // 128 groups of 8
+    double s = 0.0;
+    for (int blk = grp; blk < nblk; blk += 128) s += (double)partials[((size_t)b * nblk + blk) * kFlowNP + k];
+    // reduce the 128 groups: lanes k, k+8, ... hold the same component
+    for (int off = 32; off >= 8; off >>= 1) s += __shfl_down(s, off);
+    if ((tid & 63) < 8) acc[tid >> 6][k] = s;
+    __syncthreads();
+    if (tid != 0) return;
+    double S[8];
+    for (int j = 0; j < 8; j++) {
+        double t = 0.0;
+        for (int wv = 0; wv < 16; wv++) t += acc[wv][j];
+        S[j] = t;
+    }
+    const double n = (double)D * H * W;
+    const double Sy = S[0], Sw = S[1], Syy = S[2], Sww = S[3], Syw = S[4];
+    const double my = Sy / n, mw = Sw / n;
+    const double Saa = Syy - Sy * my, Sbb = Sww - Sw * mw, Sab = Syw - Sy * mw;
+    const double sd = sqrt(Saa * Sbb + 1e-10);
+    const double alpha = lc.ncc_alpha, sq = Syy - 2.0 * Syw + Sww;
+    const double mse = sq / n, ncc = alpha * (1.0 - Sab / sd), ssd = (double)lc.ssd_alpha * sq;
+    double total = (double)lc.w_mse * mse + (double)lc.w_ncc * ncc + (double)lc.w_ssd * ssd;
+    // smoothness (extension): lambda/ndim * sum_d mean_{c,p}(forward difference along d)^2
+    const int ext[3] = {ndim == 3 ? D : H, ndim == 3 ? H : W, W};
+    FlowCoef c;
+    c.sm[0] = c.sm[1] = c.sm[2] = 0.f;
+    if (smooth_weight != 0.f) {
+        double reg = 0.0;
+        for (int dd = 0; dd < ndim; dd++) {
+            const double cnt = (double)ndim * n / ext[dd] * (ext[dd] - 1);
+            if (cnt > 0) {
+                reg += S[5 + dd] / cnt;
+                c.sm[dd] = (float)((double)smooth_weight / ndim * 2.0 / cnt);
+            }
+        }
+        total += (double)smooth_weight / ndim * reg;
+    }
+    c.k1 = (float)((double)lc.w_ncc * (-alpha / sd));
+    c.k2 = (float)((double)lc.w_ncc * (alpha * Sab * Saa / (sd * sd * sd)));
+    c.my = (float)my; c.mw = (float)mw;
+    c.q = (float)((double)lc.w_mse * 2.0 / n + (double)lc.w_ssd * (double)lc.ssd_alpha * 2.0);
+    int t = step ? step[b] : 0;
+    if (oc.kind == TRX_OPT_ADAM) {
+        const double bc1 = 1.0 - pow((double)oc.beta1, (double)(t + 1)), bc2 = 1.0 - pow((double)oc.beta2, (double)(t + 1));
+        c.step_size = (float)((double)oc.lr / bc1);
+        c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    } else {
+        c.step_size = oc.lr;
+        c.inv_sqrt_bc2 = 1.f;
+    }
+    coef[b] = c;
+    if (losses && t < losses_capacity) losses[(size_t)b * losses_capacity + t] = (float)total;
+    if (step) step[b] = t + 1;
+    if (terms) {
+        terms[b * 4 + 0] = (float)total; terms[b * 4 + 1] = (float)mse;
+        terms[b * 4 + 2] = (float)ncc;   terms[b * 4 + 3] = (float)ssd;
+    }
+}
+
+// MODE 0: optimiser update (SGD/Adam) written to flow_out;  MODE 1: write the gradient to flow_out
+template <int ND, int MODE, bool SMOOTH>
+__global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol, const float *flow,
+                                                                float *flow_out, float *__restrict__ adam_m,
+                                                                float *__restrict__ adam_v, const FlowCoef *__restrict__ coef,
+                                                                trx_opt_cfg oc)
+{
+    const int b = blockIdx.y;
+    const int D = vol.D, H = vol.H, W = vol.W;
+    const size_t nvox = (size_t)D * H * W;
+    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
+    const float *__restrict__ tgt = vol.target + (size_t)b * vol.target_stride;
+    const float *fl = flow + (size_t)b * ND * nvox;   // may alias fo (in-place update): no restrict
+    float *fo = flow_out + (size_t)b * ND * nvox;
+    const FlowCoef c = coef[b];
+    const size_t dstride[3] = {ND == 3 ? (size_t)H * W : (size_t)W, ND == 3 ? (size_t)W : 1, 1};
+    for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
+        int z, y, x;
+        decode(i, H, W, z, y, x);
+        float d[3];
+        const float w = flow_sample<ND>(mov, fl, nvox, i, D, H, W, z, y, x, d);
+        const float yv = tgt[i];
+        const float go = fmaf(c.k1, yv - c.my, fmaf(c.k2, w - c.mw, c.q * (w - yv)));
+#pragma unroll
+        for (int ch = 0; ch < ND; ch++) {
+            float g = go * d[ch];
+            const float f0 = fl[ch * nvox + i];
+            if constexpr (SMOOTH) {
+                const int pos[3] = {ND == 3 ? z : y, ND == 3 ? y : x, x};
+                const int ext[3] = {ND == 3 ? D : H, ND == 3 ? H : W, W};
+#pragma unroll
+                for (int dd = 0; dd < ND; dd++) {
+                    float a = 0.f;
+                    if (pos[dd] > 0) a += f0 - fl[ch * nvox + i - dstride[dd]];
+                    if (pos[dd] + 1 < ext[dd]) a -= fl[ch * nvox + i + dstride[dd]] - f0;
+                    g = fmaf(c.sm[dd], a, g);
+                }
+            }
+            if constexpr (MODE == 1) {
+                fo[ch * nvox + i] = g;
+            } else {
+                float p = f0;
+                if (oc.kind == TRX_OPT_ADAM) {
+                    float *mm = adam_m + (size_t)b * ND * nvox + ch * nvox + i, *vv = adam_v + (size_t)b * ND * nvox + ch * nvox + i;
+                    const float mi = *mm + (g - *mm) * (1.0f - oc.beta1);
+                    const float vi = oc.beta2 * *vv + (1.0f - oc.beta2) * g * g;
+                    *mm = mi; *vv = vi;
+                    const float denom = sqrtf(vi) * c.inv_sqrt_bc2 + oc.eps;
+                    p = p - c.step_size * (mi / denom);
+                } else {
+                    p = p - c.step_size * g;
+                }
+                fo[ch * nvox + i] = p;
+            }
+        }
+    }
+}
+
+template <int ND>
+__global__ __launch_bounds__(TRX_BLOCK) void flow_warp_kernel(trx_volumes vol, const float *__restrict__ flow, int channels,
+                                                              float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int D = vol.D, H = vol.H, W = vol.W;
+    const size_t nvox = (size_t)D * H * W;
+    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
+    const float *__restrict__ fl = flow + (size_t)b * ND * nvox;
+    float *__restrict__ o = out + (size_t)b * channels * nvox;
+    for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
+        int z, y, x;
+        decode(i, H, W, z, y, x);
+        float d[3];
+        for (int ch = 0; ch < channels; ch++) o[ch * nvox + i] = flow_sample<ND>(mov + ch * nvox, fl, nvox, i, D, H, W, z, y, x, d);
+    }
+}
+
+template <int ND>
+__global__ __launch_bounds__(TRX_BLOCK) void flow_warp_bwd_kernel(trx_volumes vol, const float *__restrict__ flow, int channels,
+                                                                  const float *__restrict__ grad_out, float *__restrict__ dflow)
+{
+    const int b = blockIdx.y;
+    const int D = vol.D, H = vol.H, W = vol.W;
+    const size_t nvox = (size_t)D * H * W;
+    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
+    const float *__restrict__ fl = flow + (size_t)b * ND * nvox;
+    const float *__restrict__ go = grad_out + (size_t)b * channels * nvox;
+    float *__restrict__ df = dflow + (size_t)b * ND * nvox;
+    for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
+        int z, y, x;
+        decode(i, H, W, z, y, x);
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int ch = 0; ch < channels; ch++) {
+            float d[3];
+            flow_sample<ND>(mov + ch * nvox, fl, nvox, i, D, H, W, z, y, x, d);
+            const float g = go[ch * nvox + i];
+#pragma unroll
+            for (int c = 0; c < ND; c++) acc[c] = fmaf(g, d[c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < ND; c++) df[c * nvox + i] = acc[c];
+    }
+}
+
+static int check_vol_flow(const trx_volumes *v, bool need_target)
+{
+    if (!v || !v->moving || (need_target && !v->target)) return TRX_ERR_ARG;
+    if (v->ndim != 2 && v->ndim != 3) return TRX_ERR_NDIM;
+    if (v->B < 1 || v->D < 1 || v->H < 1 || v->W < 1 || v->B > 65535) return TRX_ERR_ARG;
+    if (v->ndim == 2 && v->D != 1) return TRX_ERR_NDIM;
+    return TRX_OK;
+}
+
+static unsigned flow_grid_x(const trx_volumes &v)
+{
+    const size_t nvox = (size_t)v.D * v.H * v.W;
+    size_t nb = (nvox + TRX_BLOCK - 1) / TRX_BLOCK;
+    size_t cap = (size_t)(4096 + v.B - 1) / v.B;  // ~4096 blocks in flight overall
+    if (cap < 64) cap = 64;
+    return (unsigned)(nb < cap ? nb : cap);
+}
+
+}  // namespace trx
+
+using namespace trx;
+
+extern "C" size_t trx_flow_workspace_bytes(const trx_volumes *vol)
+{
+    if (check_vol_flow(vol, false) != TRX_OK) return 0;
+    return (size_t)vol->B * flow_grid_x(*vol) * kFlowNP * sizeof(float) + (size_t)vol->B * sizeof(FlowCoef) + 256;
+}
+
+static FlowCoef *coef_ptr(const trx_volumes *vol, void *workspace)
+{
+    size_t off = (size_t)vol->B * flow_grid_x(*vol) * kFlowNP * sizeof(float);
+    off = (off + 255) & ~(size_t)255;
+    return (FlowCoef *)((char *)workspace + off);
+}
+
+static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth, float *partials, hipStream_t s)
+{
+    dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
+    if (vol->ndim == 3) {
+        if (smooth) hipLaunchKernelGGL((flow_moments_kernel<3, true>), grid, block, 0, s, *vol, flow, partials);
+        else hipLaunchKernelGGL((flow_moments_kernel<3, false>), grid, block, 0, s, *vol, flow, partials);
+    } else {
+        if (smooth) hipLaunchKernelGGL((flow_moments_kernel<2, true>), grid, block, 0, s, *vol, flow, partials);
+        else hipLaunchKernelGGL((flow_moments_kernel<2, false>), grid, block, 0, s, *vol, flow, partials);
+    }
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+template <int MODE>
+static int launch_update(const trx_volumes *vol, const float *flow, float *flow_out, float *m, float *v, const FlowCoef *coef,
+                         const trx_opt_cfg &oc, bool smooth, hipStream_t s)
+{
+    dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
+    if (vol->ndim == 3) {
+        if (smooth) hipLaunchKernelGGL((flow_update_kernel<3, MODE, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc);
+        else hipLaunchKernelGGL((flow_update_kernel<3, MODE, false>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc);
+    } else {
+        if (smooth) hipLaunchKernelGGL((flow_update_kernel<2, MODE, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc);
+        else hipLaunchKernelGGL((flow_update_kernel<2, MODE, false>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc);
+    }
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+static int flow_step_impl(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_flow_state *st,
+                          float *cur, float *nxt, void *workspace, hipStream_t s)
+{
+    const bool smooth = st->smooth_weight != 0.f;
+    float *partials = (float *)workspace;
+    FlowCoef *coef = coef_ptr(vol, workspace);
+    int rc = launch_moments(vol, cur, smooth, partials, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, partials, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
+                       vol->W, *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef);
+    TRX_CHECK_LAUNCH();
+    return launch_update<0>(vol, cur, nxt, st->adam_m, st->adam_v, coef, *opt, smooth, s);
+}
+
+static int check_flow_args(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_flow_state *st,
+                           void *workspace, size_t workspace_bytes)
+{
+    int rc = check_vol_flow(vol, true);
+    if (rc) return rc;
+    if (!loss || !opt || !st || !workspace || !st->flow) return TRX_ERR_ARG;
+    if (opt->kind != TRX_OPT_SGD && opt->kind != TRX_OPT_ADAM) return TRX_ERR_ARG;
+    if (opt->kind == TRX_OPT_ADAM && (!st->adam_m || !st->adam_v)) return TRX_ERR_ARG;
+    if (st->smooth_weight != 0.f && !st->flow_tmp) return TRX_ERR_ARG;
+    if (workspace_bytes < trx_flow_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
+    return TRX_OK;
+}
+
+extern "C" int trx_flow_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_flow_state *st,
+                            int iters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_flow_args(vol, loss, opt, st, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (iters < 0) return TRX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bool smooth = st->smooth_weight != 0.f;
+    float *cur = st->flow, *nxt = smooth ? st->flow_tmp : st->flow;
+    for (int i = 0; i < iters; i++) {
+        rc = flow_step_impl(vol, loss, opt, st, cur, nxt, workspace, s);
+        if (rc) return rc;
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != st->flow) {  // odd number of double-buffered steps: result lives in flow_tmp
+        const size_t bytes = (size_t)vol->B * vol->ndim * vol->D * vol->H * vol->W * sizeof(float);
+        if (hipMemcpyAsync(st->flow, cur, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return TRX_ERR_HIP;
+    }
+    return TRX_OK;
+}
+
+extern "C" int trx_flow_step(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_flow_state *st,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    return trx_flow_run(vol, loss, opt, st, 1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int trx_flow_loss_grad(const trx_volumes *vol, const trx_loss_cfg *loss, const float *flow, float *terms, float *dflow,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_vol_flow(vol, true);
+    if (rc) return rc;
+    if (!loss || !flow || !terms || !workspace) return TRX_ERR_ARG;
+    if (workspace_bytes < trx_flow_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float *partials = (float *)workspace;
+    FlowCoef *coef = coef_ptr(vol, workspace);
+    rc = launch_moments(vol, flow, false, partials, s);
+    if (rc) return rc;
+    trx_opt_cfg oc = {TRX_OPT_SGD, 0.f, 0.f, 0.f, 0.f};
+    hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, partials, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
+                       vol->W, *loss, oc, 0.f, (float *)nullptr, 0, (int *)nullptr, terms, coef);
+    TRX_CHECK_LAUNCH();
+    if (!dflow) return TRX_OK;
+    return launch_update<1>(vol, flow, dflow, nullptr, nullptr, coef, oc, false, s);
+}
+
+extern "C" int trx_flow_warp(const trx_volumes *vol, const float *flow, int channels, float *out, void *stream)
+{
+    int rc = check_vol_flow(vol, false);
+    if (rc) return rc;
+    if (!flow || !out || channels < 1) return TRX_ERR_ARG;
+    dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    if (vol->ndim == 3) hipLaunchKernelGGL((flow_warp_kernel<3>), grid, block, 0, s, *vol, flow, channels, out);
+    else hipLaunchKernelGGL((flow_warp_kernel<2>), grid, block, 0, s, *vol, flow, channels, out);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+extern "C" int trx_flow_warp_backward(const trx_volumes *vol, const float *flow, int channels, const float *grad_out, float *dflow,
+                                      void *stream)
+{
+    int rc = check_vol_flow(vol, false);
+    if (rc) return rc;
+    if (!flow || !grad_out || !dflow || channels < 1) return TRX_ERR_ARG;
+    dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    if (vol->ndim == 3) hipLaunchKernelGGL((flow_warp_bwd_kernel<3>), grid, block, 0, s, *vol, flow, channels, grad_out, dflow);
+    else hipLaunchKernelGGL((flow_warp_bwd_kernel<2>), grid, block, 0, s, *vol, flow, channels, grad_out, dflow);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
