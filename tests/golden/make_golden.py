@@ -354,6 +354,7 @@ def main():
     flow_deform_semantics(ss)
     ss["ncc_self"] = npf(tr.NCCLoss()(ph.vol((5, 6, 7), 0.37), ph.vol((5, 6, 7), 0.37)))
     ss["norm124"] = npf(tr.norm(torch.tensor([1.0, 2.0, 4.0])))
+    ss["nmi2d"] = npf(tr.NMILoss()(ph.blobs((32, 32), 1), ph.blobs((32, 32), 2)))
 
     tj = {}
     print("trajectories")

@@ -1,0 +1,152 @@
+"""GPU parity: the HIP dense-flow path (SpatialTransformer semantics) vs oracle + golden vectors.
+
+Tolerances as in test_gpu_affine.py (fp32; bar = max(stated floor, 2x the reference's own
+fp32-vs-fp64 gap)).  The smoothness regulariser and Adam are extensions that the reference does
+not have ("parity unpinned"): they are checked against plain torch autograd / torch.optim.Adam.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import phantoms as ph
+from conftest import bar
+
+pytestmark = pytest.mark.gpu
+
+FLOW_CASES = ["D3", "D2", "F3", "F2"]
+LOSSES = {"ncc": dict(w_ncc=1.0), "mse": dict(w_mse=1.0)}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torchregister_amd._engine as e
+    assert torch.cuda.is_available()
+    return e
+
+
+def _mt(shape):
+    return ph.vol(shape, 0.37, "sin"), ph.vol(shape, 0.23, "cos")
+
+
+@pytest.mark.parametrize("case", FLOW_CASES)
+def test_flow_warp_and_grad_vs_golden(eng, single_step, case):
+    g = single_step
+    shape = tuple(g[f"{case}/shape"])
+    mov, tgt = _mt(shape)
+    fl = ph.flow_field(shape, float(g[f"{case}/amp"]))
+    w = eng.flow_warp(mov.cuda(), fl.cuda()).cpu().numpy()
+    g32, g64 = g[f"{case}/warped32"], g[f"{case}/warped64"]
+    assert np.max(np.abs(w - g32)) <= bar(g32, g64, 2e-6)
+    for lname, kw in LOSSES.items():
+        terms, dfl = eng.flow_loss_grad(mov.cuda(), tgt.cuda(), fl.cuda(), eng.LossSpec(**kw))
+        l32, l64 = float(g[f"{case}/{lname}32"]), float(g[f"{case}/{lname}64"])
+        d32, d64 = g[f"{case}/d{lname}32"], g[f"{case}/d{lname}64"]
+        assert abs(terms[0, 0].item() - l32) <= bar(l32, l64, 2e-5 * max(1.0, abs(l64)))
+        assert np.max(np.abs(dfl.cpu().numpy() - d32)) <= bar(d32, d64, 1e-4 * np.max(np.abs(d64)))
+
+
+@pytest.mark.parametrize("case", ["D3", "F2"])
+def test_flow_warp_backward_generic(eng, single_step, case):
+    """Generic warp backward with grad_out = dMSE/dwarped reproduces the golden dMSE/dflow."""
+    g = single_step
+    shape = tuple(g[f"{case}/shape"])
+    mov, tgt = _mt(shape)
+    fl = ph.flow_field(shape, float(g[f"{case}/amp"])).cuda()
+    w = eng.flow_warp(mov.cuda(), fl)
+    go = 2.0 * (w - tgt.cuda()) / w.numel()
+    dfl = eng.flow_warp_backward(mov.cuda(), fl, go).cpu().numpy()
+    d32, d64 = g[f"{case}/dmse32"], g[f"{case}/dmse64"]
+    assert np.max(np.abs(dfl - d32)) <= bar(d32, d64, 1e-4 * np.max(np.abs(d64)))
+
+
+def test_flow_multichannel_deform(eng, single_step):
+    """Register.__call__ in flow mode: every channel warped by the same flow (ref:torchregister.py:123-126)."""
+    g = single_step
+    shape = tuple(g["deform/shape"])
+    x = torch.cat([ph.vol(shape, 0.37, "sin"), ph.vol(shape, 0.23, "cos")], dim=1)
+    fl = ph.flow_field(shape, 1.1, 0.07)
+    w = eng.flow_warp(x.cuda(), fl.cuda()).cpu().numpy()
+    assert np.max(np.abs(w - g["deform/call2c"])) <= 2e-6
+
+
+@pytest.mark.parametrize("name,loss", [("c_flow3d_ncc", "ncc"), ("c_flow3d_mse", "mse"), ("c_flow2d_ncc", "ncc")])
+def test_flow_trajectories_vs_golden(eng, trajectories, name, loss):
+    g = trajectories
+    lr, iters = float(g[f"{name}/meta"][0]), int(g[f"{name}/meta"][1])
+    shape = tuple(g[f"{name}/shape"])
+    seed = int(g[f"{name}/meta"][2])
+    mov, tgt = torch.from_numpy(g[f"{name}/moving"]), ph.blobs(shape, 1000 + seed)
+    s = eng.FlowSolver(mov.cuda(), tgt.cuda(), loss=eng.LossSpec(**LOSSES[loss]), lr=lr, capacity=iters)
+    s.run(iters)
+    torch.cuda.synchronize()
+    losses = s.losses[0].cpu().numpy().astype(np.float64)
+    l32, l64 = g[f"{name}/losses32"], g[f"{name}/losses64"]
+    assert np.max(np.abs(losses - l32)) <= bar(l32, l64, 1e-4 * np.max(np.abs(l64)))
+    f32, f64 = g[f"{name}/flow32"], g[f"{name}/flow64"]
+    assert np.max(np.abs(s.flow.cpu().numpy() - f32)) <= bar(f32, f64, 1e-4)
+    w = eng.flow_warp(mov.cuda(), s.flow).cpu().numpy()
+    assert np.max(np.abs(w - g[f"{name}/final_warped32"])) <= bar(g[f"{name}/final_warped32"], g[f"{name}/final_warped64"], 1e-4)
+
+
+def _torch_flow_ref(mov, tgt, lr, iters, optimizer, smooth, dtype):
+    """Plain-torch reference of the extensions (Adam, smoothness) on CPU."""
+    from oracle import compose
+    nd = mov.dim() - 2
+    mov, tgt = mov.to(dtype), tgt.to(dtype)
+    fl = torch.zeros(1, nd, *mov.shape[2:], dtype=dtype, requires_grad=True)
+    opt = torch.optim.SGD([fl], lr) if optimizer == "sgd" else torch.optim.Adam([fl], lr)
+    losses = []
+    for _ in range(iters):
+        opt.zero_grad()
+        e = compose.ncc_loss(tgt, compose.flow_warp(mov, fl))
+        if smooth:
+            reg = 0.0
+            for d in range(nd):
+                df = fl.diff(dim=2 + d)
+                reg = reg + (df * df).mean()
+            e = e + smooth * reg / nd
+        e.backward()
+        opt.step()
+        losses.append(e.item())
+    return np.asarray(losses), fl.detach().numpy()
+
+
+@pytest.mark.parametrize("optimizer,smooth", [("sgd", 5.0), ("adam", 0.0), ("adam", 2.0)])
+def test_flow_extensions_vs_torch(eng, optimizer, smooth):
+    shape = (12, 14, 16)
+    from oracle import compose
+    tgt = ph.blobs(shape, 1009)
+    mov = compose.affine_warp(torch.tensor(ph.THETA_STAR3)[None], tgt)
+    lr, iters = (1.0, 15) if optimizer == "sgd" else (0.05, 15)
+    l32, f32 = _torch_flow_ref(mov, tgt, lr, iters, optimizer, smooth, torch.float32)
+    l64, f64 = _torch_flow_ref(mov, tgt, lr, iters, optimizer, smooth, torch.float64)
+    s = eng.FlowSolver(mov.cuda(), tgt.cuda(), loss=eng.LossSpec(w_ncc=1.0), optimizer=optimizer, lr=lr, capacity=iters,
+                       smooth_weight=smooth)
+    s.run(iters)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(s.losses[0].cpu().numpy() - l32)) <= bar(l32, l64, 1e-4 * np.max(np.abs(l64)))
+    assert np.max(np.abs(s.flow.cpu().numpy() - f32)) <= bar(f32, f64, 2e-4)
+
+
+def test_flow_full_size_properties(eng):
+    """256^3: zero flow reproduces moving exactly; integer shift flow == slicing; run is deterministic."""
+    shape = (256, 256, 256)
+    mov = ph.blobs(shape, 1000).cuda()
+    zero = torch.zeros(1, 3, *shape, device="cuda")
+    assert torch.equal(eng.flow_warp(mov, zero), mov)
+    fl = zero.clone()
+    fl[:, 0] = 2.0
+    fl[:, 2] = -3.0
+    w = eng.flow_warp(mov, fl)
+    assert torch.equal(w[0, 0, :-2, :, 3:], mov[0, 0, 2:, :, :-3])
+    assert torch.count_nonzero(w[0, 0, -2:]).item() == 0 and torch.count_nonzero(w[0, 0, :, :, :3]).item() == 0
+    tgt = ph.blobs(shape, 1001).cuda()
+    outs = []
+    for _ in range(2):
+        s = eng.FlowSolver(mov, tgt, loss=eng.LossSpec(w_ncc=1.0), lr=10.0, capacity=3)
+        s.run(3)
+        torch.cuda.synchronize()
+        outs.append((s.losses.clone(), s.flow.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0][0, 2].item() < outs[0][0][0, 0].item()

@@ -1,0 +1,113 @@
+// Standalone kernel micro-benchmark (development tool, not shipped): times the product kernels
+// and experimental variants on B pairs of S^3 random volumes with hipEvents.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kbench.hip -o build/kbench && build/kbench 8 256
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../torchregister_amd/csrc/affine.hip"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+// E1: streaming skeleton — aligned read of moving + target, 5 moments, same block geometry
+__global__ __launch_bounds__(256) void skel_kernel(trx_volumes vol, trx::AffineGeom g, float *partials)
+{
+    const int b = blockIdx.y;
+    int id = blockIdx.x;
+    const int xs = id % g.nxseg; id /= g.nxseg;
+    const int yc = id % g.nychunk;
+    const int z = id / g.nychunk;
+    const int tid = threadIdx.x;
+    const int lx = tid & (g.TX - 1), ly = tid >> g.logTX;
+    const int x = xs * g.TX + lx;
+    const int H = vol.H, W = vol.W;
+    const float *mov = vol.moving + (size_t)b * vol.moving_stride;
+    const float *tgt = vol.target + (size_t)b * vol.target_stride;
+    float m[5] = {0, 0, 0, 0, 0};
+    if (x < W) {
+        const int y0 = yc * g.TY * g.RPT + ly;
+        for (int j = 0; j < g.RPT; j++) {
+            const int y = y0 + j * g.TY;
+            if (y >= H) break;
+            const size_t vox = ((size_t)z * H + y) * W + x;
+            const float yv = tgt[vox], w = mov[vox];
+            m[0] += yv; m[1] += w; m[2] = fmaf(yv, yv, m[2]); m[3] = fmaf(w, w, m[3]); m[4] = fmaf(yv, w, m[4]);
+        }
+    }
+    trx::block_reduce_store<5>(m, partials + ((size_t)b * g.nblk + blockIdx.x) * 5);
+}
+
+// E1b: float4 grid-stride skeleton (best-case streaming read of both volumes)
+__global__ __launch_bounds__(256) void skel4_kernel(const float4 *a, const float4 *b, size_t n4, float *partials)
+{
+    float m[5] = {0, 0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 u = a[i], v = b[i];
+        m[0] += u.x + u.y + u.z + u.w; m[1] += v.x + v.y + v.z + v.w;
+        m[2] += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w; m[3] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        m[4] += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    }
+    trx::block_reduce_store<5>(m, partials + (size_t)blockIdx.x * 5);
+}
+
+template <typename F>
+static float time_it(F f, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    f(); f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; i++) f();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1000.f / reps;
+}
+
+int main(int argc, char **argv)
+{
+    int B = argc > 1 ? atoi(argv[1]) : 8, S = argc > 2 ? atoi(argv[2]) : 256;
+    int tb = argc > 3 ? atoi(argv[3]) : trx::kTargetBlocks;
+    size_t nvox = (size_t)S * S * S, n = nvox * B;
+    std::vector<float> h(n);
+    srand(1);
+    for (size_t i = 0; i < n; i++) h[i] = (float)rand() / RAND_MAX;
+    float *mov, *tgt, *theta, *partials;
+    CK(hipMalloc(&mov, n * 4)); CK(hipMalloc(&tgt, n * 4));
+    CK(hipMemcpy(mov, h.data(), n * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < n; i++) h[i] = (float)rand() / RAND_MAX;
+    CK(hipMemcpy(tgt, h.data(), n * 4, hipMemcpyHostToDevice));
+    std::vector<float> th(B * 12);
+    const float t0[12] = {0.95f, -0.1f, 0.02f, 0.05f, 0.1f, 0.97f, 0.0f, -0.03f, 0.0f, 0.03f, 1.02f, 0.02f};
+    for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = t0[i];
+    CK(hipMalloc(&theta, B * 12 * 4));
+    CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
+    float *tab;
+    CK(hipMalloc(&tab, 3 * S * 4));
+    hipLaunchKernelGGL(trx::fill_tables_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, tab, S, S, S);
+    trx_volumes vol = {mov, tgt, nvox, nvox, 3, B, S, S, S, tab, tab + S, tab + 2 * S};
+    trx::AffineGeom g = trx::affine_geom(vol, tb);
+    CK(hipMalloc(&partials, (size_t)B * g.nblk * 41 * 4 + 4096));
+    printf("B=%d S=%d geom TX=%d TY=%d RPT=%d nblk=%d\n", B, S, g.TX, g.TY, g.RPT, g.nblk);
+    dim3 grid(g.nblk, B), block(256);
+    const double alg = 8.0 * nvox;  // bytes per pair-iteration
+    auto rep = [&](const char *name, float us) {
+        printf("%-28s %9.1f us/launch  %7.2f us/pair  %6.2f TB/s alg\n", name, us, us / B, alg * B / us / 1e6);
+    };
+    rep("skel (dword, same geom)", time_it([&] { hipLaunchKernelGGL(skel_kernel, grid, block, 0, 0, vol, g, partials); }, 20));
+    rep("skel4 (float4 grid-stride)", time_it([&] { hipLaunchKernelGGL(skel4_kernel, dim3(4096), block, 0, 0, (const float4 *)mov, (const float4 *)tgt, n / 4, partials); }, 20));
+    rep("accum MODE1 (moments)", time_it([&] { hipLaunchKernelGGL((trx::affine_accum_kernel<3, 1>), grid, block, 0, 0, vol, theta, g, 1, (size_t)0, partials); }, 20));
+    rep("accum MODE0 (full F1)", time_it([&] { hipLaunchKernelGGL((trx::affine_accum_kernel<3, 0>), grid, block, 0, 0, vol, theta, g, 1, (size_t)0, partials); }, 20));
+    trx::TileGeom tgm = trx::tile_geom(vol);
+    printf("tile geom: %d x %d x %d tiles, %d blocks/pair\n", tgm.ntx, tgm.nty, tgm.ntz, tgm.blocks_per_pair);
+    dim3 tgrid(tgm.blocks_per_pair, B);
+    rep("tile MODE1 (moments)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<1>), tgrid, block, 0, 0, vol, theta, tgm, partials); }, 20));
+    rep("tile MODE0 (full F1)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, block, 0, 0, vol, theta, tgm, partials); }, 20));
+    // identity theta (all samples on voxel centres)
+    const float id[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = id[i];
+    CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
+    rep("accum MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_accum_kernel<3, 0>), grid, block, 0, 0, vol, theta, g, 1, (size_t)0, partials); }, 20));
+    rep("tile MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, block, 0, 0, vol, theta, tgm, partials); }, 20));
+    return 0;
+}

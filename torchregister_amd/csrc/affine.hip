@@ -12,6 +12,8 @@
 //   dL/dtheta = cy * sum(y J) + cw * sum(w J) + c0 * sum(J).
 // The streaming kernel accumulates {Sy, Sw, Syy, Sww, Syw} and sum(q J) for q in {1, y, w};
 // the coefficients only exist after the pass, in the finalise kernel.
+#include <cstdlib>
+
 #include "trx_common.h"
 
 namespace trx {
@@ -89,15 +91,14 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
             by = fmaf(th[3], xn, th[5]);
             t_x1 = th[1]; t_y1 = th[4];
         }
-        const float hW = 0.5f * W, hH = 0.5f * H, hD = 0.5f * D;
-        const float oW = 0.5f * (W - 1), oH = 0.5f * (H - 1), oD = 0.5f * (D - 1);
+        const float fW = (float)W, fH = (float)H, fD = (float)D;
         const int y0 = yc * g.TY * g.RPT + ly;
         for (int j = 0; j < g.RPT; j++) {
             const int y = y0 + j * g.TY;
             if (y >= H) break;
             const float yn = base_coord(vol.yn, y, H);
-            const float ix = fmaf(fmaf(t_x1, yn, bx), hW, oW);
-            const float iy = fmaf(fmaf(t_y1, yn, by), hH, oH);
+            const float ix = unnorm<ND>(fmaf(t_x1, yn, bx), fW);
+            const float iy = unnorm<ND>(fmaf(t_y1, yn, by), fH);
             const size_t vox = ((size_t)z * H + y) * W + x;
             float gq[NC];
             float w;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
                 for (int ch = 0; ch < channels; ch++) {
                     const float go = tgt[ch * chan_stride + vox];
                     if constexpr (ND == 3) {
-                        const float iz = fmaf(fmaf(t_z1, yn, bz), hD, oD);
+                        const float iz = unnorm<ND>(fmaf(t_z1, yn, bz), fD);
                         Samp3 s = sample3(mov + ch * chan_stride, D, H, W, ix, iy, iz);
                         gq[0] = fmaf(go, s.dx, gq[0]); gq[1] = fmaf(go, s.dy, gq[1]); gq[2] = fmaf(go, s.dz, gq[2]);
                     } else {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
                 w = 0.f;
             } else {
                 if constexpr (ND == 3) {
-                    const float iz = fmaf(fmaf(t_z1, yn, bz), hD, oD);
+                    const float iz = unnorm<ND>(fmaf(t_z1, yn, bz), fD);
                     Samp3 s = sample3(mov, D, H, W, ix, iy, iz);
                     w = s.v; gq[0] = s.dx; gq[1] = s.dy; gq[2] = s.dz;
                 } else {
@@ -163,6 +164,269 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
             vals[o++] = A[q][c];
         }
     block_reduce_store<NP>(vals, partials + ((size_t)b * g.nblk + blockIdx.x) * NP);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-tiled 3-D variant of the F1 pass (the fast path for near-identity transforms).
+//
+// A 256-thread block owns output tiles of 32(x) x 16(y) x 8(z) voxels.  The pre-image of a tile
+// under the affine map is a small parallelepiped; its bounding box (x origin aligned to 4 voxels)
+// is staged once into LDS with coalesced 16-byte loads (zero-filled outside the volume, which IS
+// grid_sample's zero padding), then all 8-corner gathers are ds_read2_b32 from LDS with
+// compile-time strides and no bounds checks.  Tiles whose box exceeds the LDS budget (large
+// rotations / zoom-out), or volumes with W % 4 != 0, take the global-gather path (sample3) inside
+// the same kernel, so results never depend on which path ran beyond fp32 rounding.
+// Blocks are persistent over a contiguous run of tiles of ONE pair and keep the 41 partial sums
+// in registers; thread (x, z) is fixed inside a tile so the xn / zn columns fold once per tile.
+// ------------------------------------------------------------------------------------------
+constexpr int kTX = 32, kTY = 16, kTZ = 8;          // output tile
+constexpr int kBW = 44, kBH = 24, kBD = 14;         // LDS box (floats); kBW % 4 == 0
+constexpr int kBW4 = kBW / 4;
+constexpr int kBoxCells = kBW * kBH * kBD;          // 14784 floats = 59136 B -> 2 blocks / CU
+
+struct TileGeom {
+    int ntx, nty, ntz, ntiles, blocks_per_pair;
+};
+
+static TileGeom tile_geom(const trx_volumes &v)
+{
+    TileGeom t;
+    t.ntx = (v.W + kTX - 1) / kTX; t.nty = (v.H + kTY - 1) / kTY; t.ntz = (v.D + kTZ - 1) / kTZ;
+    t.ntiles = t.ntx * t.nty * t.ntz;
+    int bpp = (512 + v.B - 1) / v.B;                 // 2 resident blocks on each of 256 CUs
+    if (bpp < 8) bpp = 8;
+    if (bpp > t.ntiles) bpp = t.ntiles;
+    t.blocks_per_pair = bpp;
+    return t;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_reduce_store_smem(const float (&vals)[NV], float *__restrict__ out, float *smem)
+{
+    // smem: >= TRX_WAVES*16*65 + TRX_WAVES*16 floats of scratch (aliases the tile box)
+    constexpr int CH = 16;
+    float(*red)[CH][65] = reinterpret_cast<float(*)[CH][65]>(smem);
+    float(*wsum)[CH] = reinterpret_cast<float(*)[CH]>(smem + TRX_WAVES * CH * 65);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int c0 = 0; c0 < NV; c0 += CH) {
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (c0 + j < NV) red[wave][j][lane] = vals[c0 + j];
+        __syncthreads();
+        if (lane < CH && c0 + lane < NV) {
+            float s = 0.f;
+#pragma unroll 16
+            for (int i = 0; i < 64; i++) s += red[wave][lane][i];
+            wsum[wave][lane] = s;
+        }
+        __syncthreads();
+        if (tid < CH && c0 + tid < NV) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < TRX_WAVES; w++) s += wsum[w][tid];
+            out[c0 + tid] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// one voxel's contribution to the running sums (x and z fixed per thread inside a tile)
+template <int MODE>
+__device__ __forceinline__ void f1_accumulate(const Samp3 &sm, float yv, float yn, float (&m)[5], float (&At)[3][3],
+                                              float (&Byt)[3][3])
+{
+    const float w = sm.v;
+    m[0] += yv; m[1] += w;
+    m[2] = fmaf(yv, yv, m[2]); m[3] = fmaf(w, w, m[3]); m[4] = fmaf(yv, w, m[4]);
+    if constexpr (MODE == 0) {
+        const float gq[3] = {sm.dx, sm.dy, sm.dz};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float u = yn * gq[c];
+            At[0][c] += gq[c];                    Byt[0][c] += u;
+            At[1][c] = fmaf(yv, gq[c], At[1][c]); Byt[1][c] = fmaf(yv, u, Byt[1][c]);
+            At[2][c] = fmaf(w, gq[c], At[2][c]);  Byt[2][c] = fmaf(w, u, Byt[2][c]);
+        }
+    }
+}
+
+constexpr int kBoxIters = (kBW4 * kBH * kBD + TRX_BLOCK - 1) / TRX_BLOCK;   // float4 slots per thread
+
+// Requires vol.xn / vol.yn / vol.zn != NULL (the launcher materialises them when the caller passes NULL).
+template <int MODE>
+__global__ __launch_bounds__(TRX_BLOCK, 2) void affine_tile_kernel(trx_volumes vol, const float *__restrict__ theta,
+                                                                    TileGeom tg, float *__restrict__ partials)
+{
+    constexpr int NQ = (MODE == 0) ? 3 : 0;
+    constexpr int NP = (MODE == 0) ? np_full(3) : 5;
+    __shared__ __attribute__((aligned(16))) float box[kBoxCells];
+    const int b = blockIdx.y;
+    const int D = vol.D, H = vol.H, W = vol.W;
+    const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
+    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
+    const float *__restrict__ tgt = vol.target + (size_t)b * vol.target_stride;
+    const float *__restrict__ xtab = vol.xn, *__restrict__ ytab = vol.yn, *__restrict__ ztab = vol.zn;
+    const int tid = threadIdx.x;
+    const int lx = tid & (kTX - 1), lz = tid >> 5;
+    const float fW = (float)W, fH = (float)H, fD = (float)D;
+    const float t00 = th[0], t01 = th[1], t02 = th[2], t03 = th[3];
+    const float t10 = th[4], t11 = th[5], t12 = th[6], t13 = th[7];
+    const float t20 = th[8], t21 = th[9], t22 = th[10], t23 = th[11];
+    const bool vec_ok = ((W & 3) == 0) && ((((size_t)mov) & 15) == 0);
+
+    float A[3][3], By[3][3], Bx[3][3], Bz[3][3], m[5];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) A[q][c] = By[q][c] = Bx[q][c] = Bz[q][c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) m[i] = 0.f;
+
+    const int per = (tg.ntiles + tg.blocks_per_pair - 1) / tg.blocks_per_pair;
+    const int t_begin = blockIdx.x * per;
+    const int t_end = min(t_begin + per, tg.ntiles);
+    for (int t = t_begin; t < t_end; t++) {
+        int r = t;
+        const int X0 = (r % tg.ntx) * kTX; r /= tg.ntx;
+        const int Y0 = (r % tg.nty) * kTY;
+        const int Z0 = (r / tg.nty) * kTZ;
+        const int nx = min(kTX, W - X0), ny = min(kTY, H - Y0), nz = min(kTZ, D - Z0);
+        // bounding box of the tile's pre-image: the map is affine, extremes sit at the 8 corners
+        const float cxn[2] = {xtab[X0], xtab[X0 + nx - 1]}, cyn[2] = {ytab[Y0], ytab[Y0 + ny - 1]};
+        const float czn[2] = {ztab[Z0], ztab[Z0 + nz - 1]};
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float ax = cxn[k & 1], ay = cyn[(k >> 1) & 1], az = czn[k >> 2];
+            const float cx = unnorm<3>(fmaf(t01, ay, fmaf(t00, ax, fmaf(t02, az, t03))), fW);
+            const float cy = unnorm<3>(fmaf(t11, ay, fmaf(t10, ax, fmaf(t12, az, t13))), fH);
+            const float cz = unnorm<3>(fmaf(t21, ay, fmaf(t20, ax, fmaf(t22, az, t23))), fD);
+            lo[0] = fminf(lo[0], cx); hi[0] = fmaxf(hi[0], cx);
+            lo[1] = fminf(lo[1], cy); hi[1] = fmaxf(hi[1], cy);
+            lo[2] = fminf(lo[2], cz); hi[2] = fmaxf(hi[2], cz);
+        }
+        const float slack = 0.02f;   // fp32 rounding of interior points relative to the corners
+        bool fits = vec_ok;
+#pragma unroll
+        for (int c = 0; c < 3; c++) fits = fits && (lo[c] > -1.0e6f) && (hi[c] < 1.0e6f);   // also rejects NaN
+        int ox = 0, oy = 0, oz = 0, ex4 = 0, ey = 0, ez = 0;
+        if (fits) {
+            const int lx0 = (int)floorf(lo[0] - slack), hx1 = (int)floorf(hi[0] + slack) + 1;
+            oy = (int)floorf(lo[1] - slack); const int hy1 = (int)floorf(hi[1] + slack) + 1;
+            oz = (int)floorf(lo[2] - slack); const int hz1 = (int)floorf(hi[2] + slack) + 1;
+            ox = lx0 & ~3;
+            ex4 = ((hx1 - ox) >> 2) + 1; ey = hy1 - oy + 1; ez = hz1 - oz + 1;
+            fits = (ex4 <= kBW4) && (ey <= kBH) && (ez <= kBD);
+        }
+        fits = __builtin_amdgcn_readfirstlane(fits);   // block-uniform by construction
+
+        const int x = X0 + lx, z = Z0 + lz;
+        const bool act = (lx < nx) && (lz < nz);
+        const int xc = act ? x : X0, zc = act ? z : Z0;      // clamped: idle lanes load valid addresses
+        const float xn = xtab[xc], zn = ztab[zc];
+        const float bx = fmaf(t00, xn, fmaf(t02, zn, t03));
+        const float by = fmaf(t10, xn, fmaf(t12, zn, t13));
+        const float bz = fmaf(t20, xn, fmaf(t22, zn, t23));
+        float At[3][3], Byt[3][3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) At[q][c] = Byt[q][c] = 0.f;
+        const float *__restrict__ tp = tgt + ((size_t)zc * H + Y0) * W + xc;
+
+        if (fits) {
+            // ---- (1) issue every global load of the tile up front: target column + box slots ----
+            float tv[kTY];
+#pragma unroll
+            for (int j = 0; j < kTY; j++) tv[j] = tp[(size_t)min(j, ny - 1) * W];
+            float4 bv[kBoxIters];
+            int bdst[kBoxIters];
+#pragma unroll
+            for (int k = 0; k < kBoxIters; k++) {
+                const int q4 = tid + k * TRX_BLOCK;
+                const int row = q4 / kBW4, dx4 = q4 - row * kBW4;
+                const int dz = row / kBH, dy = row - dz * kBH;
+                const int gz = oz + dz, gy = oy + dy, gx = ox + dx4 * 4;
+                const bool need = (dx4 < ex4) && (dy < ey) && (dz < ez);
+                const bool inb = need && ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+                bdst[k] = need ? q4 * 4 : -1;
+                bv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inb) bv[k] = *reinterpret_cast<const float4 *>(mov + (size_t)((unsigned)((gz * H + gy) * W + gx)));
+            }
+            float ynr[kTY];
+#pragma unroll
+            for (int j = 0; j < kTY; j++) ynr[j] = ytab[Y0 + min(j, ny - 1)];
+            // ---- (2) box -> LDS -----------------------------------------------------------------
+#pragma unroll
+            for (int k = 0; k < kBoxIters; k++)
+                if (bdst[k] >= 0) *reinterpret_cast<float4 *>(box + bdst[k]) = bv[k];
+            __syncthreads();
+            // ---- (3) gather from LDS ------------------------------------------------------------
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < kTY; j++) {
+                    if (j < ny) {
+                        const float yn = ynr[j];
+                        const float ix = unnorm<3>(fmaf(t01, yn, bx), fW);
+                        const float iy = unnorm<3>(fmaf(t11, yn, by), fH);
+                        const float iz = unnorm<3>(fmaf(t21, yn, bz), fD);
+                        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+                        const int a = (((int)fz - oz) * kBH + ((int)fy - oy)) * kBW + ((int)fx - ox);
+                        const float *p = box + a;
+                        const float v000 = p[0], v001 = p[1], v010 = p[kBW], v011 = p[kBW + 1];
+                        const float *q = p + kBW * kBH;
+                        const float v100 = q[0], v101 = q[1], v110 = q[kBW], v111 = q[kBW + 1];
+                        const Samp3 sm = lerp3(v000, v001, v010, v011, v100, v101, v110, v111, ix - fx, iy - fy, iz - fz);
+                        f1_accumulate<MODE>(sm, tv[j], yn, m, At, Byt);
+                    }
+                }
+            }
+            __syncthreads();   // the box is overwritten by the next tile
+        } else if (act) {
+            // large deformation (or W % 4 != 0): gather straight from global memory
+#pragma unroll 1
+            for (int j = 0; j < ny; j++) {
+                const float yn = ytab[Y0 + j];
+                const float ix = unnorm<3>(fmaf(t01, yn, bx), fW);
+                const float iy = unnorm<3>(fmaf(t11, yn, by), fH);
+                const float iz = unnorm<3>(fmaf(t21, yn, bz), fD);
+                const float yv = tp[(size_t)j * W];
+                const Samp3 sm = sample3(mov, D, H, W, ix, iy, iz);
+                f1_accumulate<MODE>(sm, yv, yn, m, At, Byt);
+            }
+        }
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    A[q][c] += At[q][c]; By[q][c] += Byt[q][c];
+                    Bx[q][c] = fmaf(xn, At[q][c], Bx[q][c]); Bz[q][c] = fmaf(zn, At[q][c], Bz[q][c]);
+                }
+        }
+    }
+
+    float vals[NP];
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) vals[o++] = m[i];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            vals[o++] = Bx[q][c]; vals[o++] = By[q][c]; vals[o++] = Bz[q][c]; vals[o++] = A[q][c];
+        }
+    block_reduce_store_smem<NP>(vals, partials + ((size_t)b * tg.blocks_per_pair + blockIdx.x) * NP, box);
+}
+
+// closed-form base coordinates for callers that pass no tables: (2i+1)/S - 1
+__global__ void fill_tables_kernel(float *__restrict__ tab, int W, int H, int D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W) tab[i] = (float)(2 * i + 1) / (float)W - 1.0f;
+    if (i < H) tab[W + i] = (float)(2 * i + 1) / (float)H - 1.0f;
+    if (i < D) tab[W + H + i] = (float)(2 * i + 1) / (float)D - 1.0f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -378,8 +642,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_warp_kernel(trx_volumes vol,
     const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
     const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
     float *__restrict__ o = out + (size_t)b * channels * nvox;
-    const float hW = 0.5f * W, hH = 0.5f * H, hD = 0.5f * D;
-    const float oW = 0.5f * (W - 1), oH = 0.5f * (H - 1), oD = 0.5f * (D - 1);
+    const float fW = (float)W, fH = (float)H, fD = (float)D;
     for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
         const int x = (int)(i % W);
         const size_t r = i / W;
@@ -388,13 +651,13 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_warp_kernel(trx_volumes vol,
         const float xn = base_coord(vol.xn, x, W), yn = base_coord(vol.yn, y, H);
         if constexpr (ND == 3) {
             const float zn = base_coord(vol.zn, z, D);
-            const float ix = fmaf(fmaf(th[1], yn, fmaf(th[0], xn, fmaf(th[2], zn, th[3]))), hW, oW);
-            const float iy = fmaf(fmaf(th[5], yn, fmaf(th[4], xn, fmaf(th[6], zn, th[7]))), hH, oH);
-            const float iz = fmaf(fmaf(th[9], yn, fmaf(th[8], xn, fmaf(th[10], zn, th[11]))), hD, oD);
+            const float ix = unnorm<3>(fmaf(th[1], yn, fmaf(th[0], xn, fmaf(th[2], zn, th[3]))), fW);
+            const float iy = unnorm<3>(fmaf(th[5], yn, fmaf(th[4], xn, fmaf(th[6], zn, th[7]))), fH);
+            const float iz = unnorm<3>(fmaf(th[9], yn, fmaf(th[8], xn, fmaf(th[10], zn, th[11]))), fD);
             for (int ch = 0; ch < channels; ch++) o[ch * nvox + i] = sample3(mov + ch * chan_stride, D, H, W, ix, iy, iz).v;
         } else {
-            const float ix = fmaf(fmaf(th[1], yn, fmaf(th[0], xn, th[2])), hW, oW);
-            const float iy = fmaf(fmaf(th[4], yn, fmaf(th[3], xn, th[5])), hH, oH);
+            const float ix = unnorm<2>(fmaf(th[1], yn, fmaf(th[0], xn, th[2])), fW);
+            const float iy = unnorm<2>(fmaf(th[4], yn, fmaf(th[3], xn, th[5])), fH);
             for (int ch = 0; ch < channels; ch++) o[ch * nvox + i] = sample2(mov + ch * chan_stride, H, W, ix, iy).v;
         }
     }
@@ -420,8 +683,26 @@ extern "C" size_t trx_affine_workspace_bytes(const trx_volumes *vol)
 {
     if (check_vol(vol, false) != TRX_OK) return 0;
     AffineGeom g = affine_geom(*vol, kTargetBlocks);
-    return (size_t)vol->B * g.nblk * np_full(3) * sizeof(float) + 256;
+    size_t nblk = (size_t)g.nblk;
+    if (vol->ndim == 3) {
+        TileGeom t = tile_geom(*vol);
+        if ((size_t)t.blocks_per_pair > nblk) nblk = (size_t)t.blocks_per_pair;
+    }
+    const size_t tab = ((size_t)(vol->W + vol->H + vol->D) * sizeof(float) + 255) & ~(size_t)255;
+    return (size_t)vol->B * nblk * np_full(3) * sizeof(float) + 256 + tab;
 }
+
+static bool use_tile_path(const trx_volumes *vol)
+{
+    if (vol->ndim != 3) return false;
+    const char *e = getenv("TRX_AFFINE_PATH");   // development switch: "gather" forces the untiled kernel
+    return !(e && e[0] == 'g');
+}
+
+// MODE 0 / 1 dispatch: LDS-tiled kernel for 3-D, row-walking gather kernel otherwise.
+// Returns the number of partial rows per pair through *nblk.
+template <int MODE>
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s);
 
 template <int MODE>
 static int launch_accum(const trx_volumes *vol, const float *theta, const AffineGeom &g, int channels, size_t chan_stride,
@@ -436,6 +717,33 @@ static int launch_accum(const trx_volumes *vol, const float *theta, const Affine
     return TRX_OK;
 }
 
+template <int MODE>
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s)
+{
+    if (use_tile_path(vol)) {
+        TileGeom t = tile_geom(*vol);
+        trx_volumes v = *vol;
+        if (!v.xn || !v.yn || !v.zn) {
+            // tables live behind the partials (trx_affine_workspace_bytes reserves the room)
+            AffineGeom g = affine_geom(*vol, kTargetBlocks);
+            size_t nb = (size_t)g.nblk > (size_t)t.blocks_per_pair ? (size_t)g.nblk : (size_t)t.blocks_per_pair;
+            size_t off = ((size_t)vol->B * nb * np_full(3) * sizeof(float) + 255) & ~(size_t)255;
+            float *tab = (float *)((char *)partials + off);
+            const int n = max(v.W, max(v.H, v.D));
+            hipLaunchKernelGGL(fill_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tab, v.W, v.H, v.D);
+            TRX_CHECK_LAUNCH();
+            v.xn = tab; v.yn = tab + v.W; v.zn = tab + v.W + v.H;
+        }
+        hipLaunchKernelGGL((affine_tile_kernel<MODE>), dim3(t.blocks_per_pair, vol->B), dim3(TRX_BLOCK), 0, s, v, theta, t, partials);
+        TRX_CHECK_LAUNCH();
+        *nblk = t.blocks_per_pair;
+        return TRX_OK;
+    }
+    AffineGeom g = affine_geom(*vol, kTargetBlocks);
+    *nblk = g.nblk;
+    return launch_accum<MODE>(vol, theta, g, 1, 0, partials, s);
+}
+
 extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
                                const trx_affine_state *st, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -448,16 +756,16 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     if (st->mode != TRX_PARAM_AFFINE && st->mode != TRX_PARAM_RIGID) return TRX_ERR_ARG;
     if (workspace_bytes < trx_affine_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    AffineGeom g = affine_geom(*vol, kTargetBlocks);
     float *partials = (float *)workspace;
-    rc = launch_accum<0>(vol, st->theta, g, 1, 0, partials, s);
+    int nblk = 0;
+    rc = launch_f1<0>(vol, st->theta, partials, &nblk, s);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
     if (vol->ndim == 3)
-        hipLaunchKernelGGL((affine_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, g.nblk, nvox,
+        hipLaunchKernelGGL((affine_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
                            vol->D, vol->H, vol->W, *loss, *opt, *st);
     else
-        hipLaunchKernelGGL((affine_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, g.nblk, nvox,
+        hipLaunchKernelGGL((affine_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
                            vol->D, vol->H, vol->W, *loss, *opt, *st);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
@@ -482,12 +790,12 @@ extern "C" int trx_affine_loss(const trx_volumes *vol, const trx_loss_cfg *loss,
     if (!loss || !theta || !terms || !workspace) return TRX_ERR_ARG;
     if (workspace_bytes < trx_affine_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    AffineGeom g = affine_geom(*vol, kTargetBlocks);
     float *partials = (float *)workspace;
-    rc = launch_accum<1>(vol, theta, g, 1, 0, partials, s);
+    int nblk = 0;
+    rc = launch_f1<1>(vol, theta, partials, &nblk, s);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
-    hipLaunchKernelGGL(affine_loss_finalize_kernel, dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, g.nblk, nvox, *loss, terms);
+    hipLaunchKernelGGL(affine_loss_finalize_kernel, dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox, *loss, terms);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }

@@ -99,6 +99,18 @@ __device__ __forceinline__ Samp2 sample2(const float *__restrict__ mov, int H, i
     return s;
 }
 
+// grid_sample's un-normalisation (align_corners=False), written with the SAME roundings as the
+// ATen CPU kernels the reference runs on: 3-D scalar path ((c+1)*S-1)/2 (the final fma(a,.5,-.5)
+// is bitwise (a-1)/2), 2-D vectorised path fma(c+1, S/2, -0.5).  Mathematically identical to a
+// single fma, but at theta = identity (the start of every affine run) each sample sits exactly on
+// a voxel, where the trilinear derivative is one-sided and the side is decided by this last bit.
+template <int ND>
+__device__ __forceinline__ float unnorm(float c, float S)
+{
+    if constexpr (ND == 3) return fmaf((c + 1.0f) * S, 0.5f, -0.5f);
+    else return fmaf(c + 1.0f, 0.5f * S, -0.5f);
+}
+
 // base coordinate of affine_grid(align_corners=False)
 __device__ __forceinline__ float base_coord(const float *__restrict__ tab, int i, int S)
 {

@@ -1,0 +1,190 @@
+"""Building blocks mirrored from the reference's utils module (same names and argument meaning).
+
+ref: = /root/reference/src/TorchRegister/utils.py.  Losses are ordinary torch modules (they run
+on the GPU through PyTorch-ROCm) so they can be used stand-alone exactly like the reference's;
+inside Register.optim the MSE / NCC / SSD family is recognised and replaced by the fused HIP
+kernels (see warpings.loss_spec_from).  SpatialTransformer is backed by the HIP flow kernels.
+"""
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from . import _engine
+
+EPSILON = 1e-10  # ref:utils.py:15
+
+
+def norm(x):
+    """Min-max normalise to [0,1] (ref:utils.py:262-267; its own epsilon is 1e-9)."""
+    try:
+        return (x - torch.min(x)) / ((torch.max(x) - torch.min(x)) + 1e-9)
+    except Exception:
+        print("WARNING: Input could not be normalized!")
+
+
+def padNd(input_, target, device="cpu", mode="constant", value=0):
+    """Centre-pad input_ to target's spatial size, extra voxel in front (ref:utils.py:271-277)."""
+    dims = input_.dim() - 2
+    pads = []
+    for i in reversed(range(dims)):
+        delta = target.shape[2 + i] - input_.shape[2 + i]
+        front = -(-delta // 2)
+        pads += [front, delta - front]
+    return F.pad(input_, tuple(pads), mode=mode, value=value).to(dtype=torch.float, device=device)
+
+
+class NCCLoss(nn.Module):
+    """alpha * (1 - global NCC) (ref:utils.py:186-205). `grad_edges` / `device` are accepted and ignored
+    like in the reference.  Call order is (target, warped)."""
+
+    def __init__(self, alpha=100, grad_edges=True, device="cpu"):
+        super().__init__()
+        self.NCC = None
+        self.alpha = alpha
+
+    def forward(self, y, yp):
+        a = y - torch.mean(y)
+        b = yp - torch.mean(yp)
+        self.NCC = torch.sum(a * b) / ((torch.sum(a ** 2) * torch.sum(b ** 2) + EPSILON) ** 0.5)
+        return (1 - self.NCC) * self.alpha
+
+
+class SSDLoss(nn.Module):
+    """alpha * sum((y - yp)^2) (ref:utils.py:208-221)."""
+
+    def __init__(self, alpha=3):
+        super().__init__()
+        self.SSD = None
+        self.alpha = alpha
+
+    def forward(self, y, yp):
+        self.SSD = torch.sum((y - yp) ** 2)
+        return self.SSD * self.alpha
+
+
+# ---- Parzen-window NMI (ref:utils.py:18-79, 224-259): plain torch ops, NOT on the fused path --------
+def K_gauss(input_):
+    return (1 / (2 * torch.pi)) * torch.exp(-(input_ ** 2) / 2)
+
+
+def PDF_xis(signals, xis, h=3):
+    diff = signals.unsqueeze(-1) - xis.unsqueeze(1)          # [N, S, bins]
+    return (1 / h) * torch.mean(K_gauss(diff / h), dim=1)
+
+
+def PDF(signals, Xs, h=3):
+    return PDF_xis(signals, Xs, h)
+
+
+def get_pdf(data, steps=256, bandwidth=2):
+    signals = torch.flatten(data, start_dim=1)
+    # the reference names these (min, max) but takes (max, min): the sample line runs max -> min
+    hi, lo = torch.max(signals).item(), torch.min(signals).item()
+    line = torch.linspace(hi, lo, steps, dtype=torch.float, device=signals.device) * torch.ones(
+        (len(data), steps), dtype=torch.float, device=signals.device)
+    return PDF(signals, line, h=bandwidth)
+
+
+def NMI(img1, img2, bins=256, bandwidth=0.1):
+    h1 = get_pdf(img1, steps=bins, bandwidth=bandwidth)
+    h2 = get_pdf(img2, steps=bins, bandwidth=bandwidth)
+    hj = get_pdf(torch.stack((img1, img2), dim=1), steps=bins, bandwidth=bandwidth)
+    p1 = h1 / h1.sum(dim=1, keepdim=True)
+    p2 = h2 / h2.sum(dim=1, keepdim=True)
+    pj = hj / hj.sum(dim=1, keepdim=True)
+    # sign convention of the reference: E = -sum(p * -log2(p + eps)) = +sum(p log2 p)
+    e1 = torch.sum(p1 * torch.log2(p1 + EPSILON), dim=1)
+    e2 = torch.sum(p2 * torch.log2(p2 + EPSILON), dim=1)
+    ej = torch.sum(pj * torch.log2(pj + EPSILON), dim=1)
+    mi = e1 + e2 - ej
+    return 2 * mi / (e1 + e2), mi
+
+
+class NMILoss(nn.Module):
+    """alpha * mean|NMI - 1| on 2^d patches of a nearest-resampled 200^d copy (ref:utils.py:224-259)."""
+
+    def __init__(self, alpha=1000, bins=256, patch_size=100, bandwidth=3):
+        super().__init__()
+        self.bins, self.alpha, self.patch, self.bandwidth = bins, alpha, patch_size, bandwidth
+
+    def forward(self, y, yp):
+        r = self.patch * 2
+        nd = y.dim() - 2
+        y = F.interpolate(y, size=(r,) * nd, mode="nearest")
+        yp = F.interpolate(yp, size=(r,) * nd, mode="nearest")
+        y = y.view((2 ** nd) * y.shape[0] * y.shape[1], *([self.patch] * nd))
+        yp = yp.view((2 ** nd) * yp.shape[0] * yp.shape[1], *([self.patch] * nd))
+        nmi, _ = NMI(y, yp, self.bins, self.bandwidth)
+        return torch.mean(torch.abs(nmi - 1.0) * self.alpha)
+
+
+class Theta(nn.Module):
+    """Pose vector -> affine matrix entries (ref:utils.py:280-310).
+
+    3-D: x = (psi, theta, phi, tx, ty, tz): R = Rz(theta) Ry(psi) Rx(phi), t = max_translate*tanh(.)
+    2-D: x = (angle, tx, ty): [[cos, -sin, tx], [sin, cos, ty]] (translation not bounded)."""
+
+    def __init__(self):
+        super().__init__()
+        self.sin, self.cos, self.tanh = torch.sin, torch.cos, torch.tanh
+
+    def forward(self, x, max_translate=0.25):
+        if len(x) > 3:
+            out = _engine.pose_to_theta(x)
+            if max_translate != 0.25:
+                out = out.clone()
+                out[3::4] = max_translate * torch.tanh(x[3:6])
+            return out.flatten()
+        return _engine.pose_to_theta(x).flatten()
+
+
+class Regressor(nn.Module):
+    """Learnable pose, torch.rand initialised on `device` (ref:utils.py:313-330)."""
+
+    def __init__(self, moving, device):
+        super().__init__()
+        n = 6 if moving.dim() == 5 else 3
+        self.reg = nn.Parameter(torch.rand((n), device=device), requires_grad=True)
+        self.thetas = Theta()
+
+    def forward(self):
+        theta = self.thetas(self.reg)
+        return theta.view(1, 3, 4) if theta.shape[-1] == 12 else theta.view(1, 2, 3)
+
+
+class _FlowWarpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, flow):
+        ctx.save_for_backward(src, flow)
+        return _engine.flow_warp(src, flow)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        src, flow = ctx.saved_tensors
+        dflow = _engine.flow_warp_backward(src, flow, grad_out) if ctx.needs_input_grad[1] else None
+        return None, dflow   # no gradient flows to the moving image on this path
+
+
+class SpatialTransformer(nn.Module):
+    """N-D spatial transformer: sample src at voxel + flow, zeros outside (ref:utils.py:333-365).
+
+    Same constructor/forward signature as the reference; the identity-grid buffer is kept for
+    state_dict compatibility but the HIP kernel adds the voxel index itself.  Gradient wrt `flow`
+    is provided (HIP backward); gradient wrt `src` is not (the reference never needs it)."""
+
+    def __init__(self, size, mode="bilinear"):
+        super().__init__()
+        if mode != "bilinear":
+            raise NotImplementedError("only mode='bilinear' (what Register uses) is implemented on the HIP path")
+        self.mode = mode
+        self.size = tuple(int(s) for s in size)
+        vectors = [torch.arange(0, s) for s in self.size]
+        grid = torch.stack(torch.meshgrid(*vectors, indexing="ij")).unsqueeze(0).float()
+        self.register_buffer("grid", grid, persistent=True)
+
+    def forward(self, src, flow):
+        if tuple(flow.shape[2:]) != tuple(src.shape[2:]):
+            raise ValueError("flow and src spatial sizes differ")
+        if src.shape[0] != flow.shape[0]:
+            flow = flow.expand(src.shape[0], *flow.shape[1:])
+        return _FlowWarpFn.apply(src, flow)
