@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: registration iterations/sec (3-D 256^3 fp32, affine + NCC) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N = 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on): every GPU owns
+8 independent (moving, target) pairs of 256^3 fp32 volumes (1 GiB resident in HBM), affine mode,
+NCC loss (alpha = 100), SGD on theta as in the reference.  One STEP = one optimiser iteration for
+all 8 pairs of a rank: fused warp + NCC + analytic backward (one HIP kernel) + finalise/optimiser
+kernel; nothing is skipped and there is no host sync inside the timed region.  Pairs are independent,
+so N GPUs shard with no collective ("weak" scaling: 8 pairs per GPU at every N).
+value = N * 8 * K / max-over-ranks(elapsed)  [pair-iterations / s].
+
+Extra objects in the JSON line (rank 0, N = 1 only):
+  roofline     - dominant kernel (the fused F1 pass) timed in isolation with events on the launch
+                 stream; achieved = 8 B/voxel * 256^3 * 8 pairs / avg kernel time; peak 8.0 TB/s.
+  cpu_baseline - the oracle's torch-CPU composition of the reference's loop (kind "port": the
+                 reference itself cannot travel), bounded sample at 256^3 on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PAIRS_PER_GPU = 8
+SIZE = 256
+HBM_PEAK = 8.0e12          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+ALG_BYTES_PER_VOXEL = 8    # read moving (4) + target (4) once per pair-iteration
+THETA_STAR = [[0.95, -0.1, 0.02, 0.05], [0.1, 0.97, 0.0, -0.03], [0.0, 0.03, 1.02, 0.02]]
+
+
+def blobs_gpu(shape, seed, device):
+    """Same phantom as tests/phantoms.blobs (6 Gaussian blobs on a [-1,1]^3 lattice), built on the GPU in fp32."""
+    g = torch.Generator().manual_seed(int(seed))
+    axes = [torch.linspace(-1, 1, s, device=device) for s in shape]
+    img = torch.zeros(shape, device=device)
+    for _ in range(6):
+        c = torch.rand(3, generator=g) - 0.5
+        sig = 0.05 + 0.2 * torch.rand(1, generator=g)
+        a = torch.rand(1, generator=g)
+        r2 = ((axes[0] - float(c[0])) ** 2)[:, None, None] + ((axes[1] - float(c[1])) ** 2)[None, :, None] + ((axes[2] - float(c[2])) ** 2)[None, None, :]
+        img += float(a) * torch.exp(-r2 / (2 * float(sig) ** 2))
+    return img.view(1, 1, *shape)
+
+
+def make_batch(rank, device, size=SIZE, pairs=PAIRS_PER_GPU):
+    import torchregister_amd as tr
+    shape = (size,) * 3
+    from torchregister_amd.sharding import weak_pair_ids
+    tgt = torch.cat([blobs_gpu(shape, 1000 + pid, device) for pid in weak_pair_ids(rank, pairs)])
+    th = torch.tensor(THETA_STAR, device=device)[None].expand(pairs, 3, 4).contiguous()
+    mov = tr.get_affine_warp(th, tgt)
+    return mov, tgt
+
+
+def cpu_baseline(budget_s=12.0):
+    """Reference loop re-composed from torch CPU ops (oracle/compose.py) on ONE 256^3 pair."""
+    from oracle import compose
+    torch.manual_seed(0)
+    shape = (SIZE,) * 3
+    tgt = blobs_gpu(shape, 1000, "cpu")
+    mov = compose.affine_warp(torch.tensor(THETA_STAR)[None], tgt)
+    th = torch.eye(3, 4)[None].clone().requires_grad_()
+    opt = torch.optim.SGD([th], 1e-6)
+
+    def it():
+        opt.zero_grad()
+        e = compose.ncc_loss(tgt, compose.affine_warp(th, mov))
+        e.backward()
+        opt.step()
+        return e.item()
+
+    it()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        it()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {"value": n / el, "unit": "pair-iterations/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} iterations of one 256^3 pair, affine+NCC+SGD, torch {torch.__version__} CPU ops "
+                      f"(oracle/compose.py), {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=SIZE, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    import torchregister_amd as tr
+    mov, tgt = make_batch(rank, device, args.size)
+    solver = tr.AffineSolver(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer="sgd", lr=1e-6,
+                             capacity=args.steps + args.warmup)
+    solver.run(args.warmup)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    solver.run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    from torchregister_amd.sharding import max_over_ranks
+    elapsed = max_over_ranks(elapsed, device)
+    losses = solver.losses[:, : args.steps + args.warmup]
+    assert torch.isfinite(losses).all(), "non-finite loss in the benchmark run"
+    assert (losses[:, -1] < losses[:, 0]).all(), "the optimiser made no progress"
+
+    out = None
+    if rank == 0:
+        total = world * PAIRS_PER_GPU * args.steps
+        out = {"metric": "registration iterations/sec (3D 256^3 fp32, affine+NCC)", "value": total / elapsed,
+               "unit": "pair-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"3D {args.size}^3 fp32 affine+NCC, {PAIRS_PER_GPU} independent pairs per GPU "
+                                      f"(BASELINE.json configs[3] share of one GPU), SGD on theta",
+                          "pairs_per_gpu": PAIRS_PER_GPU, "volume": [args.size] * 3, "loss": "NCC(alpha=100)", "optimizer": "sgd",
+                          "parallelism": f"{world} x independent shards, no collective"}}
+        if world == 1:
+            # ---- roofline leg: the fused F1 kernel alone, events on the launch stream ----------------
+            reps = 50
+            solver.accumulate_only()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                solver.accumulate_only()
+            e1.record()
+            torch.cuda.synchronize()
+            k_s = e0.elapsed_time(e1) * 1e-3 / reps
+            alg = ALG_BYTES_PER_VOXEL * args.size ** 3 * PAIRS_PER_GPU
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "hbm", "kernel": "affine_tile_kernel<0> (fused warp+NCC fwd/bwd)", "achieved": alg / k_s / 1e9,
+                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / k_s / HBM_PEAK, "traffic": traffic,
+                               "kernel_ms": k_s * 1e3, "algorithmic_bytes_per_launch": alg}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

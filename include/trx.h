@@ -102,6 +102,11 @@ size_t trx_affine_workspace_bytes(const trx_volumes *vol /*[host]*/);
 int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
                     const trx_affine_state *st, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Pass 1 of trx_affine_step alone (the streaming kernel: per-block partial sums into `workspace`,
+ * no finalise, no state change).  Exposed so that the dominant kernel can be timed in isolation
+ * (bench.py roofline leg) and for callers that want to overlap their own finalise. */
+int trx_affine_accumulate(const trx_volumes *vol, const float *theta, void *workspace, size_t workspace_bytes, void *stream);
+
 /* `iters` iterations enqueued back to back (no host sync in between; replaces the whole loop). */
 int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
                    const trx_affine_state *st, int iters, void *workspace, size_t workspace_bytes, void *stream);

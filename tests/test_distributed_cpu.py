@@ -1,0 +1,66 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU plumbing: shard assignment, MAX timing reduce and the
+result gather.  The data path itself has no collective (pairs are independent)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total_pairs, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from torchregister_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharding.pair_range(rank, world, total_pairs)
+    # fake per-shard results: theta encodes the global pair id, losses the rank
+    theta = torch.stack([torch.full((3, 4), float(i)) for i in range(lo, hi)]) if hi > lo else torch.zeros(0, 3, 4)
+    losses = torch.full((hi - lo, 5), float(rank))
+    t = sharding.max_over_ranks(1.0 + rank)
+    th_all, l_all = sharding.gather_results(theta, losses)
+    q.put((rank, lo, hi, t, th_all[:, 0, 0].tolist(), l_all[:, 0].tolist(), sharding.weak_pair_ids(rank, 8)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total_pairs", [64, 7])
+def test_two_rank_sharding_gloo(total_pairs):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total_pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, t0, th0, l0, w0), (r1, lo1, hi1, t1, th1, l1, w1) = res
+    assert (lo0, hi1) == (0, total_pairs) and hi0 == lo1                     # shards tile the batch
+    assert abs((hi0 - lo0) - (hi1 - lo1)) <= 1
+    assert t0 == t1 == 2.0                                                   # MAX over ranks
+    assert th0 == th1 == [float(i) for i in range(total_pairs)]               # gathered in pair order on every rank
+    assert l0 == [0.0] * (hi0 - lo0) + [1.0] * (hi1 - lo1)
+    assert w0 == list(range(0, 8)) and w1 == list(range(8, 16))              # weak-scaling ids (bench.py)
+
+
+def test_single_process_identity():
+    sys.path.insert(0, ROOT)
+    from torchregister_amd import sharding
+    assert sharding.pair_range(0, 1, 5) == (0, 5)
+    assert sharding.max_over_ranks(3.5) == 3.5
+    a, b = sharding.gather_results(torch.ones(2, 3, 4), torch.zeros(2, 7))
+    assert a.shape == (2, 3, 4) and b.shape == (2, 7)

@@ -177,6 +177,13 @@ class AffineSolver:
                                          _lib.current_stream(self.batch.device))
         _lib.check(rc, "trx_affine_run")
 
+    def accumulate_only(self):
+        """Launch only the streaming F1 kernel (partials into the workspace); used for kernel timing."""
+        with torch.cuda.device(self.batch.device):
+            rc = self.lib.trx_affine_accumulate(ctypes.byref(self.vol), _lib.ptr(self.theta), _lib.ptr(self.workspace), self.ws_bytes,
+                                                _lib.current_stream(self.batch.device))
+        _lib.check(rc, "trx_affine_accumulate")
+
     def eval_loss(self, theta=None):
         """Loss terms [B,4] = (total, mse, ncc, ssd) at `theta` (default: current theta)."""
         th = self.theta if theta is None else pad_theta(theta.reshape(self.batch.B, -1), self.nd)

@@ -63,6 +63,7 @@ SIGNATURES = {
     "trx_affine_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Volumes)]),
     "trx_affine_step": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.POINTER(LossCfg), ctypes.POINTER(OptCfg),
                                        ctypes.POINTER(AffineState), _P, ctypes.c_size_t, _P]),
+    "trx_affine_accumulate": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, _P, ctypes.c_size_t, _P]),
     "trx_affine_run": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.POINTER(LossCfg), ctypes.POINTER(OptCfg),
                                       ctypes.POINTER(AffineState), ctypes.c_int, _P, ctypes.c_size_t, _P]),
     "trx_affine_loss": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.POINTER(LossCfg), _P, _P, _P, ctypes.c_size_t, _P]),

@@ -771,6 +771,16 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     return TRX_OK;
 }
 
+extern "C" int trx_affine_accumulate(const trx_volumes *vol, const float *theta, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_vol(vol, true);
+    if (rc) return rc;
+    if (!theta || !workspace) return TRX_ERR_ARG;
+    if (workspace_bytes < trx_affine_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
+    int nblk = 0;
+    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream);
+}
+
 extern "C" int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
                               const trx_affine_state *st, int iters, void *workspace, size_t workspace_bytes, void *stream)
 {
