@@ -182,7 +182,6 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
 constexpr int kTX = 32, kTY = 16, kTZ = 8;          // output tile
 constexpr int kBW = 44, kBH = 24, kBD = 14;         // LDS box (floats); kBW % 4 == 0
 constexpr int kBW4 = kBW / 4;
-constexpr int kBoxCells = kBW * kBH * kBD;          // 14784 floats = 59136 B -> 2 blocks / CU
 
 struct TileGeom {
     int ntx, nty, ntz, ntiles, blocks_per_pair;
@@ -193,42 +192,8 @@ static TileGeom tile_geom(const trx_volumes &v)
     TileGeom t;
     t.ntx = (v.W + kTX - 1) / kTX; t.nty = (v.H + kTY - 1) / kTY; t.ntz = (v.D + kTZ - 1) / kTZ;
     t.ntiles = t.ntx * t.nty * t.ntz;
-    int bpp = (512 + v.B - 1) / v.B;                 // 2 resident blocks on each of 256 CUs
-    if (bpp < 8) bpp = 8;
-    if (bpp > t.ntiles) bpp = t.ntiles;
-    t.blocks_per_pair = bpp;
+    t.blocks_per_pair = t.ntx * t.ntz;               // one block per (x-tile, z-tile) column, walking y
     return t;
-}
-
-template <int NV>
-__device__ __forceinline__ void block_reduce_store_smem(const float (&vals)[NV], float *__restrict__ out, float *smem)
-{
-    // smem: >= TRX_WAVES*16*65 + TRX_WAVES*16 floats of scratch (aliases the tile box)
-    constexpr int CH = 16;
-    float(*red)[CH][65] = reinterpret_cast<float(*)[CH][65]>(smem);
-    float(*wsum)[CH] = reinterpret_cast<float(*)[CH]>(smem + TRX_WAVES * CH * 65);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int c0 = 0; c0 < NV; c0 += CH) {
-#pragma unroll
-        for (int j = 0; j < CH; j++)
-            if (c0 + j < NV) red[wave][j][lane] = vals[c0 + j];
-        __syncthreads();
-        if (lane < CH && c0 + lane < NV) {
-            float s = 0.f;
-#pragma unroll 16
-            for (int i = 0; i < 64; i++) s += red[wave][lane][i];
-            wsum[wave][lane] = s;
-        }
-        __syncthreads();
-        if (tid < CH && c0 + tid < NV) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < TRX_WAVES; w++) s += wsum[w][tid];
-            out[c0 + tid] = s;
-        }
-        __syncthreads();
-    }
 }
 
 // one voxel's contribution to the running sums (x and z fixed per thread inside a tile)
@@ -251,159 +216,235 @@ __device__ __forceinline__ void f1_accumulate(const Samp3 &sm, float yv, float y
     }
 }
 
-constexpr int kBoxIters = (kBW4 * kBH * kBD + TRX_BLOCK - 1) / TRX_BLOCK;   // float4 slots per thread
+#ifndef TRX_TILE_MIN_WAVES
+#define TRX_TILE_MIN_WAVES 4   // waves per SIMD the register allocator must allow (2 blocks x 8 waves per CU)
+#endif
+constexpr int kTileThreads = 512;                       // 8 waves: (32 x) x (8 z) x (2 halves of 8 rows)
+constexpr int kTileWaves = kTileThreads / 64;
+constexpr int kRows = kTY / 2;                           // rows per thread
+constexpr int kBoxSlots = kBW4 * kBH * kBD;              // 3696 float4 slots
+constexpr int kBoxIters = (kBoxSlots + kTileThreads - 1) / kTileThreads;   // 8 LDS-DMA pieces per wave
+constexpr int kBoxAlloc = kBoxIters * kTileThreads * 4;  // floats incl. the tail the last piece spills into (64 KiB)
+
+template <int NV, int NW>
+__device__ __forceinline__ void block_reduce_store_nw(const float (&vals)[NV], float *__restrict__ out, float *smem)
+{
+    // smem: >= NW*16*65 + NW*16 floats of scratch (aliases the tile box)
+    constexpr int CH = 16;
+    float(*red)[CH][65] = reinterpret_cast<float(*)[CH][65]>(smem);
+    float(*wsum)[CH] = reinterpret_cast<float(*)[CH]>(smem + NW * CH * 65);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int c0 = 0; c0 < NV; c0 += CH) {
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (c0 + j < NV) red[wave][j][lane] = vals[c0 + j];
+        __syncthreads();
+        if (lane < CH && c0 + lane < NV) {
+            float s = 0.f;
+#pragma unroll 16
+            for (int i = 0; i < 64; i++) s += red[wave][lane][i];
+            wsum[wave][lane] = s;
+        }
+        __syncthreads();
+        if (tid < CH && c0 + tid < NV) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w++) s += wsum[w][tid];
+            out[c0 + tid] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// value is identical in every lane: pin it to an SGPR so it does not occupy a VGPR
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ float lane_bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
 // Requires vol.xn / vol.yn / vol.zn != NULL (the launcher materialises them when the caller passes NULL).
+//
+// Work decomposition: a 512-thread block owns one (x-tile, z-tile) COLUMN of the volume and walks it
+// along y, 16 rows per tile.  Thread (lx, lz, half) keeps its voxel column (x, z) for the whole block, so
+// only sum(q grad) and sum(q grad yn) live in registers (23 accumulators); the xn / zn columns of the 41
+// sums are one multiply at the very end.
+//
+// Sample coordinates are formed as  (ATen's identity coordinate of this voxel) + (deviation of theta
+// from identity): i_x = id_x(x) + (W/2)((t00-1) xn + t01 yn + t02 zn + t03), etc.  id_c uses ATen's exact
+// un-normalisation roundings (unnorm<3>), so at theta = identity the coordinates are BITWISE those of
+// the reference (every sample sits on a voxel there and the one-sided derivative depends on the last
+// bit); for any other theta this is the same affine map to within fp32 rounding, at 4 VALU ops / voxel.
 template <int MODE>
-__global__ __launch_bounds__(TRX_BLOCK, 2) void affine_tile_kernel(trx_volumes vol, const float *__restrict__ theta,
-                                                                    TileGeom tg, float *__restrict__ partials)
+__global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_kernel(trx_volumes vol, const float *__restrict__ theta,
+                                                                                        TileGeom tg, float *__restrict__ partials)
 {
     constexpr int NQ = (MODE == 0) ? 3 : 0;
     constexpr int NP = (MODE == 0) ? np_full(3) : 5;
-    __shared__ __attribute__((aligned(16))) float box[kBoxCells];
+    __shared__ __attribute__((aligned(16))) float box[kBoxAlloc];
     const int b = blockIdx.y;
     const int D = vol.D, H = vol.H, W = vol.W;
     const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
     const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
     const float *__restrict__ tgt = vol.target + (size_t)b * vol.target_stride;
     const float *__restrict__ xtab = vol.xn, *__restrict__ ytab = vol.yn, *__restrict__ ztab = vol.zn;
-    const int tid = threadIdx.x;
-    const int lx = tid & (kTX - 1), lz = tid >> 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform (SGPR)
+    const int lx = tid & (kTX - 1), lz = (tid >> 5) & (kTZ - 1), lh = wave >> 2;
     const float fW = (float)W, fH = (float)H, fD = (float)D;
+    const float hW = 0.5f * fW, hH = 0.5f * fH, hD = 0.5f * fD;
     const float t00 = th[0], t01 = th[1], t02 = th[2], t03 = th[3];
     const float t10 = th[4], t11 = th[5], t12 = th[6], t13 = th[7];
     const float t20 = th[8], t21 = th[9], t22 = th[10], t23 = th[11];
+    const float sx = uni(hW * t01), sy = uni(hH * (t11 - 1.0f)), sz = uni(hD * t21);
     const bool vec_ok = ((W & 3) == 0) && ((((size_t)mov) & 15) == 0);
+    const unsigned last4 = (unsigned)((size_t)D * H * W - 4);
 
-    float A[3][3], By[3][3], Bx[3][3], Bz[3][3], m[5];
+    const int X0 = (blockIdx.x % tg.ntx) * kTX, Z0 = (blockIdx.x / tg.ntx) * kTZ;
+    const int nx = min(kTX, W - X0), nz = min(kTZ, D - Z0);
+    // per-thread voxel column (x, z); idle lanes are clamped so every load stays in bounds
+    const bool act = (lx < nx) && (lz < nz);
+    const int x = X0 + (act ? lx : 0), z = Z0 + (act ? lz : 0);
+    const float xn = xtab[x], zn = ztab[z];
+    const float base_x = unnorm<3>(xn, fW) + hW * fmaf(t00 - 1.0f, xn, fmaf(t02, zn, t03));
+    const float base_y = hH * fmaf(t10, xn, fmaf(t12, zn, t13));
+    const float base_z = unnorm<3>(zn, fD) + hD * fmaf(t20, xn, fmaf(t22 - 1.0f, zn, t23));
+
+    // Pre-image bounding box of a tile = image of its (X0, Y0, Z0) corner + a tile-independent extent:
+    // the map is affine, so extremes sit at corners; d(i_c)/d(voxel step along axis a) = t_ca * S_c / S_a.
+    float ext_lo[3], ext_hi[3];
+    {
+        const float ex[3] = {(float)(kTX - 1), (float)(kTY - 1), (float)(kTZ - 1)};
+        const float slope[3][3] = {{t00, t01 * fW / fH, t02 * fW / fD}, {t10 * fH / fW, t11, t12 * fH / fD}, {t20 * fD / fW, t21 * fD / fH, t22}};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            ext_lo[c] = ext_hi[c] = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const float e = slope[c][a] * ex[a];
+                ext_lo[c] += fminf(e, 0.f); ext_hi[c] += fmaxf(e, 0.f);
+            }
+            ext_lo[c] = uni(ext_lo[c]); ext_hi[c] = uni(ext_hi[c]);
+        }
+    }
+    const float cxn = xtab[X0], czn = ztab[Z0];
+    const float corner_x = uni(unnorm<3>(cxn, fW) + hW * fmaf(t00 - 1.0f, cxn, fmaf(t02, czn, t03)));
+    const float corner_y = uni(hH * fmaf(t10, cxn, fmaf(t12, czn, t13)));
+    const float corner_z = uni(unnorm<3>(czn, fD) + hD * fmaf(t20, cxn, fmaf(t22 - 1.0f, czn, t23)));
+
+    // LDS-DMA slot geometry of this thread (tile independent): slot k covers box float4 (dz, dy, dx4)
+    int rel[kBoxIters];
+#pragma unroll
+    for (int k = 0; k < kBoxIters; k++) {
+        const int q4 = (k * kTileWaves + wave) * 64 + lane;
+        const int row = q4 / kBW4, dx4 = q4 - row * kBW4;
+        const int dz = row / kBH, dy = row - dz * kBH;
+        rel[k] = (dz * H + dy) * W + dx4 * 4;
+    }
+
+    float A[3][3], By[3][3], m[5];
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) A[q][c] = By[q][c] = Bx[q][c] = Bz[q][c] = 0.f;
+        for (int c = 0; c < 3; c++) A[q][c] = By[q][c] = 0.f;
 #pragma unroll
     for (int i = 0; i < 5; i++) m[i] = 0.f;
+    const int j0 = lh * kRows;                              // first row of this thread's half
+    const float *__restrict__ tp = tgt + (size_t)z * H * W + x;
 
-    const int per = (tg.ntiles + tg.blocks_per_pair - 1) / tg.blocks_per_pair;
-    const int t_begin = blockIdx.x * per;
-    const int t_end = min(t_begin + per, tg.ntiles);
-    for (int t = t_begin; t < t_end; t++) {
-        int r = t;
-        const int X0 = (r % tg.ntx) * kTX; r /= tg.ntx;
-        const int Y0 = (r % tg.nty) * kTY;
-        const int Z0 = (r / tg.nty) * kTZ;
-        const int nx = min(kTX, W - X0), ny = min(kTY, H - Y0), nz = min(kTZ, D - Z0);
-        // bounding box of the tile's pre-image: the map is affine, extremes sit at the 8 corners
-        const float cxn[2] = {xtab[X0], xtab[X0 + nx - 1]}, cyn[2] = {ytab[Y0], ytab[Y0 + ny - 1]};
-        const float czn[2] = {ztab[Z0], ztab[Z0 + nz - 1]};
-        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float ax = cxn[k & 1], ay = cyn[(k >> 1) & 1], az = czn[k >> 2];
-            const float cx = unnorm<3>(fmaf(t01, ay, fmaf(t00, ax, fmaf(t02, az, t03))), fW);
-            const float cy = unnorm<3>(fmaf(t11, ay, fmaf(t10, ax, fmaf(t12, az, t13))), fH);
-            const float cz = unnorm<3>(fmaf(t21, ay, fmaf(t20, ax, fmaf(t22, az, t23))), fD);
-            lo[0] = fminf(lo[0], cx); hi[0] = fmaxf(hi[0], cx);
-            lo[1] = fminf(lo[1], cy); hi[1] = fmaxf(hi[1], cy);
-            lo[2] = fminf(lo[2], cz); hi[2] = fmaxf(hi[2], cz);
-        }
-        const float slack = 0.02f;   // fp32 rounding of interior points relative to the corners
-        bool fits = vec_ok;
-#pragma unroll
-        for (int c = 0; c < 3; c++) fits = fits && (lo[c] > -1.0e6f) && (hi[c] < 1.0e6f);   // also rejects NaN
-        int ox = 0, oy = 0, oz = 0, ex4 = 0, ey = 0, ez = 0;
+    for (int ty = 0; ty < tg.nty; ty++) {
+        const int Y0 = ty * kTY;
+        const int ny = min(kTY, H - Y0);
+        // row tables of this tile, one row per lane (lanes 0..15), broadcast later with v_readlane
+        const float yn_l = ytab[Y0 + min(lane & (kTY - 1), ny - 1)];
+        const float yid_l = unnorm<3>(yn_l, fH);
+        const float yn0 = lane_bcast(yn_l, 0), yid0 = lane_bcast(yid_l, 0);
+        const float cx = fmaf(sx, yn0, corner_x), cy = yid0 + fmaf(sy, yn0, corner_y), cz = fmaf(sz, yn0, corner_z);
+        const float slack = 0.05f;   // fp32 rounding + table non-uniformity of interior points vs the corner + extent bound
+        bool fits = vec_ok && (fabsf(cx) < 1.0e6f) && (fabsf(cy) < 1.0e6f) && (fabsf(cz) < 1.0e6f);   // also rejects NaN
+        int ox = 0, oy = 0, oz = 0;
+        bool interior = false;
         if (fits) {
-            const int lx0 = (int)floorf(lo[0] - slack), hx1 = (int)floorf(hi[0] + slack) + 1;
-            oy = (int)floorf(lo[1] - slack); const int hy1 = (int)floorf(hi[1] + slack) + 1;
-            oz = (int)floorf(lo[2] - slack); const int hz1 = (int)floorf(hi[2] + slack) + 1;
+            const int lx0 = (int)floorf(cx + ext_lo[0] - slack), hx1 = (int)floorf(cx + ext_hi[0] + slack) + 1;
+            oy = (int)floorf(cy + ext_lo[1] - slack); const int hy1 = (int)floorf(cy + ext_hi[1] + slack) + 1;
+            oz = (int)floorf(cz + ext_lo[2] - slack); const int hz1 = (int)floorf(cz + ext_hi[2] + slack) + 1;
             ox = lx0 & ~3;
-            ex4 = ((hx1 - ox) >> 2) + 1; ey = hy1 - oy + 1; ez = hz1 - oz + 1;
-            fits = (ex4 <= kBW4) && (ey <= kBH) && (ez <= kBD);
+            fits = (((hx1 - ox) >> 2) + 1 <= kBW4) && (hy1 - oy + 1 <= kBH) && (hz1 - oz + 1 <= kBD);
+            // the whole box capacity lies inside the volume: no zero padding needed for this tile
+            interior = (ox >= 0) && (oy >= 0) && (oz >= 0) && (ox + kBW <= W) && (oy + kBH <= H) && (oz + kBD <= D);
         }
-        fits = __builtin_amdgcn_readfirstlane(fits);   // block-uniform by construction
-
-        const int x = X0 + lx, z = Z0 + lz;
-        const bool act = (lx < nx) && (lz < nz);
-        const int xc = act ? x : X0, zc = act ? z : Z0;      // clamped: idle lanes load valid addresses
-        const float xn = xtab[xc], zn = ztab[zc];
-        const float bx = fmaf(t00, xn, fmaf(t02, zn, t03));
-        const float by = fmaf(t10, xn, fmaf(t12, zn, t13));
-        const float bz = fmaf(t20, xn, fmaf(t22, zn, t23));
-        float At[3][3], Byt[3][3];
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) At[q][c] = Byt[q][c] = 0.f;
-        const float *__restrict__ tp = tgt + ((size_t)zc * H + Y0) * W + xc;
+        fits = __builtin_amdgcn_readfirstlane(fits);        // block-uniform by construction
+        interior = __builtin_amdgcn_readfirstlane(interior);
 
         if (fits) {
-            // ---- (1) issue every global load of the tile up front: target column + box slots ----
-            float tv[kTY];
+            // ---- (1) target column into registers, box straight into LDS (LDS-DMA, no staging VGPRs) ----
+            float tv[kRows];
 #pragma unroll
-            for (int j = 0; j < kTY; j++) tv[j] = tp[(size_t)min(j, ny - 1) * W];
-            float4 bv[kBoxIters];
-            int bdst[kBoxIters];
+            for (int j = 0; j < kRows; j++) tv[j] = tp[(size_t)(Y0 + min(j0 + j, ny - 1)) * W];
+            const int obase = (oz * H + oy) * W + ox;
+            unsigned oob = 0;   // bit k: slot k of this thread lies outside the volume
 #pragma unroll
             for (int k = 0; k < kBoxIters; k++) {
-                const int q4 = tid + k * TRX_BLOCK;
-                const int row = q4 / kBW4, dx4 = q4 - row * kBW4;
-                const int dz = row / kBH, dy = row - dz * kBH;
-                const int gz = oz + dz, gy = oy + dy, gx = ox + dx4 * 4;
-                const bool need = (dx4 < ex4) && (dy < ey) && (dz < ez);
-                const bool inb = need && ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-                bdst[k] = need ? q4 * 4 : -1;
-                bv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (inb) bv[k] = *reinterpret_cast<const float4 *>(mov + (size_t)((unsigned)((gz * H + gy) * W + gx)));
+                unsigned idx;
+                if (interior) {
+                    idx = min((unsigned)(obase + rel[k]), last4);   // the tail slots of the last piece only need a valid address
+                } else {
+                    const int q4 = (k * kTileWaves + wave) * 64 + lane;
+                    const int row = q4 / kBW4, dx4 = q4 - row * kBW4;
+                    const int dz = row / kBH, dy = row - dz * kBH;
+                    const int gz = oz + dz, gy = oy + dy, gx = ox + dx4 * 4;
+                    const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+                    idx = inb ? (unsigned)(obase + rel[k]) : 0u;
+                    if (!inb) oob |= 1u << k;
+                }
+                __builtin_amdgcn_global_load_lds(mov + idx, box + (k * kTileWaves + wave) * 256, 16, 0, 0);
             }
-            float ynr[kTY];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (oob) {   // zero padding: cells outside the volume (boundary tiles only)
 #pragma unroll
-            for (int j = 0; j < kTY; j++) ynr[j] = ytab[Y0 + min(j, ny - 1)];
-            // ---- (2) box -> LDS -----------------------------------------------------------------
-#pragma unroll
-            for (int k = 0; k < kBoxIters; k++)
-                if (bdst[k] >= 0) *reinterpret_cast<float4 *>(box + bdst[k]) = bv[k];
+                for (int k = 0; k < kBoxIters; k++)
+                    if (oob & (1u << k))
+                        *reinterpret_cast<float4 *>(box + ((k * kTileWaves + wave) * 64 + lane) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             __syncthreads();
-            // ---- (3) gather from LDS ------------------------------------------------------------
+            // ---- (2) gather from LDS ----------------------------------------------------------------
             if (act) {
+                const int cofs = (oz * kBH + oy) * kBW + ox;
+                auto voxel = [&](int j) {
+                    // wave-uniform row constants (this wave's half: rows j0 .. j0+7), v_readlane with an SGPR lane
+                    const float yn = lane_bcast(yn_l, j0 + j), yid = lane_bcast(yid_l, j0 + j);
+                    const float ix = fmaf(sx, yn, base_x);
+                    const float iy = yid + fmaf(sy, yn, base_y);
+                    const float iz = fmaf(sz, yn, base_z);
+                    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+                    const int a = __mul24(__mul24((int)fz, kBH) + (int)fy, kBW) + (int)fx - cofs;
+                    const float *p = box + a;
+                    const float v000 = p[0], v001 = p[1], v010 = p[kBW], v011 = p[kBW + 1];
+                    const float *q = p + kBW * kBH;
+                    const float v100 = q[0], v101 = q[1], v110 = q[kBW], v111 = q[kBW + 1];
+                    const Samp3 sm = lerp3(v000, v001, v010, v011, v100, v101, v110, v111, ix - fx, iy - fy, iz - fz);
+                    f1_accumulate<MODE>(sm, tv[j], yn, m, A, By);
+                };
+                if (ny == kTY) {
 #pragma unroll
-                for (int j = 0; j < kTY; j++) {
-                    if (j < ny) {
-                        const float yn = ynr[j];
-                        const float ix = unnorm<3>(fmaf(t01, yn, bx), fW);
-                        const float iy = unnorm<3>(fmaf(t11, yn, by), fH);
-                        const float iz = unnorm<3>(fmaf(t21, yn, bz), fD);
-                        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-                        const int a = (((int)fz - oz) * kBH + ((int)fy - oy)) * kBW + ((int)fx - ox);
-                        const float *p = box + a;
-                        const float v000 = p[0], v001 = p[1], v010 = p[kBW], v011 = p[kBW + 1];
-                        const float *q = p + kBW * kBH;
-                        const float v100 = q[0], v101 = q[1], v110 = q[kBW], v111 = q[kBW + 1];
-                        const Samp3 sm = lerp3(v000, v001, v010, v011, v100, v101, v110, v111, ix - fx, iy - fy, iz - fz);
-                        f1_accumulate<MODE>(sm, tv[j], yn, m, At, Byt);
-                    }
+                    for (int j = 0; j < kRows; j++) voxel(j);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kRows; j++)
+                        if (j0 + j < ny) voxel(j);
                 }
             }
             __syncthreads();   // the box is overwritten by the next tile
         } else if (act) {
             // large deformation (or W % 4 != 0): gather straight from global memory
 #pragma unroll 1
-            for (int j = 0; j < ny; j++) {
+            for (int j = j0; j < min(j0 + kRows, ny); j++) {
                 const float yn = ytab[Y0 + j];
-                const float ix = unnorm<3>(fmaf(t01, yn, bx), fW);
-                const float iy = unnorm<3>(fmaf(t11, yn, by), fH);
-                const float iz = unnorm<3>(fmaf(t21, yn, bz), fD);
-                const float yv = tp[(size_t)j * W];
+                const float ix = fmaf(sx, yn, base_x);
+                const float iy = unnorm<3>(yn, fH) + fmaf(sy, yn, base_y);
+                const float iz = fmaf(sz, yn, base_z);
+                const float yv = tp[(size_t)(Y0 + j) * W];
                 const Samp3 sm = sample3(mov, D, H, W, ix, iy, iz);
-                f1_accumulate<MODE>(sm, yv, yn, m, At, Byt);
+                f1_accumulate<MODE>(sm, yv, yn, m, A, By);
             }
-        }
-        if constexpr (MODE == 0) {
-#pragma unroll
-            for (int q = 0; q < 3; q++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    A[q][c] += At[q][c]; By[q][c] += Byt[q][c];
-                    Bx[q][c] = fmaf(xn, At[q][c], Bx[q][c]); Bz[q][c] = fmaf(zn, At[q][c], Bz[q][c]);
-                }
         }
     }
 
@@ -415,9 +456,9 @@ __global__ __launch_bounds__(TRX_BLOCK, 2) void affine_tile_kernel(trx_volumes v
     for (int q = 0; q < NQ; q++)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            vals[o++] = Bx[q][c]; vals[o++] = By[q][c]; vals[o++] = Bz[q][c]; vals[o++] = A[q][c];
+            vals[o++] = xn * A[q][c]; vals[o++] = By[q][c]; vals[o++] = zn * A[q][c]; vals[o++] = A[q][c];
         }
-    block_reduce_store_smem<NP>(vals, partials + ((size_t)b * tg.blocks_per_pair + blockIdx.x) * NP, box);
+    block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)b * tg.blocks_per_pair + blockIdx.x) * NP, box);
 }
 
 // closed-form base coordinates for callers that pass no tables: (2i+1)/S - 1
@@ -734,7 +775,7 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             TRX_CHECK_LAUNCH();
             v.xn = tab; v.yn = tab + v.W; v.zn = tab + v.W + v.H;
         }
-        hipLaunchKernelGGL((affine_tile_kernel<MODE>), dim3(t.blocks_per_pair, vol->B), dim3(TRX_BLOCK), 0, s, v, theta, t, partials);
+        hipLaunchKernelGGL((affine_tile_kernel<MODE>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, partials);
         TRX_CHECK_LAUNCH();
         *nblk = t.blocks_per_pair;
         return TRX_OK;
