@@ -219,6 +219,31 @@ __device__ __forceinline__ void f1_accumulate(const Samp3 &sm, float yv, float y
 #ifndef TRX_TILE_MIN_WAVES
 #define TRX_TILE_MIN_WAVES 4   // waves per SIMD the register allocator must allow (2 blocks x 8 waves per CU)
 #endif
+// packed running sums of the tile kernel: AB[q][c] = (sum q*g_c, sum q*g_c*yn), M01 = (Sy, Sw), M23 = (Syy, Sww)
+struct F1Acc {
+    f2 AB[3][3], M01, M23;
+    float M4;
+};
+
+template <int MODE>
+__device__ __forceinline__ void f1_accumulate_pk(const Samp3 &sm, float yv, float yn, F1Acc &a)
+{
+    const f2 yw = {yv, sm.v};
+    a.M01 += yw;
+    a.M23 = yw * yw + a.M23;
+    a.M4 = fmaf(yv, sm.v, a.M4);
+    if constexpr (MODE == 0) {
+        const float gq[3] = {sm.dx, sm.dy, sm.dz};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const f2 gu = {gq[c], yn * gq[c]};
+            a.AB[0][c] += gu;
+            a.AB[1][c] = gu * yv + a.AB[1][c];
+            a.AB[2][c] = gu * sm.v + a.AB[2][c];
+        }
+    }
+}
+
 constexpr int kTileThreads = 512;                       // 8 waves: (32 x) x (8 z) x (2 halves of 8 rows)
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kRows = kTY / 2;                           // rows per thread
@@ -298,7 +323,12 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     const bool vec_ok = ((W & 3) == 0) && ((((size_t)mov) & 15) == 0);
     const unsigned last4 = (unsigned)((size_t)D * H * W - 4);
 
-    const int X0 = (blockIdx.x % tg.ntx) * kTX, Z0 = (blockIdx.x / tg.ntx) * kTZ;
+    // XCD-aware column order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
+    // contiguous slab of columns so that the halo re-reads of neighbouring columns hit the same L2.
+    const int ncol = tg.ntx * tg.ntz;
+    int col = blockIdx.x;
+    if ((ncol & 7) == 0) col = (blockIdx.x & 7) * (ncol >> 3) + (blockIdx.x >> 3);
+    const int X0 = (col % tg.ntx) * kTX, Z0 = (col / tg.ntx) * kTZ;
     const int nx = min(kTX, W - X0), nz = min(kTZ, D - Z0);
     // per-thread voxel column (x, z); idle lanes are clamped so every load stays in bounds
     const bool act = (lx < nx) && (lz < nz);
@@ -340,13 +370,13 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         rel[k] = (dz * H + dy) * W + dx4 * 4;
     }
 
-    float A[3][3], By[3][3], m[5];
+    F1Acc acc;
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) A[q][c] = By[q][c] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 5; i++) m[i] = 0.f;
+        for (int c = 0; c < 3; c++) acc.AB[q][c] = (f2)(0.f);
+    acc.M01 = acc.M23 = (f2)(0.f);
+    acc.M4 = 0.f;
     const int j0 = lh * kRows;                              // first row of this thread's half
     const float *__restrict__ tp = tgt + (size_t)z * H * W + x;
 
@@ -407,21 +437,20 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             __syncthreads();
             // ---- (2) gather from LDS ----------------------------------------------------------------
             if (act) {
-                const int cofs = (oz * kBH + oy) * kBW + ox;
+                const float *bp = box - ((oz * kBH + oy) * kBW + ox);   // box address of voxel (0,0,0) of the volume
                 auto voxel = [&](int j) {
                     // wave-uniform row constants (this wave's half: rows j0 .. j0+7), v_readlane with an SGPR lane
                     const float yn = lane_bcast(yn_l, j0 + j), yid = lane_bcast(yid_l, j0 + j);
                     const float ix = fmaf(sx, yn, base_x);
                     const float iy = yid + fmaf(sy, yn, base_y);
                     const float iz = fmaf(sz, yn, base_z);
-                    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-                    const int a = __mul24(__mul24((int)fz, kBH) + (int)fy, kBW) + (int)fx - cofs;
-                    const float *p = box + a;
-                    const float v000 = p[0], v001 = p[1], v010 = p[kBW], v011 = p[kBW + 1];
-                    const float *q = p + kBW * kBH;
-                    const float v100 = q[0], v101 = q[1], v110 = q[kBW], v111 = q[kBW + 1];
-                    const Samp3 sm = lerp3(v000, v001, v010, v011, v100, v101, v110, v111, ix - fx, iy - fy, iz - fz);
-                    f1_accumulate<MODE>(sm, tv[j], yn, m, A, By);
+                    const int a = __mul24(floor_to_int(iz), kBH * kBW) + __mul24(floor_to_int(iy), kBW) + floor_to_int(ix);
+                    const float *p = bp + a;
+                    const f2 r00 = *reinterpret_cast<const f2u *>(p), r01 = *reinterpret_cast<const f2u *>(p + kBW);
+                    const f2 r10 = *reinterpret_cast<const f2u *>(p + kBW * kBH), r11 = *reinterpret_cast<const f2u *>(p + kBW * kBH + kBW);
+                    const Samp3 sm = lerp3_pairs<MODE == 0>(r00, r01, r10, r11, __builtin_amdgcn_fractf(ix), __builtin_amdgcn_fractf(iy),
+                                                            __builtin_amdgcn_fractf(iz));
+                    f1_accumulate_pk<MODE>(sm, tv[j], yn, acc);
                 };
                 if (ny == kTY) {
 #pragma unroll
@@ -443,20 +472,20 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                 const float iz = fmaf(sz, yn, base_z);
                 const float yv = tp[(size_t)(Y0 + j) * W];
                 const Samp3 sm = sample3(mov, D, H, W, ix, iy, iz);
-                f1_accumulate<MODE>(sm, yv, yn, m, A, By);
+                f1_accumulate_pk<MODE>(sm, yv, yn, acc);
             }
         }
     }
 
     float vals[NP];
-    int o = 0;
-#pragma unroll
-    for (int i = 0; i < 5; i++) vals[o++] = m[i];
+    vals[0] = acc.M01.x; vals[1] = acc.M01.y; vals[2] = acc.M23.x; vals[3] = acc.M23.y; vals[4] = acc.M4;
+    int o = 5;
 #pragma unroll
     for (int q = 0; q < NQ; q++)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            vals[o++] = xn * A[q][c]; vals[o++] = By[q][c]; vals[o++] = zn * A[q][c]; vals[o++] = A[q][c];
+            const float a = acc.AB[q][c].x;
+            vals[o++] = xn * a; vals[o++] = acc.AB[q][c].y; vals[o++] = zn * a; vals[o++] = a;
         }
     block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)b * tg.blocks_per_pair + blockIdx.x) * NP, box);
 }

@@ -23,6 +23,41 @@ namespace trx {
 struct Samp3 {
     float v, dx, dy, dz;
 };
+// Packed fp32: one v_pk_* instruction works on a 64-bit VGPR pair.  The VALU issues one wave64
+// instruction per 4 cycles per SIMD whether it is packed or not (measured: SQ_ACTIVE_INST_VALU ==
+// SQ_INSTS_VALU quad-cycles), so explicit pairs halve the cost of the interpolation / accumulation math.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));   // 4-byte aligned pair -> ds_read2_b32
+
+// floor(x) as int32 in ONE instruction (v_cvt_flr_i32_f32) instead of v_floor_f32 + v_cvt_i32_f32
+__device__ __forceinline__ int floor_to_int(float x)
+{
+    int i;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(x));
+    return i;
+}
+
+// Trilinear sample + gradient from the four x-pairs (x0, x0+1) at (z0,y0), (z0,y1), (z1,y0), (z1,y1):
+// z and y are interpolated on pairs (8 packed instructions), x last (6 scalar ones).
+template <bool GRAD>
+__device__ __forceinline__ Samp3 lerp3_pairs(f2 r00, f2 r01, f2 r10, f2 r11, float tx, float ty, float tz)
+{
+    const f2 dz0 = r10 - r00, dz1 = r11 - r01;
+    const f2 z0 = dz0 * tz + r00, z1 = dz1 * tz + r01;
+    const f2 dy = z1 - z0;
+    const f2 yv = dy * ty + z0;
+    Samp3 s;
+    s.dx = yv.y - yv.x;
+    s.v = fmaf(tx, s.dx, yv.x);
+    if constexpr (GRAD) {
+        const f2 dzy = (dz1 - dz0) * ty + dz0;
+        s.dy = fmaf(tx, dy.y - dy.x, dy.x);
+        s.dz = fmaf(tx, dzy.y - dzy.x, dzy.x);
+    } else {
+        s.dy = s.dz = 0.f;
+    }
+    return s;
+}
 struct Samp2 {
     float v, dx, dy;
 };
