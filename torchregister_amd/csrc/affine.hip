@@ -321,7 +321,6 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     const float t20 = th[8], t21 = th[9], t22 = th[10], t23 = th[11];
     const float sx = uni(hW * t01), sy = uni(hH * (t11 - 1.0f)), sz = uni(hD * t21);
     const bool vec_ok = ((W & 3) == 0) && ((((size_t)mov) & 15) == 0);
-    const unsigned last4 = (unsigned)((size_t)D * H * W - 4);
 
     // XCD-aware column order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
     // contiguous slab of columns so that the halo re-reads of neighbouring columns hit the same L2.
@@ -361,13 +360,14 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     const float corner_z = uni(unnorm<3>(czn, fD) + hD * fmaf(t20, cxn, fmaf(t22 - 1.0f, czn, t23)));
 
     // LDS-DMA slot geometry of this thread (tile independent): slot k covers box float4 (dz, dy, dx4)
-    int rel[kBoxIters];
+    int rel[kBoxIters], dpk[kBoxIters];   // element offset inside the volume; packed (dz << 16 | dy << 8 | dx4)
 #pragma unroll
     for (int k = 0; k < kBoxIters; k++) {
         const int q4 = (k * kTileWaves + wave) * 64 + lane;
         const int row = q4 / kBW4, dx4 = q4 - row * kBW4;
         const int dz = row / kBH, dy = row - dz * kBH;
         rel[k] = (dz * H + dy) * W + dx4 * 4;
+        dpk[k] = (dz << 16) | (dy << 8) | dx4;
     }
 
     F1Acc acc;
@@ -390,19 +390,21 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         const float cx = fmaf(sx, yn0, corner_x), cy = yid0 + fmaf(sy, yn0, corner_y), cz = fmaf(sz, yn0, corner_z);
         const float slack = 0.05f;   // fp32 rounding + table non-uniformity of interior points vs the corner + extent bound
         bool fits = vec_ok && (fabsf(cx) < 1.0e6f) && (fabsf(cy) < 1.0e6f) && (fabsf(cz) < 1.0e6f);   // also rejects NaN
-        int ox = 0, oy = 0, oz = 0;
+        int ox = 0, oy = 0, oz = 0, ex4 = 0, ey = 0, ez = 0;
         bool interior = false;
         if (fits) {
             const int lx0 = (int)floorf(cx + ext_lo[0] - slack), hx1 = (int)floorf(cx + ext_hi[0] + slack) + 1;
             oy = (int)floorf(cy + ext_lo[1] - slack); const int hy1 = (int)floorf(cy + ext_hi[1] + slack) + 1;
             oz = (int)floorf(cz + ext_lo[2] - slack); const int hz1 = (int)floorf(cz + ext_hi[2] + slack) + 1;
             ox = lx0 & ~3;
-            fits = (((hx1 - ox) >> 2) + 1 <= kBW4) && (hy1 - oy + 1 <= kBH) && (hz1 - oz + 1 <= kBD);
+            ex4 = ((hx1 - ox) >> 2) + 1; ey = hy1 - oy + 1; ez = hz1 - oz + 1;
+            fits = (ex4 <= kBW4) && (ey <= kBH) && (ez <= kBD);
             // the whole box capacity lies inside the volume: no zero padding needed for this tile
             interior = (ox >= 0) && (oy >= 0) && (oz >= 0) && (ox + kBW <= W) && (oy + kBH <= H) && (oz + kBD <= D);
         }
         fits = __builtin_amdgcn_readfirstlane(fits);        // block-uniform by construction
         interior = __builtin_amdgcn_readfirstlane(interior);
+        ex4 = __builtin_amdgcn_readfirstlane(ex4); ey = __builtin_amdgcn_readfirstlane(ey); ez = __builtin_amdgcn_readfirstlane(ez);
 
         if (fits) {
             // ---- (1) target column into registers, box straight into LDS (LDS-DMA, no staging VGPRs) ----
@@ -410,22 +412,27 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
 #pragma unroll
             for (int j = 0; j < kRows; j++) tv[j] = tp[(size_t)(Y0 + min(j0 + j, ny - 1)) * W];
             const int obase = (oz * H + oy) * W + ox;
-            unsigned oob = 0;   // bit k: slot k of this thread lies outside the volume
+            unsigned oob = 0;   // bit k: slot k of this thread is needed but lies outside the volume
+            // only the float4 slots inside the tile's actual pre-image extent (ex4 x ey x ez) are fetched:
+            // lanes outside it are masked off, so the bytes a CU ingests track the need, not the box capacity
+            const int lim = ((ez - 1) << 16) | ((ey - 1) << 8) | (ex4 - 1);
 #pragma unroll
             for (int k = 0; k < kBoxIters; k++) {
-                unsigned idx;
-                if (interior) {
-                    idx = min((unsigned)(obase + rel[k]), last4);   // the tail slots of the last piece only need a valid address
-                } else {
-                    const int q4 = (k * kTileWaves + wave) * 64 + lane;
-                    const int row = q4 / kBW4, dx4 = q4 - row * kBW4;
-                    const int dz = row / kBH, dy = row - dz * kBH;
-                    const int gz = oz + dz, gy = oy + dy, gx = ox + dx4 * 4;
-                    const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-                    idx = inb ? (unsigned)(obase + rel[k]) : 0u;
-                    if (!inb) oob |= 1u << k;
+                const int d = dpk[k];
+                // per-field compare of (dz,dy,dx4) <= (ez-1,ey-1,ex4-1): no field of lim-d may borrow
+                const bool need = (((lim - d) & 0x80808080) == 0) && ((d >> 16) < ez);
+                if (need) {
+                    unsigned idx;
+                    if (interior) {
+                        idx = (unsigned)(obase + rel[k]);
+                    } else {
+                        const int gz = oz + (d >> 16), gy = oy + ((d >> 8) & 0xff), gx = ox + (d & 0xff) * 4;
+                        const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+                        idx = inb ? (unsigned)(obase + rel[k]) : 0u;
+                        if (!inb) oob |= 1u << k;
+                    }
+                    __builtin_amdgcn_global_load_lds(mov + idx, box + (k * kTileWaves + wave) * 256, 16, 0, 0);
                 }
-                __builtin_amdgcn_global_load_lds(mov + idx, box + (k * kTileWaves + wave) * 256, 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (oob) {   // zero padding: cells outside the volume (boundary tiles only)
