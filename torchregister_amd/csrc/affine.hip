@@ -184,7 +184,7 @@ constexpr int kBW = 44, kBH = 24, kBD = 14;         // LDS box (floats); kBW % 4
 constexpr int kBW4 = kBW / 4;
 
 struct TileGeom {
-    int ntx, nty, ntz, ntiles, blocks_per_pair;
+    int ntx, nty, ntz, ntiles, blocks_per_pair, ysplit, tiles_per_seg;
 };
 
 static TileGeom tile_geom(const trx_volumes &v)
@@ -192,7 +192,15 @@ static TileGeom tile_geom(const trx_volumes &v)
     TileGeom t;
     t.ntx = (v.W + kTX - 1) / kTX; t.nty = (v.H + kTY - 1) / kTY; t.ntz = (v.D + kTZ - 1) / kTZ;
     t.ntiles = t.ntx * t.nty * t.ntz;
-    t.blocks_per_pair = t.ntx * t.ntz;               // one block per (x-tile, z-tile) column, walking y
+    // one block per (x-tile, z-tile) column walking y; small batches split every column into y segments
+    // so that at least ~1024 blocks (two rounds of 2 blocks on each of 256 CUs) exist
+    const int ncol = t.ntx * t.ntz;
+    int ys = (1024 + v.B * ncol - 1) / (v.B * ncol);
+    if (ys < 1) ys = 1;
+    if (ys > t.nty) ys = t.nty;
+    t.tiles_per_seg = (t.nty + ys - 1) / ys;
+    t.ysplit = (t.nty + t.tiles_per_seg - 1) / t.tiles_per_seg;
+    t.blocks_per_pair = ncol * t.ysplit;
     return t;
 }
 
@@ -325,8 +333,9 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     // XCD-aware column order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
     // contiguous slab of columns so that the halo re-reads of neighbouring columns hit the same L2.
     const int ncol = tg.ntx * tg.ntz;
-    int col = blockIdx.x;
-    if ((ncol & 7) == 0) col = (blockIdx.x & 7) * (ncol >> 3) + (blockIdx.x >> 3);
+    const int yseg = blockIdx.x / ncol, cb = blockIdx.x - yseg * ncol;
+    int col = cb;
+    if ((ncol & 7) == 0) col = (cb & 7) * (ncol >> 3) + (cb >> 3);
     const int X0 = (col % tg.ntx) * kTX, Z0 = (col / tg.ntx) * kTZ;
     const int nx = min(kTX, W - X0), nz = min(kTZ, D - Z0);
     // per-thread voxel column (x, z); idle lanes are clamped so every load stays in bounds
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     const int j0 = lh * kRows;                              // first row of this thread's half
     const float *__restrict__ tp = tgt + (size_t)z * H * W + x;
 
-    for (int ty = 0; ty < tg.nty; ty++) {
+    for (int ty = yseg * tg.tiles_per_seg; ty < min((yseg + 1) * tg.tiles_per_seg, tg.nty); ty++) {
         const int Y0 = ty * kTY;
         const int ny = min(kTY, H - Y0);
         // row tables of this tile, one row per lane (lanes 0..15), broadcast later with v_readlane
@@ -588,13 +597,16 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
     constexpr int NG = TRX_FIN_THREADS / 64;
     double s = 0.0;
     if (k < NP) {
-        int blk = grp;
-        for (; blk + 3 * NG < nblk; blk += 4 * NG) {
-            const float a0 = part[(size_t)blk * NP + k], a1 = part[(size_t)(blk + NG) * NP + k];
-            const float a2 = part[(size_t)(blk + 2 * NG) * NP + k], a3 = part[(size_t)(blk + 3 * NG) * NP + k];
-            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        // batches of 8 independent loads per thread (all in flight together), fixed summation order
+        for (int blk0 = grp; blk0 < nblk; blk0 += 8 * NG) {
+            float a[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int blk = blk0 + i * NG;
+                a[i] = (blk < nblk) ? part[(size_t)blk * NP + k] : 0.f;
+            }
+            s += (((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) + (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]));
         }
-        for (; blk < nblk; blk += NG) s += (double)part[(size_t)blk * NP + k];
     }
     acc[grp][k] = s;
     __syncthreads();
