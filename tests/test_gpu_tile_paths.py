@@ -1,0 +1,111 @@
+"""GPU parity of the LDS-tiled F1 kernel across its code paths: interior tiles, boundary tiles (zero
+padding through the LDS fix-up), tiles whose pre-image does not fit the LDS box (global-gather fallback),
+volumes with W % 4 != 0 (fallback), ragged sizes that are not multiples of the 32x16x8 tile, y-split
+columns (small batches) and batches.  Checker: the C oracle in fp64 (tolerance: loss 2e-5 rel,
+gradient 2e-4 of max — the fp32 floors of test_gpu_affine.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import phantoms as ph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torchregister_amd._engine as e
+    assert torch.cuda.is_available()
+    return e
+
+
+def rot_theta(ax, ay, az, scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0)):
+    cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    m = rz @ ry @ rx @ np.diag(scale)
+    return np.concatenate([m, np.asarray(shift, dtype=np.float64)[:, None]], axis=1)
+
+
+def generic(th):
+    """Perturb theta by ~1e-3 irrational-ish amounts: 'nice' decimal entries put whole lines of samples
+    EXACTLY on integer coordinates (e.g. theta* with D=40: iz integral wherever 3d+5h = 26 mod 150),
+    where the trilinear derivative is one-sided and fp32-vs-fp64 rounding picks different sides."""
+    th = np.array(th, dtype=np.float64)
+    k = np.arange(th.size, dtype=np.float64).reshape(th.shape)
+    return th + 1.3e-3 * np.sin(1.2345 * (k + 1.0)) + 0.7e-3 * np.cos(2.718 * k)
+
+
+THETAS = {
+    "identity": np.eye(3, 4),
+    "star": np.asarray(ph.THETA_STAR3, dtype=np.float64),
+    "small_rot": rot_theta(0.04, -0.07, 0.09, (1.03, 0.96, 1.01), (0.02, -0.03, 0.05)),
+    "shift_out": rot_theta(0.02, 0.01, -0.03, (1.0, 1.0, 1.0), (0.45, -0.4, 0.3)),      # large OOB region
+    "rot30": rot_theta(0.1, 0.2, 0.52, (0.9, 1.1, 1.0), (0.05, 0.0, -0.05)),             # box does not fit: fallback
+    "rigid_rand": rot_theta(0.77, 0.5, 0.09, (1, 1, 1), (0.03, 0.07, 0.15)),             # typical torch.rand rigid init
+    "zoom_out": rot_theta(0.0, 0.0, 0.0, (1.6, 1.5, 1.7), (0.0, 0.0, 0.0)),
+    "flip": np.array([[-1.0, 0.02, 0, 0.01], [0.01, 1.0, 0, 0], [0, 0, -0.98, 0.02]]),
+}
+SHAPES = [(40, 36, 44), (16, 48, 64), (24, 20, 30), (9, 33, 68), (64, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("tname", list(THETAS))
+def test_f1_step_vs_oracle(eng, shape, tname):
+    tgt = ph.blobs(shape, 77)
+    mov = ph.blobs(shape, 78) + 0.1 * ph.vol(shape, 0.013, "sin")
+    th64 = THETAS[tname] if tname == "identity" else generic(THETAS[tname])
+    th = torch.tensor(th64, dtype=torch.float32)[None]
+    kw = dict(w_ncc=1.0, w_mse=0.5)
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
+    s.run(1)
+    torch.cuda.synchronize()
+    th_used = th[0].double().numpy()          # the fp32-rounded theta, evaluated by the oracle in fp64
+    total, _, dth, _ = oracle.c_affine_loss_grad(mov[0, 0].double().numpy(), tgt[0, 0].double().numpy(), th_used, oracle.wts(**kw),
+                                                 oracle.base_tables(shape, np.float64))
+    loss = s.losses[0, 0].item()
+    grad = s.grad[0, :12].cpu().numpy().reshape(3, 4)
+    assert abs(loss - total) <= 2e-5 * max(1.0, abs(total)), (loss, total)
+    if tname == "identity":
+        return  # every sample on a voxel: one-sided derivative, side decided by last-bit rounding
+    assert np.max(np.abs(grad - dth)) <= 2e-4 * np.max(np.abs(dth)), (grad, dth)
+    # loss-only kernel (MODE 1) agrees
+    assert abs(s.eval_loss(th.cuda())[0, 0].item() - loss) <= 1e-6 * max(1.0, abs(loss))
+
+
+def test_forced_gather_path_matches_tile_path(eng, monkeypatch):
+    """TRX_AFFINE_PATH=gather (development switch) runs the un-tiled kernel: same results to fp32 rounding."""
+    shape = (40, 48, 64)
+    tgt, mov = ph.blobs(shape, 5).cuda(), ph.blobs(shape, 6).cuda()
+    th = torch.tensor(generic(THETAS["small_rot"]), dtype=torch.float32)[None]
+    outs = []
+    for path in ("tile", "gather"):
+        monkeypatch.setenv("TRX_AFFINE_PATH", path)
+        s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=1e-4, init=th, capacity=3)
+        s.run(3)
+        torch.cuda.synchronize()
+        outs.append((s.losses.clone(), s.theta.clone()))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=2e-6, atol=1e-5)
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=0, atol=2e-6)
+
+
+def test_batch_of_mixed_thetas(eng):
+    """Pairs of one launch may take different paths (fits / fallback / boundary) independently."""
+    shape = (32, 40, 48)
+    names = ["star", "rot30", "shift_out", "zoom_out", "identity"]
+    tgt = torch.cat([ph.blobs(shape, 100 + i) for i in range(len(names))])
+    mov = torch.cat([ph.blobs(shape, 200 + i) for i in range(len(names))])
+    th = torch.stack([torch.tensor(THETAS[n] if n == "identity" else generic(THETAS[n]), dtype=torch.float32) for n in names])
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=0.0, init=th, capacity=1)
+    s.run(1)
+    torch.cuda.synchronize()
+    for i, n in enumerate(names):
+        total, _, dth, _ = oracle.c_affine_loss_grad(mov[i, 0].double().numpy(), tgt[i, 0].double().numpy(), th[i].double().numpy(),
+                                                     oracle.wts(w_ncc=1.0), oracle.base_tables(shape, np.float64))
+        assert abs(s.losses[i, 0].item() - total) <= 2e-5 * max(1.0, abs(total)), n
+        if n != "identity":
+            assert np.max(np.abs(s.grad[i, :12].cpu().numpy().reshape(3, 4) - dth)) <= 2e-4 * np.max(np.abs(dth)), n
