@@ -109,3 +109,19 @@ def test_batch_of_mixed_thetas(eng):
         assert abs(s.losses[i, 0].item() - total) <= 2e-5 * max(1.0, abs(total)), n
         if n != "identity":
             assert np.max(np.abs(s.grad[i, :12].cpu().numpy().reshape(3, 4) - dth)) <= 2e-4 * np.max(np.abs(dth)), n
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 36), (8, 16, 40), (8, 16, 44), (16, 36, 44), (8, 33, 52), (12, 16, 76)])
+def test_partial_x_tiles_identity_mse(eng, shape):
+    """Regression: partial x tiles with fewer than 16 active columns (the row constants are broadcast
+    from lanes 0..15 with v_readlane, which must not happen under the `active voxel` branch).  At theta =
+    identity the warp is the identity, so the fused MSE must equal mean((moving - target)^2)."""
+    B = 3
+    tgt = torch.cat([ph.blobs(shape, 300 + i) for i in range(B)])
+    mov = torch.cat([ph.blobs(shape, 400 + i) for i in range(B)])
+    for _ in range(2):   # twice: a stale-LDS bug shows up as run-to-run differences
+        s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(w_mse=1.0), lr=0.0, capacity=1)
+        s.run(1)
+        torch.cuda.synchronize()
+        ref = ((mov.double() - tgt.double()) ** 2).mean(dim=(1, 2, 3, 4)).numpy()
+        assert np.allclose(s.losses[:, 0].cpu().numpy(), ref, rtol=2e-6, atol=0)

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Secondary timings (development): flow step (SGD/Adam/smooth), forward warps, loss-only; 256^3."""
+import sys, os, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torchregister_amd as tr
+from torchregister_amd import _engine as eng
+from bench import blobs_gpu, THETA_STAR
+
+def timeit(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3   # us
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dev = torch.device("cuda")
+shape = (S,) * 3
+N = S ** 3
+tgt = blobs_gpu(shape, 1000, dev)
+mov = tr.get_affine_warp(torch.tensor(THETA_STAR, device=dev)[None], tgt)
+def rep(name, us, nbytes):
+    print(f"{name:38s} {us:10.1f} us   {nbytes / us / 1e6:6.2f} TB/s algorithmic")
+for opt, bpv in (("sgd", 52), ("adam", 100)):
+    fs = tr.FlowSolver(mov, tgt, loss=tr.LossSpec(w_ncc=1.0), optimizer=opt, lr=1.0 if opt == "sgd" else 0.01, capacity=64)
+    rep(f"flow step NCC+{opt} (1 pair)", timeit(lambda: fs.run(1)), bpv * N)
+fs = tr.FlowSolver(mov, tgt, loss=tr.LossSpec(w_ncc=1.0), optimizer="adam", lr=0.01, capacity=64, smooth_weight=1.0)
+rep("flow step NCC+adam+smooth (1 pair)", timeit(lambda: fs.run(2)) / 2, 124 * N)
+fl = fs.flow
+rep("flow_warp 1ch", timeit(lambda: eng.flow_warp(mov, fl)), 20 * N)
+th = torch.tensor(THETA_STAR, device=dev)[None]
+rep("affine_warp 1ch (1 pair)", timeit(lambda: eng.affine_warp(th, mov)), 8 * N)
+mov8 = mov.expand(8, 1, *shape).contiguous()
+rep("affine_warp 1ch (8 pairs)", timeit(lambda: eng.affine_warp(th.expand(8, 3, 4).contiguous(), mov8)), 8 * N * 8)
+s = tr.AffineSolver(mov, tgt, loss=tr.LossSpec(w_ncc=1.0), lr=1e-6, capacity=64)
+rep("affine step (1 pair)", timeit(lambda: s.run(1)), 8 * N)
+rep("affine loss-only (1 pair)", timeit(lambda: s.eval_loss()), 8 * N)

@@ -224,6 +224,9 @@ __device__ __forceinline__ void f1_accumulate(const Samp3 &sm, float yv, float y
     }
 }
 
+#ifndef TRX_DBG_SKIP
+#define TRX_DBG_SKIP 0   // development ablation (tools/kbench.hip): 1 = no gather/compute, 2 = no box staging, 3 = no target loads
+#endif
 #ifndef TRX_TILE_MIN_WAVES
 #define TRX_TILE_MIN_WAVES 4   // waves per SIMD the register allocator must allow (2 blocks x 8 waves per CU)
 #endif
@@ -387,15 +390,15 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     acc.M01 = acc.M23 = (f2)(0.f);
     acc.M4 = 0.f;
     const int j0 = lh * kRows;                              // first row of this thread's half
-    const float *__restrict__ tp = tgt + (size_t)z * H * W + x;
+    const int toff = (z * H + j0) * W + x;                  // this thread's target offset inside a tile's row block
 
-    for (int ty = yseg * tg.tiles_per_seg; ty < min((yseg + 1) * tg.tiles_per_seg, tg.nty); ty++) {
-        const int Y0 = ty * kTY;
-        const int ny = min(kTY, H - Y0);
-        // row tables of this tile, one row per lane (lanes 0..15), broadcast later with v_readlane
-        const float yn_l = ytab[Y0 + min(lane & (kTY - 1), ny - 1)];
-        const float yid_l = unnorm<3>(yn_l, fH);
-        const float yn0 = lane_bcast(yn_l, 0), yid0 = lane_bcast(yid_l, 0);
+    // Geometry of up to 64 tiles at a time, ONE TILE PER LANE (the per-tile cost is then a few
+    // v_readlane instead of ~40 VALU instructions): box origin, needed extent, fits / interior flags.
+    const int ty_begin = yseg * tg.tiles_per_seg, ty_end = min((yseg + 1) * tg.tiles_per_seg, tg.nty);
+    int g_ox = 0, g_oy = 0, g_oz = 0, g_pk = 0;
+    auto lane_geometry = [&](int ty_first) {
+        const int ty = min(ty_first + lane, tg.nty - 1);
+        const float yn0 = ytab[ty * kTY], yid0 = unnorm<3>(yn0, fH);
         const float cx = fmaf(sx, yn0, corner_x), cy = yid0 + fmaf(sy, yn0, corner_y), cz = fmaf(sz, yn0, corner_z);
         const float slack = 0.05f;   // fp32 rounding + table non-uniformity of interior points vs the corner + extent bound
         bool fits = vec_ok && (fabsf(cx) < 1.0e6f) && (fabsf(cy) < 1.0e6f) && (fabsf(cz) < 1.0e6f);   // also rejects NaN
@@ -411,37 +414,60 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             // the whole box capacity lies inside the volume: no zero padding needed for this tile
             interior = (ox >= 0) && (oy >= 0) && (oz >= 0) && (ox + kBW <= W) && (oy + kBH <= H) && (oz + kBD <= D);
         }
-        fits = __builtin_amdgcn_readfirstlane(fits);        // block-uniform by construction
-        interior = __builtin_amdgcn_readfirstlane(interior);
-        ex4 = __builtin_amdgcn_readfirstlane(ex4); ey = __builtin_amdgcn_readfirstlane(ey); ez = __builtin_amdgcn_readfirstlane(ez);
+        g_ox = ox; g_oy = oy; g_oz = oz;
+        g_pk = fits ? ((ex4 - 1) | ((ey - 1) << 8) | ((ez - 1) << 16) | (1 << 24) | ((interior ? 1 : 0) << 25)) : 0;
+    };
+    int prev_lim = -1;
+    unsigned needmask = 0;    // bit k: DMA slot k of this thread lies inside the needed extent of the current tile
+
+    for (int ty = ty_begin; ty < ty_end; ty++) {
+        const int gl = (ty - ty_begin) & 63;
+        if (gl == 0) lane_geometry(ty);
+        const int Y0 = ty * kTY;
+        const int ny = min(kTY, H - Y0);
+        // row tables of this tile, one row per lane (lanes 0..15), broadcast later with v_readlane
+        const float yn_l = ytab[Y0 + min(lane & (kTY - 1), ny - 1)];
+        const float yid_l = unnorm<3>(yn_l, fH);
+        const int pk = __builtin_amdgcn_readlane(g_pk, gl);
+        const int ox = __builtin_amdgcn_readlane(g_ox, gl), oy = __builtin_amdgcn_readlane(g_oy, gl), oz = __builtin_amdgcn_readlane(g_oz, gl);
+        const bool fits = (pk >> 24) & 1, interior = (pk >> 25) & 1;
+        const float *__restrict__ trow = tgt + (size_t)Y0 * W;   // uniform base of this tile's target rows
 
         if (fits) {
             // ---- (1) target column into registers, box straight into LDS (LDS-DMA, no staging VGPRs) ----
             float tv[kRows];
 #pragma unroll
-            for (int j = 0; j < kRows; j++) tv[j] = tp[(size_t)(Y0 + min(j0 + j, ny - 1)) * W];
+            for (int j = 0; j < kRows; j++)
+                tv[j] = (TRX_DBG_SKIP == 3) ? 1.f : trow[(unsigned)(toff + (min(j0 + j, ny - 1) - j0) * W)];
+            const int lim = pk & 0xffffff;   // (ez-1) << 16 | (ey-1) << 8 | (ex4-1)
+            if (lim != prev_lim) {           // extents rarely change along a column: refresh the slot mask only then
+                prev_lim = lim;
+                needmask = 0;
+#pragma unroll
+                for (int k = 0; k < kBoxIters; k++)   // per-field compare (dz,dy,dx4) <= lim: no field of lim-d may borrow
+                    if ((((lim - dpk[k]) & 0x80808080) == 0) && ((dpk[k] >> 16) <= (lim >> 16))) needmask |= 1u << k;
+            }
             const int obase = (oz * H + oy) * W + ox;
             unsigned oob = 0;   // bit k: slot k of this thread is needed but lies outside the volume
             // only the float4 slots inside the tile's actual pre-image extent (ex4 x ey x ez) are fetched:
             // lanes outside it are masked off, so the bytes a CU ingests track the need, not the box capacity
-            const int lim = ((ez - 1) << 16) | ((ey - 1) << 8) | (ex4 - 1);
+            if (interior) {
+                const float *__restrict__ mbase = mov + obase;    // uniform; obase >= 0 here
 #pragma unroll
-            for (int k = 0; k < kBoxIters; k++) {
-                const int d = dpk[k];
-                // per-field compare of (dz,dy,dx4) <= (ez-1,ey-1,ex4-1): no field of lim-d may borrow
-                const bool need = (((lim - d) & 0x80808080) == 0) && ((d >> 16) < ez);
-                if (need) {
-                    unsigned idx;
-                    if (interior) {
-                        idx = (unsigned)(obase + rel[k]);
-                    } else {
+                for (int k = 0; k < kBoxIters; k++)
+                    if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2)
+                        __builtin_amdgcn_global_load_lds(mbase + (unsigned)rel[k], box + (k * kTileWaves + wave) * 256, 16, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < kBoxIters; k++)
+                    if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2) {
+                        const int d = dpk[k];
                         const int gz = oz + (d >> 16), gy = oy + ((d >> 8) & 0xff), gx = ox + (d & 0xff) * 4;
                         const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-                        idx = inb ? (unsigned)(obase + rel[k]) : 0u;
+                        const unsigned idx = inb ? (unsigned)(obase + rel[k]) : 0u;
                         if (!inb) oob |= 1u << k;
+                        __builtin_amdgcn_global_load_lds(mov + idx, box + (k * kTileWaves + wave) * 256, 16, 0, 0);
                     }
-                    __builtin_amdgcn_global_load_lds(mov + idx, box + (k * kTileWaves + wave) * 256, 16, 0, 0);
-                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (oob) {   // zero padding: cells outside the volume (boundary tiles only)
@@ -452,11 +478,16 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             }
             __syncthreads();
             // ---- (2) gather from LDS ----------------------------------------------------------------
-            if (act) {
+            // wave-uniform row constants of this wave's half (rows j0 .. j0+7) -> SGPRs.  The v_readlane MUST
+            // run here, in uniform control flow: inside `if (act)` lanes 0..15 may be inactive (partial x tile)
+            // and the compiler is free to sink the computation of yn_l / yid_l into that branch.
+            float yn_r[kRows], yid_r[kRows];
+#pragma unroll
+            for (int j = 0; j < kRows; j++) { yn_r[j] = lane_bcast(yn_l, j0 + j); yid_r[j] = lane_bcast(yid_l, j0 + j); }
+            if (act && TRX_DBG_SKIP != 1) {
                 const float *bp = box - ((oz * kBH + oy) * kBW + ox);   // box address of voxel (0,0,0) of the volume
                 auto voxel = [&](int j) {
-                    // wave-uniform row constants (this wave's half: rows j0 .. j0+7), v_readlane with an SGPR lane
-                    const float yn = lane_bcast(yn_l, j0 + j), yid = lane_bcast(yid_l, j0 + j);
+                    const float yn = yn_r[j], yid = yid_r[j];
                     const float ix = fmaf(sx, yn, base_x);
                     const float iy = yid + fmaf(sy, yn, base_y);
                     const float iz = fmaf(sz, yn, base_z);
@@ -486,7 +517,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                 const float ix = fmaf(sx, yn, base_x);
                 const float iy = unnorm<3>(yn, fH) + fmaf(sy, yn, base_y);
                 const float iz = fmaf(sz, yn, base_z);
-                const float yv = tp[(size_t)(Y0 + j) * W];
+                const float yv = trow[(unsigned)(toff + (j - j0) * W)];
                 const Samp3 sm = sample3(mov, D, H, W, ix, iy, iz);
                 f1_accumulate_pk<MODE>(sm, yv, yn, acc);
             }
