@@ -101,13 +101,13 @@ int main(int argc, char **argv)
     trx::TileGeom tgm = trx::tile_geom(vol);
     printf("tile geom: %d x %d x %d tiles, %d blocks/pair\n", tgm.ntx, tgm.nty, tgm.ntz, tgm.blocks_per_pair);
     dim3 tgrid(tgm.blocks_per_pair, B);
-    rep("tile MODE1 (moments)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<1>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, partials); }, 20));
-    rep("tile MODE0 (full F1)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, partials); }, 20));
+    rep("tile MODE1 (moments)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<1>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
+    rep("tile MODE0 (full F1)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
     // identity theta (all samples on voxel centres)
     const float id[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = id[i];
     CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
     rep("accum MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_accum_kernel<3, 0>), grid, block, 0, 0, vol, theta, g, 1, (size_t)0, partials); }, 20));
-    rep("tile MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, partials); }, 20));
+    rep("tile MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
     return 0;
 }

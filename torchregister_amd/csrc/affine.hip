@@ -311,16 +311,21 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) { return __int_as
 // bit); for any other theta this is the same affine map to within fp32 rounding, at 4 VALU ops / voxel.
 template <int MODE>
 __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_kernel(trx_volumes vol, const float *__restrict__ theta,
-                                                                                        TileGeom tg, float *__restrict__ partials)
+                                                                                        TileGeom tg, int channels, float *__restrict__ partials)
 {
+    // MODE 0: F1 sums, MODE 1: moments only, MODE 3: forward warp (writes the warped volume to `partials`
+    // = out[B][channels][D][H][W]; blockIdx.y enumerates (pair, channel), channels share theta)
     constexpr int NQ = (MODE == 0) ? 3 : 0;
     constexpr int NP = (MODE == 0) ? np_full(3) : 5;
     __shared__ __attribute__((aligned(16))) float box[kBoxAlloc];
-    const int b = blockIdx.y;
+    const int b = (MODE == 3) ? blockIdx.y / channels : blockIdx.y;
+    const int ch = (MODE == 3) ? blockIdx.y - b * channels : 0;
     const int D = vol.D, H = vol.H, W = vol.W;
     const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
-    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
-    const float *__restrict__ tgt = vol.target + (size_t)b * vol.target_stride;
+    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride + (size_t)ch * D * H * W;
+    // MODE 3 has no target: `tgt` is the OUTPUT volume of this (pair, channel)
+    float *__restrict__ wout = partials + (size_t)blockIdx.y * D * H * W;
+    const float *__restrict__ tgt = (MODE == 3) ? wout : vol.target + (size_t)b * vol.target_stride;
     const float *__restrict__ xtab = vol.xn, *__restrict__ ytab = vol.yn, *__restrict__ ztab = vol.zn;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform (SGPR)
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             float tv[kRows];
 #pragma unroll
             for (int j = 0; j < kRows; j++)
-                tv[j] = (TRX_DBG_SKIP == 3) ? 1.f : trow[(unsigned)(toff + (min(j0 + j, ny - 1) - j0) * W)];
+                tv[j] = (TRX_DBG_SKIP == 3 || MODE == 3) ? 1.f : trow[(unsigned)(toff + (min(j0 + j, ny - 1) - j0) * W)];
             const int lim = pk & 0xffffff;   // (ez-1) << 16 | (ey-1) << 8 | (ex4-1)
             if (lim != prev_lim) {           // extents rarely change along a column: refresh the slot mask only then
                 prev_lim = lim;
@@ -497,7 +502,8 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                     const f2 r10 = *reinterpret_cast<const f2u *>(p + kBW * kBH), r11 = *reinterpret_cast<const f2u *>(p + kBW * kBH + kBW);
                     const Samp3 sm = lerp3_pairs<MODE == 0>(r00, r01, r10, r11, __builtin_amdgcn_fractf(ix), __builtin_amdgcn_fractf(iy),
                                                             __builtin_amdgcn_fractf(iz));
-                    f1_accumulate_pk<MODE>(sm, tv[j], yn, acc);
+                    if constexpr (MODE == 3) wout[(size_t)Y0 * W + (unsigned)(toff + j * W)] = sm.v;
+                    else f1_accumulate_pk<MODE>(sm, tv[j], yn, acc);
                 };
                 if (ny == kTY) {
 #pragma unroll
@@ -517,13 +523,18 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                 const float ix = fmaf(sx, yn, base_x);
                 const float iy = unnorm<3>(yn, fH) + fmaf(sy, yn, base_y);
                 const float iz = fmaf(sz, yn, base_z);
-                const float yv = trow[(unsigned)(toff + (j - j0) * W)];
                 const Samp3 sm = sample3(mov, D, H, W, ix, iy, iz);
-                f1_accumulate_pk<MODE>(sm, yv, yn, acc);
+                if constexpr (MODE == 3) {
+                    wout[(size_t)Y0 * W + (unsigned)(toff + (j - j0) * W)] = sm.v;
+                } else {
+                    const float yv = trow[(unsigned)(toff + (j - j0) * W)];
+                    f1_accumulate_pk<MODE>(sm, yv, yn, acc);
+                }
             }
         }
     }
 
+    if constexpr (MODE == 3) return;
     float vals[NP];
     vals[0] = acc.M01.x; vals[1] = acc.M01.y; vals[2] = acc.M23.x; vals[3] = acc.M23.y; vals[4] = acc.M4;
     int o = 5;
@@ -854,7 +865,7 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             TRX_CHECK_LAUNCH();
             v.xn = tab; v.yn = tab + v.W; v.zn = tab + v.W + v.H;
         }
-        hipLaunchKernelGGL((affine_tile_kernel<MODE>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, partials);
+        hipLaunchKernelGGL((affine_tile_kernel<MODE>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
         TRX_CHECK_LAUNCH();
         *nblk = t.blocks_per_pair;
         return TRX_OK;
@@ -935,8 +946,19 @@ extern "C" int trx_affine_warp(const trx_volumes *vol, const float *theta, int c
     int rc = check_vol(vol, false);
     if (rc) return rc;
     if (!theta || !out || channels < 1) return TRX_ERR_ARG;
+    if ((long)vol->B * channels > 65535) return TRX_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const size_t nvox = (size_t)vol->D * vol->H * vol->W;
+    if (use_tile_path(vol) && vol->xn && vol->yn && vol->zn) {
+        // LDS-tiled forward warp (same staging as the F1 pass); needs the caller's coordinate tables
+        trx_volumes v = *vol;
+        v.B = vol->B * channels;                       // geometry: every (pair, channel) is one slab of blocks
+        TileGeom t = tile_geom(v);
+        v.B = vol->B;
+        hipLaunchKernelGGL((affine_tile_kernel<3>), dim3(t.blocks_per_pair, vol->B * channels), dim3(kTileThreads), 0, s, v, theta, t, channels, out);
+        TRX_CHECK_LAUNCH();
+        return TRX_OK;
+    }
     size_t nb = (nvox + TRX_BLOCK - 1) / TRX_BLOCK;
     if (nb > 8192) nb = 8192;
     dim3 grid((unsigned)nb, vol->B), block(TRX_BLOCK);
