@@ -293,6 +293,36 @@ def flow_deform_semantics(out):
     out["deform/shape"] = np.asarray(shape)
 
 
+def flow_unet(out, name, shape, crit_names, weights, lr, epochs, seed):
+    """The reference's own flow mode (attention U-Net generates the flow; ref:warpings.py:178-242,
+    ref:utils.py:409-559) through Register, n=32.  The flow and warp are stored on a stride-4 lattice."""
+    nd = len(shape)
+    tgt = ph.blobs(shape, 1000 + seed)
+    star = ph.THETA_STAR3 if nd == 3 else ph.THETA_STAR2
+    mov = tr.get_affine_warp(torch.tensor(star)[None], tgt).detach()
+    crits = [{"ncc": tr.NCCLoss(), "mse": nn.MSELoss()}[c] for c in crit_names]
+    hook = CurveHook()
+    old = warpings.plt.plot
+    warpings.plt.plot = hook
+    try:
+        torch.manual_seed(seed)
+        reg = tr.Register(mode="flow", device="cpu", criterion=crits, weight=weights, debug=True)
+        with quiet():
+            reg.optim(mov, tgt, lr=lr, max_epochs=epochs, n=32)
+            w = reg(torch.cat([mov, 0.5 * mov + 0.25], dim=1))
+    finally:
+        warpings.plt.plot = old
+    sl = (slice(None), slice(None)) + (slice(None, None, 4),) * nd
+    out[f"{name}/losses"] = np.asarray(hook.curve, dtype=np.float64)
+    out[f"{name}/flow_s4"] = npf(reg.theta)[sl]
+    out[f"{name}/call2c_s4"] = npf(w)[sl]
+    out[f"{name}/flow_absmax"] = np.float64(npf(reg.theta).__abs__().max())
+    out[f"{name}/moving"] = npf(mov)
+    out[f"{name}/meta"] = np.asarray([lr, epochs, seed] + list(weights), dtype=np.float64)
+    out[f"{name}/shape"] = np.asarray(shape)
+    print(f"  {name}: loss {hook.curve[0]:.6f} -> {hook.curve[-1]:.6f}; |flow|max {out[f'{name}/flow_absmax']:.3f}")
+
+
 def check_kats(ss, tj):
     """SURVEY §8c KAT values (produced by the same import in the survey session)."""
     def close(a, b, tol=2e-6):
@@ -371,6 +401,8 @@ def main():
     composed_flow(tj, "c_flow3d_ncc", (12, 14, 16), "ncc", 2.0, 30, 9)
     composed_flow(tj, "c_flow3d_mse", (12, 14, 16), "mse", 2000.0, 30, 10)
     composed_flow(tj, "c_flow2d_ncc", (24, 28), "ncc", 1.0, 30, 11)
+    flow_unet(tj, "unet2d_ncc", (160, 160), ["ncc"], [1.0], 1e-3, 8, 12)
+    flow_unet(tj, "unet2d_mix", (156, 172), ["mse", "ncc"], [0.5, 0.5], 1e-3, 6, 13)
 
     check_kats(ss, tj)
     np.savez_compressed(os.path.join(HERE, "single_step.npz"), **ss)

@@ -117,7 +117,7 @@ def test_register_flow_mode(tr, trajectories, single_step):
     name = "c_flow3d_ncc"
     lr, iters = float(g[f"{name}/meta"][0]), int(g[f"{name}/meta"][1])
     mov, tgt = _mov_tgt(g, name)
-    reg = tr.Register("flow", device="cuda", criterion=[tr.NCCLoss()], weight=[1.0])
+    reg = tr.Register("flow", device="cuda", criterion=[tr.NCCLoss()], weight=[1.0], flow_model="direct")
     reg.optim(mov, tgt, lr=lr, max_epochs=iters)
     l32, l64 = g[f"{name}/losses32"], g[f"{name}/losses64"]
     assert np.max(np.abs(reg.losses[0].cpu().numpy() - l32)) <= bar(l32, l64, 1e-4 * np.max(np.abs(l64)))
@@ -147,3 +147,36 @@ def test_register_batch_extension(tr):
     assert reg.theta.shape == (4, 3, 4) and reg.losses.shape == (4, 50)
     assert (reg.losses[:, -1] < reg.losses[:, 0]).all()
     assert reg(movs).shape == movs.shape
+
+
+@pytest.mark.parametrize("name,crit", [("unet2d_ncc", ["ncc"]), ("unet2d_mix", ["mse", "ncc"])])
+def test_register_flow_mode_unet_vs_reference(tr, trajectories, name, crit):
+    """mode='flow' as the reference runs it: the attention U-Net (same seed -> same weights) generates the flow,
+    warp + loss + backward in the fused HIP kernels.  The convolutions run on MIOpen here and on MKL-DNN in the
+    reference run, so the tolerance is looser than for the pure-HIP paths: loss 5e-3 rel, flow 2 % of its range."""
+    g = trajectories
+    lr, iters, seed = float(g[f"{name}/meta"][0]), int(g[f"{name}/meta"][1]), int(g[f"{name}/meta"][2])
+    weights = [float(v) for v in g[f"{name}/meta"][3:]]
+    shape = tuple(g[f"{name}/shape"])
+    mov, tgt = torch.from_numpy(g[f"{name}/moving"]).cuda(), ph.blobs(shape, 1000 + seed).cuda()
+    crits = [{"ncc": tr.NCCLoss(), "mse": nn.MSELoss()}[c] for c in crit]
+    torch.manual_seed(seed)
+    reg = tr.Register("flow", device="cuda", criterion=crits, weight=weights)
+    reg.optim(mov, tgt, lr=lr, max_epochs=iters, n=32)
+    gl = g[f"{name}/losses"]
+    assert reg.losses.shape[1] == len(gl)
+    assert np.max(np.abs(reg.losses[0].cpu().numpy() - gl)) <= 5e-3 * np.max(np.abs(gl))
+    fl = reg.theta.cpu().numpy()[:, :, ::4, ::4]
+    assert np.max(np.abs(fl - g[f"{name}/flow_s4"])) <= 0.02 * float(g[f"{name}/flow_absmax"])
+    w = reg(torch.cat([mov, 0.5 * mov + 0.25], dim=1)).cpu().numpy()[:, :, ::4, ::4]
+    assert np.max(np.abs(w - g[f"{name}/call2c_s4"])) <= 0.02
+
+
+def test_unet_seeded_weights_and_flow_match_reference_on_cpu_shapes(tr):
+    """Attention_UNet: parameter names/shapes as in the reference (n=32: 31 278 parameters in 2-D, 89 189 in 3-D)."""
+    m2 = tr.Attention_UNet((160, 160), "bilinear", in_c=1, n=32)
+    assert sum(p.numel() for p in m2.parameters()) == 31278
+    m3 = tr.Attention_UNet((156, 156, 156), "bilinear", in_c=1, n=32)
+    assert sum(p.numel() for p in m3.parameters()) == 89189
+    names = [n for n, _ in m2.named_parameters()]
+    assert names[0] == "layer1.0.weight" and "skip1.input_filter.weight" in names and names[-1] == "out.bias"

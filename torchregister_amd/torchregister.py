@@ -2,7 +2,8 @@
 
 Same constructor, `optim` and `__call__` signatures and the same criterion/weight branching
 (ref:torchregister.py:70-106).  Extensions are keyword-only and default to reference behaviour:
-optimizer ('sgd'|'adam'), honor_criterion, init, smooth_weight; after `optim`, `.losses`
+optimizer ('sgd'|'adam'), honor_criterion, init, smooth_weight, flow_model ('unet' = the reference's
+U-Net-generated flow, 'direct' = the flow field itself is the parameter); after `optim`, `.losses`
 (the loss curve the reference only plots), `.final_theta` and `.best_idx` are available.
 """
 import torch
@@ -13,7 +14,7 @@ from .warpings import affine_register, flow_register, get_affine_warp, rigid_reg
 
 class Register():
     def __init__(self, mode='rigid', device='cpu', criterion=None, weight=None, grad_edges=False, debug=False, *,
-                 optimizer='sgd', honor_criterion=False, init=None, smooth_weight=0.0):
+                 optimizer='sgd', honor_criterion=False, init=None, smooth_weight=0.0, flow_model='unet'):
         '''
         Numerical registration on an AMD GPU (MI355X) behind the TorchRegister API.
 
@@ -43,6 +44,7 @@ class Register():
         self.honor_criterion = honor_criterion
         self.init = init
         self.smooth_weight = smooth_weight
+        self.flow_model = flow_model
         self.losses = None
         self.final_theta = None
         self.best_idx = None
@@ -54,12 +56,13 @@ class Register():
         [B,nd,...] of the last forward in flow mode) and self.warp.  Returns None.
         '''
         if self.mode == 'flow':
-            kw = dict(mode='bilinear', n=n, lr=lr, max_epochs=max_epochs, optimizer=self.optimizer, smooth_weight=self.smooth_weight)
+            kw = dict(mode='bilinear', n=n, lr=lr, max_epochs=max_epochs, optimizer=self.optimizer, smooth_weight=self.smooth_weight,
+                      flow_model=self.flow_model)
             if self.criterion is not None and self.weight is not None:       # ref:torchregister.py:71-73
                 kw.update(criterions=self.criterion, weights=self.weight)
             elif self.weight is not None:                                     # ref:torchregister.py:74-76
                 kw.update(weights=self.weight)
-            flowreg = flow_register(target.shape[2:], **kw)
+            flowreg = flow_register(target.shape[2:], **kw).to(moving.device)
             flowreg.optimize(moving, target, self.device, self.debug)
             self.theta = flowreg.flow
             self.warp = flowreg.deform

@@ -23,13 +23,14 @@ def norm(x):
 
 
 def padNd(input_, target, device="cpu", mode="constant", value=0):
-    """Centre-pad input_ to target's spatial size, extra voxel in front (ref:utils.py:271-277)."""
+    """Centre-pad input_ to target's spatial size; an odd difference puts the extra voxel at the END of
+    the axis (the reference flips its [ceil, floor] pairs before handing them to F.pad, ref:utils.py:271-277)."""
     dims = input_.dim() - 2
     pads = []
     for i in reversed(range(dims)):
         delta = target.shape[2 + i] - input_.shape[2 + i]
-        front = -(-delta // 2)
-        pads += [front, delta - front]
+        back = -(-delta // 2)
+        pads += [delta - back, back]
     return F.pad(input_, tuple(pads), mode=mode, value=value).to(dtype=torch.float, device=device)
 
 
@@ -188,3 +189,92 @@ class SpatialTransformer(nn.Module):
         if src.shape[0] != flow.shape[0]:
             flow = flow.expand(src.shape[0], *flow.shape[1:])
         return _FlowWarpFn.apply(src, flow)
+
+
+# ----------------------------------------------------------------------------------------------
+# Attention U-Net that GENERATES the flow in the reference's flow mode (ref:utils.py:368-559).
+# Host-side PyTorch-ROCm code (MIOpen convolutions) — SURVEY section 8f row 1; the warp at its end and
+# its backward are the HIP flow kernels (SpatialTransformer above).  Modules are created in the same
+# order, with the same shapes, as the reference so that a given torch seed yields the same weights.
+# ----------------------------------------------------------------------------------------------
+def _conv(dims):
+    return (nn.Conv3d, nn.ConvTranspose3d, nn.InstanceNorm3d, nn.MaxPool3d) if dims == 3 else (nn.Conv2d, nn.ConvTranspose2d, nn.InstanceNorm2d, nn.MaxPool2d)
+
+
+class attention_grid(nn.Module):
+    """Attention gate: 1x1 strided filter of the skip tensor + 1x1 filter of the gating tensor -> sigmoid map,
+    resampled (nearest) to the skip tensor and applied to it, then instance-normalised (ref:utils.py:368-406)."""
+
+    def __init__(self, x_c, g_c, i_c, stride=3, mode='nearest', dims=3):
+        super().__init__()
+        Conv, _, Norm, _ = _conv(dims)
+        self.input_filter = Conv(in_channels=x_c, out_channels=i_c, kernel_size=1, stride=stride, bias=False)
+        self.gate_filter = Conv(in_channels=g_c, out_channels=i_c, kernel_size=1, stride=1, bias=True)
+        self.psi = Conv(in_channels=i_c, out_channels=1, kernel_size=1, stride=1, bias=True)
+        self.bnorm = Norm(i_c)
+        self.mode = mode
+
+    def forward(self, x, g, device):
+        a = self.input_filter(x)
+        b = self.gate_filter(g)
+        if a.shape[-1] < b.shape[-1]:
+            a = padNd(a, b, device)
+        elif a.shape[-1] > b.shape[-1]:
+            b = padNd(b, a, device)
+        w = torch.sigmoid(self.psi(F.relu(a + b)))
+        w = F.interpolate(w, size=x.shape[2:], mode=self.mode)
+        return self.bnorm(x * w), w
+
+
+class Attention_UNet(nn.Module):
+    """9-stage valid-convolution U-Net with attention-gated skips; channels (64,128,256,512,1024)/n; input =
+    the moving image, output = (warped, flow[nd]) (ref:utils.py:409-559)."""
+
+    def __init__(self, img_size, mode='nearest', in_c=1, n=1):
+        super().__init__()
+        dims = len(img_size)
+        Conv, ConvT, Norm, Pool = _conv(dims)
+        c = [int(v / n) for v in (64, 128, 256, 512, 1024)]
+
+        def double(i, o):
+            return [Conv(in_channels=i, out_channels=o, kernel_size=3), nn.ReLU(), Norm(o),
+                    Conv(in_channels=o, out_channels=o, kernel_size=3), nn.ReLU(), Norm(o)]
+
+        def up(i, o):
+            return [ConvT(in_channels=i, out_channels=o, kernel_size=2, stride=2), nn.ReLU(), Norm(o)]
+
+        # creation order matters for seeded-initialisation parity with the reference
+        self.layer1 = nn.Sequential(*double(in_c, c[0]))
+        self.skip1 = attention_grid(c[0], c[0], c[0], dims=dims)
+        self.layer2 = nn.Sequential(*double(c[0], c[1]))
+        self.skip2 = attention_grid(c[1], c[1], c[1], dims=dims)
+        self.layer3 = nn.Sequential(*double(c[1], c[2]))
+        self.skip3 = attention_grid(c[2], c[2], c[2], dims=dims)
+        self.layer4 = nn.Sequential(*double(c[2], c[3]))
+        self.skip4 = attention_grid(c[3], c[3], c[3], dims=dims)
+        self.layer5 = nn.Sequential(*(double(c[3], c[4]) + up(c[4], c[3])))
+        self.layer6 = nn.Sequential(*(double(c[4], c[3]) + up(c[3], c[2])))
+        self.layer7 = nn.Sequential(*(double(c[3], c[2]) + up(c[2], c[1])))
+        self.layer8 = nn.Sequential(*(double(c[2], c[1]) + up(c[1], c[0])))
+        self.layer9 = nn.Sequential(*double(c[1], c[0]))
+        self.out = Conv(in_channels=c[0], out_channels=dims, kernel_size=1)
+        self.maxpool = Pool(kernel_size=2, stride=2)
+        self.warp = SpatialTransformer(img_size, 'bilinear' if mode == 'bilinear' else mode)
+
+    def features(self, x, device=None):
+        """Everything up to the flow head: returns flow [B, nd, *spatial] (no warp)."""
+        device = x.device if device is None else device
+        y1 = self.layer1(x)
+        y2 = self.layer2(self.maxpool(y1))
+        y3 = self.layer3(self.maxpool(y2))
+        y4 = self.layer4(self.maxpool(y3))
+        y = self.layer5(self.maxpool(y4))
+        for skip, ys, layer in ((self.skip4, y4, self.layer6), (self.skip3, y3, self.layer7), (self.skip2, y2, self.layer8),
+                                (self.skip1, y1, self.layer9)):
+            ys, _ = skip(ys, y, device=device)
+            y = layer(torch.cat((ys, padNd(y, ys, device=device)), dim=1))
+        return self.out(padNd(y, x, device=device))
+
+    def forward(self, x, device=None, out_att=False):
+        flow = self.features(x, device)
+        return self.warp(x, flow), flow

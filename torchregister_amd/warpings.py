@@ -156,39 +156,74 @@ def rigid_register(moving, target, lr=1E-5, epochs=1000, per=0.1, device="cpu", 
                           honor_criterion, optimizer, init, info)
 
 
+class _FlowLossFn(torch.autograd.Function):
+    """Fused warp + MSE/NCC/SSD loss of a given flow: value and dL/dflow from two streaming HIP passes
+    (trx_flow_loss_grad).  This is the autograd boundary between the U-Net (torch/MIOpen) and the HIP path."""
+
+    @staticmethod
+    def forward(ctx, flow, moving, target, spec):
+        terms, dflow = _engine.flow_loss_grad(moving, target, flow, spec, need_grad=True)
+        ctx.save_for_backward(dflow)
+        return terms[:, 0].sum()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dflow,) = ctx.saved_tensors
+        return grad_out * dflow, None, None, None
+
+
 class flow_register(nn.Module):
     """Dense flow-field registration (ref:warpings.py:178-242).
 
-    Parameterisation: the flow field itself (north-star "flow-field composition" path), optimised by the
-    fused two-pass HIP kernels.  The reference generates the flow with an attention U-Net whose weights
-    are the parameters (not built yet): `n` and `in_c` are accepted for signature
-    compatibility and ignored.  Everything downstream — `.flow` in voxel units with channel i along
-    spatial dim i, `.warp` (SpatialTransformer), `.deform(x)`, early stop at stop_crit — follows the
-    reference."""
+    flow_model='unet' (default, the reference's behaviour): an attention U-Net (utils.Attention_UNet, torch /
+    MIOpen host code) maps the moving image to the flow and its weights are the parameters; the warp + loss +
+    their backward run in the fused HIP flow kernels behind one autograd.Function.
+    flow_model='direct' (extension, the north-star "flow-field composition" path): the flow field itself is
+    the parameter, optimised entirely by the two-pass HIP kernels with no per-iteration host sync
+    (`n` / `in_c` unused; optional Adam and smoothness regulariser).
+    Either way `.flow` (voxel units, channel i along spatial dim i; the flow of the LAST FORWARD like the
+    reference's), `.warp` (SpatialTransformer), `.deform(x)` and the stop_crit early stop follow the reference."""
 
     def __init__(self, img_size, mode="bilinear", in_c=1, n=1, criterions=None, weights=[0.33, 0.33, 0.33], lr=1E-3,
-                 max_epochs=2000, stop_crit=1E-4, *, optimizer="sgd", smooth_weight=0.0):
+                 max_epochs=2000, stop_crit=1E-4, *, flow_model="unet", optimizer="sgd", smooth_weight=0.0):
         super().__init__()
+        if flow_model not in ("unet", "direct"):
+            raise ValueError("flow_model must be 'unet' or 'direct'")
         self.img_size = tuple(int(s) for s in img_size)
+        self.flow_model = flow_model
         self.criterions = [nn.MSELoss(), NCCLoss(), NMILoss()] if criterions is None else criterions
         self.weights, self.lr, self.max_epochs, self.stop_crit = weights, lr, max_epochs, stop_crit
         self.optimizer_kind, self.smooth_weight = optimizer, smooth_weight
-        self.warp = SpatialTransformer(self.img_size, mode)
+        if flow_model == "unet":
+            from .utils import Attention_UNet
+            self.model = Attention_UNet(self.img_size, mode, in_c=in_c, n=n)
+            self.warp = self.model.warp
+            self.optimizer = (torch.optim.SGD if optimizer == "sgd" else torch.optim.Adam)(self.model.parameters(), lr)
+        else:
+            self.model = None
+            self.warp = SpatialTransformer(self.img_size, mode)
         self.flow = None
+        self.final_flow = None
         self.losses = None
 
     def forward(self, x, device=None):
+        if self.model is not None:
+            y, self.flow = self.model(x, device)
+            return y
         return self.warp(x, self.flow)
 
     def optimize(self, moving, target, device=None, debug=True, grad_edges=False, check_every=50):
         if grad_edges:
             raise NotImplementedError("grad_edges=True is not supported (SURVEY Q6)")
         spec = loss_spec_from(self.criterions, self.weights[: len(self.criterions)])
+        if self.flow_model == "unet":
+            return self._optimize_unet(moving, target, spec, debug)
         if spec is None:
             return self._optimize_generic(moving, target, debug)
         solver = FlowSolver(moving, target, loss=spec, optimizer=self.optimizer_kind, lr=self.lr, capacity=max(1, self.max_epochs),
                             smooth_weight=self.smooth_weight)
         done, message = 0, "Reached max epochs"
+        last_forward = None
         while done < self.max_epochs:
             n = min(check_every, self.max_epochs - done)
             # the flow that produced loss[done-1] is the one BEFORE that step's update: the reference
@@ -199,7 +234,6 @@ class flow_register(nn.Module):
                 solver.run(1)
             else:
                 solver.run(n)
-                last_forward = None
             done += n
             ls = solver.losses[0, done - n:done]
             hit = torch.nonzero(ls <= self.stop_crit)
@@ -210,6 +244,30 @@ class flow_register(nn.Module):
         self.flow = last_forward if last_forward is not None else solver.flow
         self.final_flow = solver.flow
         self.losses = solver.losses[:, :done]
+        if debug:
+            print("Optimization ended with status: %s" % message)
+
+    def _optimize_unet(self, moving, target, spec, debug):
+        """ref:warpings.py:208-233 with the U-Net in torch and warp+loss(+backward) in HIP."""
+        self.train()
+        losses, message = [], "Reached max epochs"
+        for _ in range(self.max_epochs):
+            self.optimizer.zero_grad()
+            flow = self.model.features(moving)
+            if spec is not None:
+                err = _FlowLossFn.apply(flow, moving, target, spec)
+            else:
+                y = self.warp(moving, flow)
+                err = sum(w * c(target, y) for c, w in zip(self.criterions, self.weights))
+            err.backward()
+            self.optimizer.step()
+            self.flow = flow.detach()
+            losses.append(err.item())          # the reference syncs every iteration too (early stop)
+            if losses[-1] <= self.stop_crit:
+                message = "Converged to %f" % self.stop_crit
+                break
+        self.final_flow = self.flow
+        self.losses = torch.tensor(losses, device=moving.device)[None]
         if debug:
             print("Optimization ended with status: %s" % message)
 
