@@ -179,8 +179,11 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
 // Blocks are persistent over a contiguous run of tiles of ONE pair and keep the 41 partial sums
 // in registers; thread (x, z) is fixed inside a tile so the xn / zn columns fold once per tile.
 // ------------------------------------------------------------------------------------------
-constexpr int kTX = 32, kTY = 16, kTZ = 8;          // output tile
-constexpr int kBW = 44, kBH = 24, kBD = 14;         // LDS box (floats); kBW % 4 == 0
+#ifndef TRX_TILE_Z
+#define TRX_TILE_Z 8      // output tile depth: 8 (512-thread blocks, 2 per CU) or 4 (256-thread blocks, 4 per CU)
+#endif
+constexpr int kTX = 32, kTY = 16, kTZ = TRX_TILE_Z;                 // output tile
+constexpr int kBW = 44, kBH = 24, kBD = (TRX_TILE_Z == 8) ? 14 : 8; // LDS box (floats); kBW % 4 == 0
 constexpr int kBW4 = kBW / 4;
 
 struct TileGeom {
@@ -228,7 +231,7 @@ __device__ __forceinline__ void f1_accumulate(const Samp3 &sm, float yv, float y
 #define TRX_DBG_SKIP 0   // development ablation (tools/kbench.hip): 1 = no gather/compute, 2 = no box staging, 3 = no target loads
 #endif
 #ifndef TRX_TILE_MIN_WAVES
-#define TRX_TILE_MIN_WAVES 4   // waves per SIMD the register allocator must allow (2 blocks x 8 waves per CU)
+#define TRX_TILE_MIN_WAVES 4   // waves per SIMD the register allocator must allow (16 waves per CU)
 #endif
 // packed running sums of the tile kernel: AB[q][c] = (sum q*g_c, sum q*g_c*yn), M01 = (Sy, Sw), M23 = (Syy, Sww)
 struct F1Acc {
@@ -255,7 +258,7 @@ __device__ __forceinline__ void f1_accumulate_pk(const Samp3 &sm, float yv, floa
     }
 }
 
-constexpr int kTileThreads = 512;                       // 8 waves: (32 x) x (8 z) x (2 halves of 8 rows)
+constexpr int kTileThreads = kTX * kTZ * 2;             // (32 x) x (kTZ z) x (2 halves of 8 rows): 512 or 256 threads
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kRows = kTY / 2;                           // rows per thread
 constexpr int kBoxSlots = kBW4 * kBH * kBD;              // 3696 float4 slots
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     const float *__restrict__ xtab = vol.xn, *__restrict__ ytab = vol.yn, *__restrict__ ztab = vol.zn;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform (SGPR)
-    const int lx = tid & (kTX - 1), lz = (tid >> 5) & (kTZ - 1), lh = wave >> 2;
+    const int lx = tid & (kTX - 1), lz = (tid >> 5) & (kTZ - 1), lh = wave / (kTileWaves / 2);
     const float fW = (float)W, fH = (float)H, fD = (float)D;
     const float hW = 0.5f * fW, hH = 0.5f * fH, hD = 0.5f * fD;
     const float t00 = th[0], t01 = th[1], t02 = th[2], t03 = th[3];
@@ -673,64 +676,89 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
     __shared__ double S[64];
     const int b = blockIdx.x;
     reduce_partials<NP>(partials + (size_t)b * nblk * NP, nblk, S);
-    if (threadIdx.x != 0) return;
+    // Lane-parallel epilogue: lane i owns parameter i.  Every load of the per-pair state is issued up front
+    // by all lanes at once (ONE memory round trip; a single thread looping over the 12 parameters paid a
+    // dependent load->store chain per parameter, ~20 us); the scalar fp64 math is computed redundantly.
+    __shared__ double sh_dth[NT];
+    __shared__ float sh_pose[NPOSE];
+    const int i = threadIdx.x;
+    if (i >= 64) return;
+    const bool rigid = st.mode == TRX_PARAM_RIGID;
+    const int np = rigid ? NPOSE : NT;
+    float *param = st.param + (size_t)b * TRX_PSTRIDE;
+    float *theta = st.theta + (size_t)b * TRX_PSTRIDE;
+    const int ic = min(i, NT - 1);
+    const int t = st.step[b];
+    const float best_prev = st.best_loss[b];
+    const float theta_old = theta[ic], p_old = param[ic];
+    float m_old = 0.f, v_old = 0.f;
+    if (oc.kind == TRX_OPT_ADAM) { m_old = st.adam_m[(size_t)b * TRX_PSTRIDE + ic]; v_old = st.adam_v[(size_t)b * TRX_PSTRIDE + ic]; }
+    float pose_old[NPOSE];
+    if (rigid) {
+#pragma unroll
+        for (int k = 0; k < NPOSE; k++) pose_old[k] = param[k];
+    }
 
     const LossCoef L = loss_from_moments(S, nvox, lc);
     const double scale[3] = {0.5 * W, 0.5 * H, 0.5 * D};
-    double dth[NT];
-    for (int c = 0; c < ND; c++)
-        for (int k = 0; k <= ND; k++) {
-            const int i = c * (ND + 1) + k;
-            dth[i] = scale[c] * (L.c0 * S[5 + i] + L.cy * S[5 + NT + i] + L.cw * S[5 + 2 * NT + i]);
-        }
-
-    float *param = st.param + (size_t)b * TRX_PSTRIDE;
-    float *theta = st.theta + (size_t)b * TRX_PSTRIDE;
-    const int t = st.step[b];
+    const double dth_i = scale[ic / (ND + 1)] * (L.c0 * S[5 + ic] + L.cy * S[5 + NT + ic] + L.cw * S[5 + 2 * NT + ic]);
     const float lossf = (float)L.total;
-    if (st.losses && t < st.losses_capacity) st.losses[(size_t)b * st.losses_capacity + t] = lossf;
     // best = first strict minimum, theta of THIS forward (ref:warpings.py:85-93)
-    if (t == 0 || lossf < st.best_loss[b]) {
-        st.best_loss[b] = lossf;
-        st.best_idx[b] = t;
-        for (int i = 0; i < NT; i++) st.best_theta[(size_t)b * TRX_PSTRIDE + i] = theta[i];
+    const bool is_best = (t == 0) || (lossf < best_prev);
+    if (is_best && i < NT) st.best_theta[(size_t)b * TRX_PSTRIDE + i] = theta_old;
+    if (i == 0) {
+        if (st.losses && t < st.losses_capacity) st.losses[(size_t)b * st.losses_capacity + t] = lossf;
+        if (is_best) { st.best_loss[b] = lossf; st.best_idx[b] = t; }
+        st.step[b] = t + 1;
     }
 
-    double g[NT];
-    int np;
-    if (st.mode == TRX_PARAM_RIGID) {
-        pose_vjp<ND>(param, dth, g);
-        np = NPOSE;
-    } else {
-        for (int i = 0; i < NT; i++) g[i] = dth[i];
-        np = NT;
+    double g_i = dth_i;
+    if (rigid) {
+        if (i < NT) sh_dth[i] = dth_i;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        double dth[NT], g[NT];
+#pragma unroll
+        for (int k = 0; k < NT; k++) dth[k] = sh_dth[k];
+        pose_vjp<ND>(pose_old, dth, g);
+        g_i = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPOSE; k++) g_i = (k == i) ? g[k] : g_i;
     }
-    for (int i = 0; i < np; i++) {
-        const float gf = (float)g[i];
+    float p_new = p_old;
+    if (i < np) {
+        const float gf = (float)g_i;
         if (st.grad) st.grad[(size_t)b * TRX_PSTRIDE + i] = gf;
-        float p = param[i];
         if (oc.kind == TRX_OPT_ADAM) {
-            float *mm = st.adam_m + (size_t)b * TRX_PSTRIDE, *vv = st.adam_v + (size_t)b * TRX_PSTRIDE;
-            const float mi = mm[i] + (gf - mm[i]) * (1.0f - oc.beta1);
-            const float vi = oc.beta2 * vv[i] + (1.0f - oc.beta2) * gf * gf;
-            mm[i] = mi; vv[i] = vi;
+            const float mi = m_old + (gf - m_old) * (1.0f - oc.beta1);
+            const float vi = oc.beta2 * v_old + (1.0f - oc.beta2) * gf * gf;
+            st.adam_m[(size_t)b * TRX_PSTRIDE + i] = mi;
+            st.adam_v[(size_t)b * TRX_PSTRIDE + i] = vi;
             const double bc1 = 1.0 - pow((double)oc.beta1, (double)(t + 1));
             const double bc2 = 1.0 - pow((double)oc.beta2, (double)(t + 1));
             const float denom = (float)(sqrt((double)vi) / sqrt(bc2)) + oc.eps;
-            p = p - (float)((double)oc.lr / bc1) * (mi / denom);
+            p_new = p_old - (float)((double)oc.lr / bc1) * (mi / denom);
         } else {
-            p = p - oc.lr * gf;
+            p_new = p_old - oc.lr * gf;
         }
-        param[i] = p;
+        param[i] = p_new;
     }
-    if (st.mode == TRX_PARAM_RIGID) {
+    if (rigid) {
+        if (i < NPOSE) sh_pose[i] = p_new;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        float pose_new[NPOSE];
+#pragma unroll
+        for (int k = 0; k < NPOSE; k++) pose_new[k] = sh_pose[k];
         double thd[NT];
-        theta_from_pose<ND>(param, thd);
-        for (int i = 0; i < NT; i++) theta[i] = (float)thd[i];
-    } else {
-        for (int i = 0; i < NT; i++) theta[i] = param[i];
+        theta_from_pose<ND>(pose_new, thd);
+        double th_i = 0.0;
+#pragma unroll
+        for (int k = 0; k < NT; k++) th_i = (k == i) ? thd[k] : th_i;
+        if (i < NT) theta[i] = (float)th_i;
+    } else if (i < NT) {
+        theta[i] = p_new;
     }
-    st.step[b] = t + 1;
 }
 
 __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_loss_finalize_kernel(const float *__restrict__ partials, int nblk,
