@@ -207,32 +207,6 @@ static TileGeom tile_geom(const trx_volumes &v)
     return t;
 }
 
-// one voxel's contribution to the running sums (x and z fixed per thread inside a tile)
-template <int MODE>
-__device__ __forceinline__ void f1_accumulate(const Samp3 &sm, float yv, float yn, float (&m)[5], float (&At)[3][3],
-                                              float (&Byt)[3][3])
-{
-    const float w = sm.v;
-    m[0] += yv; m[1] += w;
-    m[2] = fmaf(yv, yv, m[2]); m[3] = fmaf(w, w, m[3]); m[4] = fmaf(yv, w, m[4]);
-    if constexpr (MODE == 0) {
-        const float gq[3] = {sm.dx, sm.dy, sm.dz};
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float u = yn * gq[c];
-            At[0][c] += gq[c];                    Byt[0][c] += u;
-            At[1][c] = fmaf(yv, gq[c], At[1][c]); Byt[1][c] = fmaf(yv, u, Byt[1][c]);
-            At[2][c] = fmaf(w, gq[c], At[2][c]);  Byt[2][c] = fmaf(w, u, Byt[2][c]);
-        }
-    }
-}
-
-#ifndef TRX_DBG_SKIP
-#define TRX_DBG_SKIP 0   // development ablation (tools/kbench.hip): 1 = no gather/compute, 2 = no box staging, 3 = no target loads
-#endif
-#ifndef TRX_TILE_MIN_WAVES
-#define TRX_TILE_MIN_WAVES 4   // waves per SIMD the register allocator must allow (16 waves per CU)
-#endif
 // packed running sums of the tile kernel: AB[q][c] = (sum q*g_c, sum q*g_c*yn), M01 = (Sy, Sw), M23 = (Syy, Sww)
 struct F1Acc {
     f2 AB[3][3], M01, M23;
