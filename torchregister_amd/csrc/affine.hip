@@ -207,6 +207,12 @@ static TileGeom tile_geom(const trx_volumes &v)
     return t;
 }
 
+#ifndef TRX_DBG_SKIP
+#define TRX_DBG_SKIP 0   // development ablation (tools/kbench.hip): 1 = no gather/compute, 2 = no box staging, 3 = no target loads
+#endif
+#ifndef TRX_TILE_MIN_WAVES
+#define TRX_TILE_MIN_WAVES 4   // waves per SIMD the register allocator must allow (16 waves per CU)
+#endif
 // packed running sums of the tile kernel: AB[q][c] = (sum q*g_c, sum q*g_c*yn), M01 = (Sy, Sw), M23 = (Syy, Sww)
 struct F1Acc {
     f2 AB[3][3], M01, M23;
