@@ -31,6 +31,11 @@ def _worker(rank, world, port, total_pairs, q):
     losses = torch.full((hi - lo, 5), float(rank))
     t = sharding.max_over_ranks(1.0 + rank)
     th_all, l_all = sharding.gather_results(theta, losses)
+    # slab mode (config 5): the only per-iteration exchange is the sum of 8 fp64 moments
+    z0, z1 = sharding.slab_range(rank, world, 37)
+    mom = torch.full((1, 8), float(z1 - z0), dtype=torch.float64)
+    dist.all_reduce(mom, op=dist.ReduceOp.SUM)
+    assert mom.tolist() == [[37.0] * 8], mom
     q.put((rank, lo, hi, t, th_all[:, 0, 0].tolist(), l_all[:, 0].tolist(), sharding.weak_pair_ids(rank, 8)))
     dist.barrier()
     dist.destroy_process_group()

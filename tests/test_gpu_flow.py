@@ -150,3 +150,34 @@ def test_flow_full_size_properties(eng):
         outs.append((s.losses.clone(), s.flow.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][0][0, 2].item() < outs[0][0][0, 0].item()
+
+
+@pytest.mark.parametrize("optimizer,lr", [("sgd", 2.0), ("adam", 0.05)])
+def test_slab_partition_equals_whole_volume(eng, optimizer, lr):
+    """Z-slab mode (config 5) emulated on one GPU: three slabs of unequal depth, moments summed by hand (what the
+    all-reduce does), must reproduce the un-partitioned FlowSolver: loss curve to 1e-5 rel (fp64 sums in a
+    different order), flow to 1e-5 abs."""
+    shape = (36, 28, 40)
+    tgt = ph.blobs(shape, 1021).cuda()
+    mov = ph.blobs(shape, 1022).cuda()
+    iters = 6
+    whole = eng.FlowSolver(mov, tgt, loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr, capacity=iters)
+    whole.run(iters)
+    bounds = [0, 10, 25, 36]
+    slabs = [eng.SlabFlowSolver(mov, tgt[:, :, a:b].contiguous(), a, loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr,
+                                capacity=iters) for a, b in zip(bounds[:-1], bounds[1:])]
+    for _ in range(iters):
+        total = sum(s.local_moments().clone() for s in slabs)
+        for s in slabs:
+            s.apply(total)
+    torch.cuda.synchronize()
+    for s in slabs:
+        assert torch.allclose(s.losses, whole.losses, rtol=1e-5, atol=1e-6)       # every rank records the whole-volume loss
+    flow = torch.cat([s.flow for s in slabs], dim=2)
+    assert torch.max(torch.abs(flow - whole.flow)).item() <= 1e-5 * max(1.0, whole.flow.abs().max().item())
+    # single-rank run() path (no process group): identical to the manual loop of one full-depth slab
+    one = eng.SlabFlowSolver(mov, tgt, 0, loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr, capacity=iters)
+    one.run(iters)
+    torch.cuda.synchronize()
+    assert torch.allclose(one.losses, whole.losses, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(one.flow, whole.flow, atol=1e-6)

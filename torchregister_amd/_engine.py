@@ -327,3 +327,83 @@ def flow_loss_grad(moving, target, flow, loss, need_grad=True):
                                     ws_bytes, _lib.current_stream(batch.device))
     _lib.check(rc, "trx_flow_loss_grad")
     return terms, dfl
+
+
+class SlabFlowSolver:
+    """One rank's Z-slab of a single-volume direct-flow registration (BASELINE config 5).
+
+    moving_full: [1,1,D,H,W] the WHOLE moving volume (replicated on every rank; it is constant).
+    target_slab: [1,1,Ds,H,W] planes [z_offset, z_offset+Ds) of the target.
+    The flow / Adam state of the slab live here.  Each iteration: pass A on the slab -> 8 fp64 sums ->
+    all-reduce over `group` (RCCL via torch.distributed when initialised; nothing else is exchanged) ->
+    pass B on the slab with the whole-volume sums.  The loss curve holds the WHOLE-volume loss on every rank."""
+
+    def __init__(self, moving_full, target_slab, z_offset, loss=None, optimizer="sgd", lr=1e-3, capacity=1000, betas=(0.9, 0.999),
+                 eps=1e-8, group=None):
+        self.lib = _lib.load()
+        _require_gpu(moving_full, "moving_full")
+        _require_gpu(target_slab, "target_slab")
+        if moving_full.dim() != 5 or target_slab.dim() != 5 or moving_full.shape[:2] != (1, 1) or target_slab.shape[:2] != (1, 1):
+            raise ValueError("slab mode takes one single-channel 3-D volume: moving [1,1,D,H,W], target slab [1,1,Ds,H,W]")
+        if moving_full.shape[3:] != target_slab.shape[3:]:
+            raise ValueError("moving and target slab differ in (H, W)")
+        self.D_full, self.z_offset = int(moving_full.shape[2]), int(z_offset)
+        self.Ds = int(target_slab.shape[2])
+        if self.z_offset < 0 or self.z_offset + self.Ds > self.D_full:
+            raise ValueError("slab does not lie inside the moving volume")
+        self.moving, self.target = moving_full.contiguous(), target_slab.contiguous()
+        dev = self.moving.device
+        self.device, self.group = dev, group
+        H, W = int(self.moving.shape[3]), int(self.moving.shape[4])
+        self.loss = loss or LossSpec(w_mse=1.0)
+        self.loss_c = self.loss.c()
+        self.opt = opt_cfg(optimizer, lr, betas, eps)
+        shape = (1, 3, self.Ds, H, W)
+        self.flow = torch.zeros(shape, device=dev)
+        adam = self.opt.kind == _lib.OPT_ADAM
+        self.adam_m = torch.zeros(shape, device=dev) if adam else None
+        self.adam_v = torch.zeros(shape, device=dev) if adam else None
+        self.capacity = int(capacity)
+        self.losses = torch.full((1, self.capacity), float("nan"), device=dev)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.moments = torch.zeros(1, 8, dtype=torch.float64, device=dev)
+        v = _lib.Volumes()
+        v.moving, v.target = self.moving.data_ptr(), self.target.data_ptr()
+        v.moving_stride, v.target_stride = self.D_full * H * W, self.Ds * H * W
+        v.ndim, v.B, v.D, v.H, v.W = 3, 1, self.Ds, H, W
+        self.vol = v
+        self.ws_bytes = self.lib.trx_flow_workspace_bytes(ctypes.byref(v))
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        st = _lib.FlowState()
+        st.flow = self.flow.data_ptr()
+        st.adam_m = self.adam_m.data_ptr() if adam else None
+        st.adam_v = self.adam_v.data_ptr() if adam else None
+        st.losses, st.losses_capacity, st.step = self.losses.data_ptr(), self.capacity, self.step_t.data_ptr()
+        st.smooth_weight = 0.0
+        self.state = st
+
+    def local_moments(self):
+        """Pass A: this slab's raw sums into self.moments (device, fp64 [1,8])."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.trx_flow_slab_moments(ctypes.byref(self.vol), self.z_offset, self.D_full, _lib.ptr(self.flow), _lib.ptr(self.moments),
+                                                _lib.ptr(self.workspace), self.ws_bytes, _lib.current_stream(self.device))
+        _lib.check(rc, "trx_flow_slab_moments")
+        return self.moments
+
+    def apply(self, global_moments):
+        """Pass B with the whole-volume sums ([1,8] fp64 on this device)."""
+        gm = global_moments.contiguous()
+        with torch.cuda.device(self.device):
+            rc = self.lib.trx_flow_slab_update(ctypes.byref(self.vol), self.z_offset, self.D_full, ctypes.byref(self.loss_c), ctypes.byref(self.opt),
+                                               ctypes.byref(self.state), _lib.ptr(gm), _lib.ptr(self.workspace), self.ws_bytes,
+                                               _lib.current_stream(self.device))
+        _lib.check(rc, "trx_flow_slab_update")
+
+    def run(self, iters):
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        for _ in range(int(iters)):
+            m = self.local_moments()
+            if multi:
+                dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.group)   # 64 bytes per iteration, the only exchange
+            self.apply(m)

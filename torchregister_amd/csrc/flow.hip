@@ -18,6 +18,13 @@ struct FlowCoef {   // per pair, written by flow_coef_kernel, read by pass B (wa
     float step_size, inv_sqrt_bc2, sm[3];  // Adam scalars; smoothness gradient scale per dim
 };
 
+// Z-slab partition of ONE volume (BASELINE config 5): target / flow / optimiser state of a rank hold planes
+// [zoff, zoff + D) of a Dm-deep volume; `moving` is the whole volume (replicated: it is constant, so no halo
+// of it is ever exchanged).  {0, D} = no partition.
+struct Slab {
+    int zoff, Dm;
+};
+
 __device__ __forceinline__ void decode(size_t i, int H, int W, int &z, int &y, int &x)
 {
     x = (int)(i % W);
@@ -32,6 +39,7 @@ __device__ __forceinline__ float flow_sample(const float *__restrict__ mov, cons
                                              size_t i, int D, int H, int W, int z, int y, int x, float *d)
 {
     if constexpr (ND == 3) {
+        // D is the depth of the volume SAMPLED (the full moving volume), z the absolute plane index
         const float iz = (float)z + fl[i], iy = (float)y + fl[nvox + i], ix = (float)x + fl[2 * nvox + i];
         Samp3 s = sample3(mov, D, H, W, ix, iy, iz);
         d[0] = s.dz; d[1] = s.dy; d[2] = s.dx;
@@ -48,7 +56,7 @@ constexpr int kFlowNP = 8;  // 5 moments + up to 3 smoothness sums
 
 template <int ND, bool SMOOTH>
 __global__ __launch_bounds__(TRX_BLOCK) void flow_moments_kernel(trx_volumes vol, const float *__restrict__ flow,
-                                                                 float *__restrict__ partials)
+                                                                 float *__restrict__ partials, Slab slab)
 {
     const int b = blockIdx.y;
     const int D = vol.D, H = vol.H, W = vol.W;
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_moments_kernel(trx_volumes vol
         int z, y, x;
         decode(i, H, W, z, y, x);
         float d[3];
-        const float w = flow_sample<ND>(mov, fl, nvox, i, D, H, W, z, y, x, d);
+        const float w = flow_sample<ND>(mov, fl, nvox, i, slab.Dm, H, W, z + slab.zoff, y, x, d);
         const float yv = tgt[i];
         vals[0] += yv; vals[1] += w;
         vals[2] = fmaf(yv, yv, vals[2]); vals[3] = fmaf(w, w, vals[3]); vals[4] = fmaf(yv, w, vals[4]);
@@ -86,7 +94,8 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_moments_kernel(trx_volumes vol
 __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict__ partials, int nblk, int ndim, int D, int H,
                                                          int W, trx_loss_cfg lc, trx_opt_cfg oc, float smooth_weight,
                                                          float *__restrict__ losses, int losses_capacity, int *__restrict__ step,
-                                                         float *__restrict__ terms, FlowCoef *__restrict__ coef)
+                                                         float *__restrict__ terms, FlowCoef *__restrict__ coef,
+                                                         double *__restrict__ mom_out, const double *__restrict__ mom_in, int D_full)
 {
     __shared__ double acc[16][8];
     const int b = blockIdx.x, tid = threadIdx.x, k = tid & 7, grp = tid >> 3;  // 128 groups of 8
@@ -103,6 +112,13 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
         for (int wv = 0; wv < 16; wv++) t += acc[wv][j];
         S[j] = t;
     }
+    if (mom_out) {               // slab mode, pass A: publish this rank's raw sums (the caller all-reduces them)
+        for (int j = 0; j < 8; j++) mom_out[b * 8 + j] = S[j];
+        return;
+    }
+    if (mom_in)                  // slab mode, pass B: sums of the WHOLE volume
+        for (int j = 0; j < 8; j++) S[j] = mom_in[b * 8 + j];
+    D = D_full;
     const double n = (double)D * H * W;
     const double Sy = S[0], Sw = S[1], Syy = S[2], Sww = S[3], Syw = S[4];
     const double my = Sy / n, mw = Sw / n;
@@ -153,7 +169,7 @@ template <int ND, int MODE, bool SMOOTH>
 __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol, const float *flow,
                                                                 float *flow_out, float *__restrict__ adam_m,
                                                                 float *__restrict__ adam_v, const FlowCoef *__restrict__ coef,
-                                                                trx_opt_cfg oc)
+                                                                trx_opt_cfg oc, Slab slab)
 {
     const int b = blockIdx.y;
     const int D = vol.D, H = vol.H, W = vol.W;
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
         int z, y, x;
         decode(i, H, W, z, y, x);
         float d[3];
-        const float w = flow_sample<ND>(mov, fl, nvox, i, D, H, W, z, y, x, d);
+        const float w = flow_sample<ND>(mov, fl, nvox, i, slab.Dm, H, W, z + slab.zoff, y, x, d);
         const float yv = tgt[i];
         const float go = fmaf(c.k1, yv - c.my, fmaf(c.k2, w - c.mw, c.q * (w - yv)));
 #pragma unroll
@@ -286,15 +302,16 @@ static FlowCoef *coef_ptr(const trx_volumes *vol, void *workspace)
     return (FlowCoef *)((char *)workspace + off);
 }
 
-static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth, float *partials, hipStream_t s)
+static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth, float *partials, hipStream_t s, Slab slab = Slab{0, -1})
 {
+    if (slab.Dm < 0) slab.Dm = vol->D;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
     if (vol->ndim == 3) {
-        if (smooth) hipLaunchKernelGGL((flow_moments_kernel<3, true>), grid, block, 0, s, *vol, flow, partials);
-        else hipLaunchKernelGGL((flow_moments_kernel<3, false>), grid, block, 0, s, *vol, flow, partials);
+        if (smooth) hipLaunchKernelGGL((flow_moments_kernel<3, true>), grid, block, 0, s, *vol, flow, partials, slab);
+        else hipLaunchKernelGGL((flow_moments_kernel<3, false>), grid, block, 0, s, *vol, flow, partials, slab);
     } else {
-        if (smooth) hipLaunchKernelGGL((flow_moments_kernel<2, true>), grid, block, 0, s, *vol, flow, partials);
-        else hipLaunchKernelGGL((flow_moments_kernel<2, false>), grid, block, 0, s, *vol, flow, partials);
+        if (smooth) hipLaunchKernelGGL((flow_moments_kernel<2, true>), grid, block, 0, s, *vol, flow, partials, slab);
+        else hipLaunchKernelGGL((flow_moments_kernel<2, false>), grid, block, 0, s, *vol, flow, partials, slab);
     }
     TRX_CHECK_LAUNCH();
     return TRX_OK;
@@ -302,15 +319,16 @@ static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth
 
 template <int MODE>
 static int launch_update(const trx_volumes *vol, const float *flow, float *flow_out, float *m, float *v, const FlowCoef *coef,
-                         const trx_opt_cfg &oc, bool smooth, hipStream_t s)
+                         const trx_opt_cfg &oc, bool smooth, hipStream_t s, Slab slab = Slab{0, -1})
 {
+    if (slab.Dm < 0) slab.Dm = vol->D;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
     if (vol->ndim == 3) {
-        if (smooth) hipLaunchKernelGGL((flow_update_kernel<3, MODE, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc);
-        else hipLaunchKernelGGL((flow_update_kernel<3, MODE, false>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc);
+        if (smooth) hipLaunchKernelGGL((flow_update_kernel<3, MODE, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab);
+        else hipLaunchKernelGGL((flow_update_kernel<3, MODE, false>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab);
     } else {
-        if (smooth) hipLaunchKernelGGL((flow_update_kernel<2, MODE, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc);
-        else hipLaunchKernelGGL((flow_update_kernel<2, MODE, false>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc);
+        if (smooth) hipLaunchKernelGGL((flow_update_kernel<2, MODE, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab);
+        else hipLaunchKernelGGL((flow_update_kernel<2, MODE, false>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab);
     }
     TRX_CHECK_LAUNCH();
     return TRX_OK;
@@ -325,7 +343,7 @@ static int flow_step_impl(const trx_volumes *vol, const trx_loss_cfg *loss, cons
     int rc = launch_moments(vol, cur, smooth, partials, s);
     if (rc) return rc;
     hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, partials, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
-                       vol->W, *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef);
+                       vol->W, *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr, (const double *)nullptr, vol->D);
     TRX_CHECK_LAUNCH();
     return launch_update<0>(vol, cur, nxt, st->adam_m, st->adam_v, coef, *opt, smooth, s);
 }
@@ -384,7 +402,7 @@ extern "C" int trx_flow_loss_grad(const trx_volumes *vol, const trx_loss_cfg *lo
     if (rc) return rc;
     trx_opt_cfg oc = {TRX_OPT_SGD, 0.f, 0.f, 0.f, 0.f};
     hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, partials, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
-                       vol->W, *loss, oc, 0.f, (float *)nullptr, 0, (int *)nullptr, terms, coef);
+                       vol->W, *loss, oc, 0.f, (float *)nullptr, 0, (int *)nullptr, terms, coef, (double *)nullptr, (const double *)nullptr, vol->D);
     TRX_CHECK_LAUNCH();
     if (!dflow) return TRX_OK;
     return launch_update<1>(vol, flow, dflow, nullptr, nullptr, coef, oc, false, s);
@@ -415,4 +433,57 @@ extern "C" int trx_flow_warp_backward(const trx_volumes *vol, const float *flow,
     else hipLaunchKernelGGL((flow_warp_bwd_kernel<2>), grid, block, 0, s, *vol, flow, channels, grad_out, dflow);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Z-slab mode (one volume partitioned over ranks, BASELINE config 5 / SURVEY 8e): the global NCC moments are
+// the only per-iteration exchange: pass A per rank -> 8 raw fp64 sums -> all-reduce by the caller (RCCL, 64
+// bytes: latency-bound) -> pass B per rank with the sums of the whole volume.
+// ---------------------------------------------------------------------------------------------------
+static int check_slab(const trx_volumes *vol, int z_offset, int D_full)
+{
+    int rc = check_vol_flow(vol, true);
+    if (rc) return rc;
+    if (vol->ndim != 3) return TRX_ERR_NDIM;
+    if (z_offset < 0 || D_full < 1 || z_offset + vol->D > D_full) return TRX_ERR_ARG;
+    return TRX_OK;
+}
+
+extern "C" int trx_flow_slab_moments(const trx_volumes *vol, int z_offset, int D_full, const float *flow, double *moments,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_slab(vol, z_offset, D_full);
+    if (rc) return rc;
+    if (!flow || !moments || !workspace) return TRX_ERR_ARG;
+    if (workspace_bytes < trx_flow_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float *partials = (float *)workspace;
+    rc = launch_moments(vol, flow, false, partials, s, Slab{z_offset, D_full});
+    if (rc) return rc;
+    trx_loss_cfg lc = {0.f, 0.f, 0.f, 0.f, 0.f};
+    trx_opt_cfg oc = {TRX_OPT_SGD, 0.f, 0.f, 0.f, 0.f};
+    hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, partials, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
+                       vol->W, lc, oc, 0.f, (float *)nullptr, 0, (int *)nullptr, (float *)nullptr, (FlowCoef *)nullptr, moments,
+                       (const double *)nullptr, D_full);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+extern "C" int trx_flow_slab_update(const trx_volumes *vol, int z_offset, int D_full, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
+                                    const trx_flow_state *st, const double *global_moments, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    int rc = check_slab(vol, z_offset, D_full);
+    if (rc) return rc;
+    if (!global_moments) return TRX_ERR_ARG;
+    rc = check_flow_args(vol, loss, opt, st, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (st->smooth_weight != 0.f) return TRX_ERR_ARG;   // the regulariser needs a flow halo exchange: not built yet
+    hipStream_t s = (hipStream_t)stream;
+    FlowCoef *coef = coef_ptr(vol, workspace);
+    hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, (const float *)workspace, 0, vol->ndim, vol->D, vol->H, vol->W,
+                       *loss, *opt, 0.f, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr,
+                       global_moments, D_full);
+    TRX_CHECK_LAUNCH();
+    return launch_update<0>(vol, st->flow, st->flow, st->adam_m, st->adam_v, coef, *opt, false, s, Slab{z_offset, D_full});
 }

@@ -52,3 +52,8 @@ def gather_results(theta, losses, device=None):
         dist.all_gather(buf, pad(t))
         outs.append(torch.cat([b[:c] for b, c in zip(buf, counts)]))
     return outs[0], outs[1]
+
+
+def slab_range(rank, world, depth):
+    """Z-slab [z0, z1) of a D-deep volume owned by `rank` (BASELINE config 5: 512 planes / 8 ranks = 64 each)."""
+    return pair_range(rank, world, depth)
