@@ -169,9 +169,10 @@ class _FlowWarpFn(torch.autograd.Function):
 class SpatialTransformer(nn.Module):
     """N-D spatial transformer: sample src at voxel + flow, zeros outside (ref:utils.py:333-365).
 
-    Same constructor/forward signature as the reference; the identity-grid buffer is kept for
-    state_dict compatibility but the HIP kernel adds the voxel index itself.  Gradient wrt `flow`
-    is provided (HIP backward); gradient wrt `src` is not (the reference never needs it)."""
+    Same constructor/forward signature as the reference.  The reference's identity-grid buffer (nd x volume
+    floats, 200 MB at 256^3, built on the CPU and copied over) is NOT created: the HIP kernel adds the voxel
+    index itself.  Gradient wrt `flow` is provided (HIP backward); gradient wrt `src` is not (the reference
+    never needs it)."""
 
     def __init__(self, size, mode="bilinear"):
         super().__init__()
@@ -179,9 +180,6 @@ class SpatialTransformer(nn.Module):
             raise NotImplementedError("only mode='bilinear' (what Register uses) is implemented on the HIP path")
         self.mode = mode
         self.size = tuple(int(s) for s in size)
-        vectors = [torch.arange(0, s) for s in self.size]
-        grid = torch.stack(torch.meshgrid(*vectors, indexing="ij")).unsqueeze(0).float()
-        self.register_buffer("grid", grid, persistent=True)
 
     def forward(self, src, flow):
         if tuple(flow.shape[2:]) != tuple(src.shape[2:]):
