@@ -32,7 +32,7 @@ extern "C" {
 
 typedef enum {
     TRX_OK = 0,
-    TRX_ERR_ARG = -1,       /* null pointer / non-positive size / bad enum */
+    TRX_ERR_ARG = -1,       /* null pointer / non-positive size / bad enum / B > 65535 / a volume of >= 2^31 voxels */
     TRX_ERR_NDIM = -2,      /* ndim not 2 or 3 (or D != 1 with ndim 2) */
     TRX_ERR_WORKSPACE = -3, /* workspace too small: see trx_*_workspace_bytes */
     TRX_ERR_HIP = -4,       /* a HIP launch failed (hipGetLastError) */

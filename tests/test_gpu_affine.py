@@ -218,3 +218,46 @@ def test_full_size_properties(eng):
     a, b = y - y.mean(), wv - wv.mean()
     ncc = 100.0 * (1 - (a * b).sum() / ((a * a).sum() * (b * b).sum() + 1e-10).sqrt())
     assert abs(s2.losses[0, 0].item() - ncc.item()) <= 2e-4 * max(1.0, abs(ncc.item()))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 4), (2, 3, 4), (1, 16, 32), (3, 1, 8), (4, 4), (1, 7), (2, 2, 2)])
+def test_tiny_and_degenerate_shapes(eng, shape):
+    """Smallest volumes (single voxel rows/planes, sizes below every tile dimension) against the C oracle."""
+    nd = len(shape)
+    mov, tgt = _mt(shape)
+    th64 = np.eye(nd, nd + 1) + 0.01 * np.sin(1.7 * np.arange(nd * (nd + 1))).reshape(nd, nd + 1)
+    th = torch.tensor(th64, dtype=torch.float32)[None]
+    w = eng.affine_warp(th.cuda(), mov.cuda()).cpu().numpy()[0, 0]
+    ref = oracle.c_affine_warp(mov[0, 0].double().numpy(), th[0].double().numpy(), oracle.base_tables(shape, np.float64))
+    assert np.max(np.abs(w - ref)) <= 2e-6
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(w_mse=1.0, w_ssd=0.1), lr=0.0, init=th, capacity=1)
+    s.run(1)
+    torch.cuda.synchronize()
+    total, _, dth, _ = oracle.c_affine_loss_grad(mov[0, 0].double().numpy(), tgt[0, 0].double().numpy(), th[0].double().numpy(),
+                                                 oracle.wts(w_mse=1.0, w_ssd=0.1), oracle.base_tables(shape, np.float64))
+    assert abs(s.losses[0, 0].item() - total) <= 2e-5 * max(1.0, abs(total))
+    g = s.grad[0, : nd * (nd + 1)].cpu().numpy().reshape(nd, nd + 1)
+    assert np.max(np.abs(g - dth)) <= 2e-4 * max(1e-6, np.max(np.abs(dth)))
+
+
+def test_graph_capture_and_side_stream(eng):
+    """The C ABI neither allocates nor synchronises: a run can be captured into a HIP graph and replayed, and it
+    follows torch's current stream."""
+    shape = (32, 32, 32)
+    mov, tgt = ph.blobs(shape, 41).cuda(), ph.blobs(shape, 42).cuda()
+    ref = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=1e-4, capacity=12)
+    ref.run(12)
+    torch.cuda.synchronize()
+    s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=1e-4, capacity=12)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        s.run(4)                       # eager, on a side stream
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            s.run(4)                   # captured: 8 kernel nodes, nothing executes yet
+        g.replay()
+        g.replay()
+    side.synchronize()
+    assert torch.equal(s.step.cpu(), torch.tensor([12], dtype=torch.int32))
+    assert torch.equal(s.losses, ref.losses) and torch.equal(s.theta, ref.theta)

@@ -809,6 +809,7 @@ static int check_vol(const trx_volumes *v, bool need_target)
     if (v->B < 1 || v->D < 1 || v->H < 1 || v->W < 1) return TRX_ERR_ARG;
     if (v->ndim == 2 && v->D != 1) return TRX_ERR_NDIM;
     if (v->B > 65535) return TRX_ERR_ARG;
+    if ((size_t)v->D * v->H * v->W >= ((size_t)1 << 31)) return TRX_ERR_ARG;   // 32-bit voxel indices inside one volume
     return TRX_OK;
 }
 
