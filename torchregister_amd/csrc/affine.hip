@@ -210,6 +210,9 @@ static TileGeom tile_geom(const trx_volumes &v)
 #ifndef TRX_DBG_SKIP
 #define TRX_DBG_SKIP 0   // development ablation (tools/kbench.hip): 1 = no gather/compute, 2 = no box staging, 3 = no target loads
 #endif
+#ifndef TRX_STAGE_PRIO
+#define TRX_STAGE_PRIO 3
+#endif
 #ifndef TRX_TILE_MIN_WAVES
 #define TRX_TILE_MIN_WAVES 4   // waves per SIMD the register allocator must allow (16 waves per CU)
 #endif
@@ -423,6 +426,9 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
 
         if (fits) {
             // ---- (1) target column into registers, box straight into LDS (LDS-DMA, no staging VGPRs) ----
+            // staging waves outrank the co-resident block's gather waves: their loads should enter the memory
+            // system as early as possible, the VALU work they displace is short
+            __builtin_amdgcn_s_setprio(TRX_STAGE_PRIO);
             float tv[kRows];
 #pragma unroll
             for (int j = 0; j < kRows; j++)
@@ -457,6 +463,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                         __builtin_amdgcn_global_load_lds(mov + idx, box + (k * kTileWaves + wave) * 256, 16, 0, 0);
                     }
             }
+            __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (oob) {   // zero padding: cells outside the volume (boundary tiles only)
 #pragma unroll
