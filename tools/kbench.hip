@@ -108,6 +108,15 @@ int main(int argc, char **argv)
     for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = id[i];
     CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
     rep("accum MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_accum_kernel<3, 0>), grid, block, 0, 0, vol, theta, g, 1, (size_t)0, partials); }, 20));
+    {   // large rotation (0.5 rad about z): no tile fits the LDS box -> in-kernel global-gather fallback
+        const float rt[12] = {0.8776f, -0.4794f, 0.f, 0.02f, 0.4794f, 0.8776f, 0.f, -0.01f, 0.f, 0.f, 1.f, 0.f};
+        for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = rt[i];
+        CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
+        rep("tile MODE0 rot 0.5 (fallback)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 10));
+        rep("accum MODE0 rot 0.5 (gather kernel)", time_it([&] { hipLaunchKernelGGL((trx::affine_accum_kernel<3, 0>), grid, block, 0, 0, vol, theta, g, 1, (size_t)0, partials); }, 10));
+        for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = id[i];
+        CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
+    }
     rep("tile MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
     return 0;
 }
