@@ -395,6 +395,7 @@ def main():
     traj_driver(tj, "affine2d_mse", "affine", (32, 32), 1e-1, 60, 3)
     traj_default_crit(tj, "affine2d_w010", (32, 32), [0.0, 1.0, 0.0], 1e-4, 40, 4)
     traj_default_crit(tj, "affine2d_w550", (32, 32), [0.5, 0.5, 0.0], 1e-4, 40, 5)
+    traj_default_crit(tj, "affine2d_default", (32, 32), [0.33, 0.33, 0.33], 1e-5, 12, 14)   # NMI active (Parzen KDE)
     composed_affine(tj, "c_affine3d_ncc", (24, 24, 24), "ncc", 3e-5, 40, 6)
     composed_affine(tj, "c_affine2d_ncc", (48, 40), "ncc", 1e-4, 40, 7)
     composed_affine(tj, "c_rigid3d_ncc", (20, 24, 28), "ncc", 2e-4, 40, 8, rigid=True)

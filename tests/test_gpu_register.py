@@ -204,3 +204,20 @@ def test_unet_seeded_weights_and_flow_match_reference_on_cpu_shapes(tr):
     assert sum(p.numel() for p in m3.parameters()) == 89189
     names = [n for n, _ in m2.named_parameters()]
     assert names[0] == "layer1.0.weight" and "skip1.input_filter.weight" in names and names[-1] == "out.bias"
+
+
+def test_register_fully_default_criterion_with_nmi(tr, trajectories):
+    """Register('affine', criterion=None, weight=[.33,.33,.33]): MSE + NCC + the Parzen-window NMI (torch ops on the
+    GPU) drive the HIP warp through autograd (generic path).  Tolerance 2e-3 rel on the curve: the KDE sums 10^4 x 256
+    exponentials per patch in a different order on the GPU."""
+    g = trajectories
+    name = "affine2d_default"
+    lr, iters = float(g[f"{name}/meta"][0]), int(g[f"{name}/meta"][1])
+    weight = [float(v) for v in g[f"{name}/meta"][4:7]]
+    mov, tgt = _mov_tgt(g, name)
+    reg = tr.Register("affine", device="cuda", criterion=None, weight=weight)
+    reg.optim(mov, tgt, lr=lr, max_epochs=iters, per=0.125)
+    gl = g[f"{name}/losses"]
+    mine = reg.losses.cpu().numpy().ravel()
+    assert np.max(np.abs(mine - gl)) <= 2e-3 * np.max(np.abs(gl)), (mine, gl)
+    assert np.max(np.abs(reg.theta.cpu().numpy() - g[f"{name}/best_theta"])) <= 2e-3
