@@ -159,14 +159,18 @@ int trx_flow_loss_grad(const trx_volumes *vol, const trx_loss_cfg *loss, const f
 /* Z-slab partition of ONE 3-D volume over ranks (BASELINE config 5): `vol` describes the rank's slab — target,
  * flow and optimiser state hold planes [z_offset, z_offset + vol->D) — while vol->moving is the WHOLE moving
  * volume [B][D_full][H][W] (replicated, constant: no halo of it is exchanged).  One iteration =
- * trx_flow_slab_moments (pass A: this rank's 8 raw fp64 sums {Sy,Sw,Syy,Sww,Syw,0,0,0} per pair) -> the caller
- * all-reduces `moments` over ranks (RCCL; 64 bytes) -> trx_flow_slab_update (loss of the whole volume into
- * losses[t], pass B on the slab).  Same span of the reference as trx_flow_step (ref:warpings.py:208-220). */
-int trx_flow_slab_moments(const trx_volumes *vol, int z_offset, int D_full, const float *flow, double *moments,
+ *   (if smooth_weight != 0) exchange one flow plane with each Z neighbour (xGMI P2P): halo_lo / halo_hi =
+ *        the neighbour's flow plane just below / above the slab, [ndim][H][W], NULL at the ends of the volume;
+ *   trx_flow_slab_moments: pass A -> this rank's 8 raw fp64 sums {Sy,Sw,Syy,Sww,Syw, smooth_z,smooth_y,smooth_x};
+ *   the caller all-reduces `moments` over ranks (RCCL; 64 bytes);
+ *   trx_flow_slab_update: loss of the whole volume into losses[t], pass B on the slab.  With the regulariser the
+ *        new flow is written to st->flow_tmp (it reads neighbours of the old flow): the caller swaps the two.
+ * Same span of the reference as trx_flow_step (ref:warpings.py:208-220). */
+int trx_flow_slab_moments(const trx_volumes *vol, int z_offset, int D_full, const float *flow, int smooth, const float *halo_hi, double *moments,
                           void *workspace, size_t workspace_bytes, void *stream);
 int trx_flow_slab_update(const trx_volumes *vol, int z_offset, int D_full, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
-                         const trx_flow_state *st, const double *global_moments, void *workspace, size_t workspace_bytes,
-                         void *stream);
+                         const trx_flow_state *st, const double *global_moments, const float *halo_lo, const float *halo_hi,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* Generic backward of the flow warp: dflow[B][ndim][...] = sum_c grad_out[B][c][...] * d warp/d flow. */
 int trx_flow_warp_backward(const trx_volumes *vol, const float *flow, int channels, const float *grad_out,

@@ -152,21 +152,29 @@ def test_flow_full_size_properties(eng):
     assert outs[0][0][0, 2].item() < outs[0][0][0, 0].item()
 
 
-@pytest.mark.parametrize("optimizer,lr", [("sgd", 2.0), ("adam", 0.05)])
-def test_slab_partition_equals_whole_volume(eng, optimizer, lr):
-    """Z-slab mode (config 5) emulated on one GPU: three slabs of unequal depth, moments summed by hand (what the
-    all-reduce does), must reproduce the un-partitioned FlowSolver: loss curve to 1e-5 rel (fp64 sums in a
-    different order), flow to 1e-5 abs."""
+@pytest.mark.parametrize("optimizer,lr,smooth", [("sgd", 2.0, 0.0), ("adam", 0.05, 0.0), ("sgd", 1.0, 4.0), ("adam", 0.05, 2.0)])
+def test_slab_partition_equals_whole_volume(eng, optimizer, lr, smooth):
+    """Z-slab mode (config 5) emulated on one GPU: three slabs of unequal depth; the moments are summed by hand (what the
+    all-reduce does) and, with the smoothness regulariser, the neighbours' boundary flow planes are copied by hand
+    (what the xGMI halo exchange does).  Must reproduce the un-partitioned FlowSolver: loss curve to 1e-5 rel
+    (fp64 sums in a different order), flow to 1e-5."""
     shape = (36, 28, 40)
     tgt = ph.blobs(shape, 1021).cuda()
     mov = ph.blobs(shape, 1022).cuda()
     iters = 6
-    whole = eng.FlowSolver(mov, tgt, loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr, capacity=iters)
+    kw = dict(loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr, capacity=iters, smooth_weight=smooth)
+    whole = eng.FlowSolver(mov, tgt, **kw)
     whole.run(iters)
     bounds = [0, 10, 25, 36]
-    slabs = [eng.SlabFlowSolver(mov, tgt[:, :, a:b].contiguous(), a, loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr,
-                                capacity=iters) for a, b in zip(bounds[:-1], bounds[1:])]
+    slabs = [eng.SlabFlowSolver(mov, tgt[:, :, a:b].contiguous(), a, **kw) for a, b in zip(bounds[:-1], bounds[1:])]
     for _ in range(iters):
+        if smooth:   # halo exchange between Z neighbours
+            planes = [s.boundary_planes() for s in slabs]
+            for r, s in enumerate(slabs):
+                if s.has_lo:
+                    s.halo_lo.copy_(planes[r - 1][1])
+                if s.has_hi:
+                    s.halo_hi.copy_(planes[r + 1][0])
         total = sum(s.local_moments().clone() for s in slabs)
         for s in slabs:
             s.apply(total)
@@ -174,9 +182,12 @@ def test_slab_partition_equals_whole_volume(eng, optimizer, lr):
     for s in slabs:
         assert torch.allclose(s.losses, whole.losses, rtol=1e-5, atol=1e-6)       # every rank records the whole-volume loss
     flow = torch.cat([s.flow for s in slabs], dim=2)
-    assert torch.max(torch.abs(flow - whole.flow)).item() <= 1e-5 * max(1.0, whole.flow.abs().max().item())
-    # single-rank run() path (no process group): identical to the manual loop of one full-depth slab
-    one = eng.SlabFlowSolver(mov, tgt, 0, loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr, capacity=iters)
+    # Adam divides by sqrt(v): where the gradient is ~1e-9 (smoothness term of a near-zero flow) a last-bit change of
+    # the coefficients (the global sums are added in a different order) moves the step by a fraction of lr
+    tol = 2e-3 if (optimizer == "adam" and smooth) else 1e-5
+    assert torch.max(torch.abs(flow - whole.flow)).item() <= tol * max(1.0, whole.flow.abs().max().item())
+    # single-rank run() path (no process group): one full-depth slab == the plain solver
+    one = eng.SlabFlowSolver(mov, tgt, 0, **kw)
     one.run(iters)
     torch.cuda.synchronize()
     assert torch.allclose(one.losses, whole.losses, rtol=1e-6, atol=1e-7)

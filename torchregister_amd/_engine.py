@@ -334,12 +334,13 @@ class SlabFlowSolver:
 
     moving_full: [1,1,D,H,W] the WHOLE moving volume (replicated on every rank; it is constant).
     target_slab: [1,1,Ds,H,W] planes [z_offset, z_offset+Ds) of the target.
-    The flow / Adam state of the slab live here.  Each iteration: pass A on the slab -> 8 fp64 sums ->
-    all-reduce over `group` (RCCL via torch.distributed when initialised; nothing else is exchanged) ->
-    pass B on the slab with the whole-volume sums.  The loss curve holds the WHOLE-volume loss on every rank."""
+    The flow / Adam state of the slab live here.  Each iteration: (with the smoothness regulariser) one flow
+    plane is exchanged with each Z neighbour (P2P over xGMI) -> pass A on the slab -> 8 fp64 sums -> all-reduce
+    over `group` (RCCL via torch.distributed when initialised) -> pass B on the slab with the whole-volume sums.
+    The loss curve holds the WHOLE-volume loss on every rank."""
 
     def __init__(self, moving_full, target_slab, z_offset, loss=None, optimizer="sgd", lr=1e-3, capacity=1000, betas=(0.9, 0.999),
-                 eps=1e-8, group=None):
+                 eps=1e-8, group=None, smooth_weight=0.0):
         self.lib = _lib.load()
         _require_gpu(moving_full, "moving_full")
         _require_gpu(target_slab, "target_slab")
@@ -358,8 +359,10 @@ class SlabFlowSolver:
         self.loss = loss or LossSpec(w_mse=1.0)
         self.loss_c = self.loss.c()
         self.opt = opt_cfg(optimizer, lr, betas, eps)
+        self.smooth = float(smooth_weight)
         shape = (1, 3, self.Ds, H, W)
         self.flow = torch.zeros(shape, device=dev)
+        self.flow_tmp = torch.empty(shape, device=dev) if self.smooth else None
         adam = self.opt.kind == _lib.OPT_ADAM
         self.adam_m = torch.zeros(shape, device=dev) if adam else None
         self.adam_v = torch.zeros(shape, device=dev) if adam else None
@@ -367,6 +370,10 @@ class SlabFlowSolver:
         self.losses = torch.full((1, self.capacity), float("nan"), device=dev)
         self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
         self.moments = torch.zeros(1, 8, dtype=torch.float64, device=dev)
+        # neighbour planes of the flow (only with the regulariser): None at the ends of the volume
+        self.has_lo, self.has_hi = self.z_offset > 0, self.z_offset + self.Ds < self.D_full
+        self.halo_lo = torch.zeros(3, H, W, device=dev) if (self.smooth and self.has_lo) else None
+        self.halo_hi = torch.zeros(3, H, W, device=dev) if (self.smooth and self.has_hi) else None
         v = _lib.Volumes()
         v.moving, v.target = self.moving.data_ptr(), self.target.data_ptr()
         v.moving_stride, v.target_stride = self.D_full * H * W, self.Ds * H * W
@@ -374,36 +381,66 @@ class SlabFlowSolver:
         self.vol = v
         self.ws_bytes = self.lib.trx_flow_workspace_bytes(ctypes.byref(v))
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self._adam = adam
+
+    def _state(self):
         st = _lib.FlowState()
         st.flow = self.flow.data_ptr()
-        st.adam_m = self.adam_m.data_ptr() if adam else None
-        st.adam_v = self.adam_v.data_ptr() if adam else None
+        st.flow_tmp = self.flow_tmp.data_ptr() if self.flow_tmp is not None else None
+        st.adam_m = self.adam_m.data_ptr() if self._adam else None
+        st.adam_v = self.adam_v.data_ptr() if self._adam else None
         st.losses, st.losses_capacity, st.step = self.losses.data_ptr(), self.capacity, self.step_t.data_ptr()
-        st.smooth_weight = 0.0
-        self.state = st
+        st.smooth_weight = self.smooth
+        return st
+
+    def boundary_planes(self):
+        """(lowest, highest) plane of this slab's flow, each [3,H,W] — what the Z neighbours need as halo."""
+        return self.flow[0, :, 0].contiguous(), self.flow[0, :, -1].contiguous()
+
+    def exchange_halos(self, rank=None, world=None):
+        """P2P exchange of one flow plane with each Z neighbour (rank r owns the slab below rank r+1)."""
+        import torch.distributed as dist
+        if not self.smooth or not (dist.is_available() and dist.is_initialized()):
+            return
+        rank = dist.get_rank(self.group) if rank is None else rank
+        lo, hi = self.boundary_planes()
+        ops = []
+        if self.has_lo:
+            ops += [dist.P2POp(dist.isend, lo, rank - 1, self.group), dist.P2POp(dist.irecv, self.halo_lo, rank - 1, self.group)]
+        if self.has_hi:
+            ops += [dist.P2POp(dist.isend, hi, rank + 1, self.group), dist.P2POp(dist.irecv, self.halo_hi, rank + 1, self.group)]
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
 
     def local_moments(self):
         """Pass A: this slab's raw sums into self.moments (device, fp64 [1,8])."""
         with torch.cuda.device(self.device):
-            rc = self.lib.trx_flow_slab_moments(ctypes.byref(self.vol), self.z_offset, self.D_full, _lib.ptr(self.flow), _lib.ptr(self.moments),
-                                                _lib.ptr(self.workspace), self.ws_bytes, _lib.current_stream(self.device))
+            rc = self.lib.trx_flow_slab_moments(ctypes.byref(self.vol), self.z_offset, self.D_full, _lib.ptr(self.flow), int(bool(self.smooth)),
+                                                _lib.ptr(self.halo_hi), _lib.ptr(self.moments), _lib.ptr(self.workspace), self.ws_bytes,
+                                                _lib.current_stream(self.device))
         _lib.check(rc, "trx_flow_slab_moments")
         return self.moments
 
     def apply(self, global_moments):
         """Pass B with the whole-volume sums ([1,8] fp64 on this device)."""
         gm = global_moments.contiguous()
+        st = self._state()
         with torch.cuda.device(self.device):
             rc = self.lib.trx_flow_slab_update(ctypes.byref(self.vol), self.z_offset, self.D_full, ctypes.byref(self.loss_c), ctypes.byref(self.opt),
-                                               ctypes.byref(self.state), _lib.ptr(gm), _lib.ptr(self.workspace), self.ws_bytes,
-                                               _lib.current_stream(self.device))
+                                               ctypes.byref(st), _lib.ptr(gm), _lib.ptr(self.halo_lo), _lib.ptr(self.halo_hi),
+                                               _lib.ptr(self.workspace), self.ws_bytes, _lib.current_stream(self.device))
         _lib.check(rc, "trx_flow_slab_update")
+        if self.smooth:
+            self.flow, self.flow_tmp = self.flow_tmp, self.flow   # the update was written to the other buffer
 
     def run(self, iters):
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         for _ in range(int(iters)):
+            if multi:
+                self.exchange_halos()
             m = self.local_moments()
             if multi:
-                dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.group)   # 64 bytes per iteration, the only exchange
+                dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.group)   # 64 bytes per iteration
             self.apply(m)

@@ -75,9 +75,9 @@ SIGNATURES = {
                                      ctypes.POINTER(FlowState), _P, ctypes.c_size_t, _P]),
     "trx_flow_run": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.POINTER(LossCfg), ctypes.POINTER(OptCfg),
                                     ctypes.POINTER(FlowState), ctypes.c_int, _P, ctypes.c_size_t, _P]),
-    "trx_flow_slab_moments": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, _P, _P, _P, ctypes.c_size_t, _P]),
+    "trx_flow_slab_moments": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_flow_slab_update": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, ctypes.POINTER(LossCfg),
-                                            ctypes.POINTER(OptCfg), ctypes.POINTER(FlowState), _P, _P, ctypes.c_size_t, _P]),
+                                            ctypes.POINTER(OptCfg), ctypes.POINTER(FlowState), _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_flow_loss_grad": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.POINTER(LossCfg), _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_flow_warp_backward": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, ctypes.c_int, _P, _P, _P]),
 }

@@ -23,6 +23,9 @@ struct FlowCoef {   // per pair, written by flow_coef_kernel, read by pass B (wa
 // of it is ever exchanged).  {0, D} = no partition.
 struct Slab {
     int zoff, Dm;
+    // neighbour ranks' flow planes adjacent to this slab ([ndim][H][W] each, flow BEFORE this iteration's update),
+    // NULL at the ends of the volume or when the smoothness regulariser is off
+    const float *halo_lo, *halo_hi;
 };
 
 __device__ __forceinline__ void decode(size_t i, int H, int W, int &z, int &y, int &x)
@@ -83,6 +86,13 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_moments_kernel(trx_volumes vol
 #pragma unroll
                     for (int c = 0; c < ND; c++) {
                         const float df = fl[c * nvox + i + dstride[dd]] - fl[c * nvox + i];
+                        vals[5 + dd] = fmaf(df, df, vals[5 + dd]);
+                    }
+                } else if (ND == 3 && dd == 0 && slab.halo_hi) {   // the difference across the slab boundary belongs to the lower slab
+                    const size_t hw = (size_t)H * W, pi = (size_t)y * W + x;
+#pragma unroll
+                    for (int c = 0; c < ND; c++) {
+                        const float df = slab.halo_hi[c * hw + pi] - fl[c * nvox + i];
                         vals[5 + dd] = fmaf(df, df, vals[5 + dd]);
                     }
                 }
@@ -198,7 +208,9 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
                 for (int dd = 0; dd < ND; dd++) {
                     float a = 0.f;
                     if (pos[dd] > 0) a += f0 - fl[ch * nvox + i - dstride[dd]];
+                    else if (ND == 3 && dd == 0 && slab.halo_lo) a += f0 - slab.halo_lo[ch * (size_t)H * W + (size_t)y * W + x];
                     if (pos[dd] + 1 < ext[dd]) a -= fl[ch * nvox + i + dstride[dd]] - f0;
+                    else if (ND == 3 && dd == 0 && slab.halo_hi) a -= slab.halo_hi[ch * (size_t)H * W + (size_t)y * W + x] - f0;
                     g = fmaf(c.sm[dd], a, g);
                 }
             }
@@ -302,7 +314,7 @@ static FlowCoef *coef_ptr(const trx_volumes *vol, void *workspace)
     return (FlowCoef *)((char *)workspace + off);
 }
 
-static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth, float *partials, hipStream_t s, Slab slab = Slab{0, -1})
+static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth, float *partials, hipStream_t s, Slab slab = Slab{0, -1, nullptr, nullptr})
 {
     if (slab.Dm < 0) slab.Dm = vol->D;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
@@ -319,7 +331,7 @@ static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth
 
 template <int MODE>
 static int launch_update(const trx_volumes *vol, const float *flow, float *flow_out, float *m, float *v, const FlowCoef *coef,
-                         const trx_opt_cfg &oc, bool smooth, hipStream_t s, Slab slab = Slab{0, -1})
+                         const trx_opt_cfg &oc, bool smooth, hipStream_t s, Slab slab = Slab{0, -1, nullptr, nullptr})
 {
     if (slab.Dm < 0) slab.Dm = vol->D;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
@@ -449,8 +461,8 @@ static int check_slab(const trx_volumes *vol, int z_offset, int D_full)
     return TRX_OK;
 }
 
-extern "C" int trx_flow_slab_moments(const trx_volumes *vol, int z_offset, int D_full, const float *flow, double *moments,
-                                     void *workspace, size_t workspace_bytes, void *stream)
+extern "C" int trx_flow_slab_moments(const trx_volumes *vol, int z_offset, int D_full, const float *flow, int smooth,
+                                     const float *halo_hi, double *moments, void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = check_slab(vol, z_offset, D_full);
     if (rc) return rc;
@@ -458,7 +470,7 @@ extern "C" int trx_flow_slab_moments(const trx_volumes *vol, int z_offset, int D
     if (workspace_bytes < trx_flow_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float *partials = (float *)workspace;
-    rc = launch_moments(vol, flow, false, partials, s, Slab{z_offset, D_full});
+    rc = launch_moments(vol, flow, smooth != 0, partials, s, Slab{z_offset, D_full, nullptr, smooth ? halo_hi : nullptr});
     if (rc) return rc;
     trx_loss_cfg lc = {0.f, 0.f, 0.f, 0.f, 0.f};
     trx_opt_cfg oc = {TRX_OPT_SGD, 0.f, 0.f, 0.f, 0.f};
@@ -470,20 +482,22 @@ extern "C" int trx_flow_slab_moments(const trx_volumes *vol, int z_offset, int D
 }
 
 extern "C" int trx_flow_slab_update(const trx_volumes *vol, int z_offset, int D_full, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
-                                    const trx_flow_state *st, const double *global_moments, void *workspace, size_t workspace_bytes,
-                                    void *stream)
+                                    const trx_flow_state *st, const double *global_moments, const float *halo_lo, const float *halo_hi,
+                                    void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = check_slab(vol, z_offset, D_full);
     if (rc) return rc;
     if (!global_moments) return TRX_ERR_ARG;
     rc = check_flow_args(vol, loss, opt, st, workspace, workspace_bytes);
     if (rc) return rc;
-    if (st->smooth_weight != 0.f) return TRX_ERR_ARG;   // the regulariser needs a flow halo exchange: not built yet
     hipStream_t s = (hipStream_t)stream;
+    const bool smooth = st->smooth_weight != 0.f;
     FlowCoef *coef = coef_ptr(vol, workspace);
     hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, (const float *)workspace, 0, vol->ndim, vol->D, vol->H, vol->W,
-                       *loss, *opt, 0.f, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr,
+                       *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr,
                        global_moments, D_full);
     TRX_CHECK_LAUNCH();
-    return launch_update<0>(vol, st->flow, st->flow, st->adam_m, st->adam_v, coef, *opt, false, s, Slab{z_offset, D_full});
+    // with the regulariser the update reads neighbours of the OLD flow: it is written to flow_tmp (the caller swaps)
+    return launch_update<0>(vol, st->flow, smooth ? st->flow_tmp : st->flow, st->adam_m, st->adam_v, coef, *opt, smooth, s,
+                            Slab{z_offset, D_full, halo_lo, halo_hi});
 }
