@@ -411,7 +411,140 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     int prev_lim = -1;
     unsigned needmask = 0;    // bit k: DMA slot k of this thread lies inside the needed extent of the current tile
 
-    for (int ty = ty_begin; ty < ty_end; ty++) {
+    // ---- box of one tile straight into LDS (LDS-DMA, no staging VGPRs); returns after the data has landed (this
+    // wave's part: the caller still needs the block barrier).  Only the float4 slots inside the tile's actual pre-image
+    // extent (ex4 x ey x ez) are fetched: lanes outside it are masked off, so the bytes a CU ingests track the need,
+    // not the box capacity.
+    auto stage_box = [&](int pk, int ox, int oy, int oz) {
+        const bool interior = (pk >> 25) & 1;
+        const int lim = pk & 0xffffff;   // (ez-1) << 16 | (ey-1) << 8 | (ex4-1)
+        if (lim != prev_lim) {           // extents rarely change along a column: refresh the slot mask only then
+            prev_lim = lim;
+            needmask = 0;
+#pragma unroll
+            for (int k = 0; k < kBoxIters; k++)   // per-field compare (dz,dy,dx4) <= lim: no field of lim-d may borrow
+                if ((((lim - dpk[k]) & 0x80808080) == 0) && ((dpk[k] >> 16) <= (lim >> 16))) needmask |= 1u << k;
+        }
+        const int obase = (oz * H + oy) * W + ox;
+        unsigned oob = 0;   // bit k: slot k of this thread is needed but lies outside the volume
+        if (interior) {
+            const float *__restrict__ mbase = mov + obase;    // uniform; obase >= 0 here
+#pragma unroll
+            for (int k = 0; k < kBoxIters; k++)
+                if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2)
+                    __builtin_amdgcn_global_load_lds(mbase + (unsigned)rel[k], box + (k * kTileWaves + wave) * 256, 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kBoxIters; k++)
+                if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2) {
+                    const int d = dpk[k];
+                    const int gz = oz + (d >> 16), gy = oy + ((d >> 8) & 0xff), gx = ox + (d & 0xff) * 4;
+                    const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+                    const unsigned idx = inb ? (unsigned)(obase + rel[k]) : 0u;
+                    if (!inb) oob |= 1u << k;
+                    __builtin_amdgcn_global_load_lds(mov + idx, box + (k * kTileWaves + wave) * 256, 16, 0, 0);
+                }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (oob) {   // zero padding: cells outside the volume (boundary tiles only)
+#pragma unroll
+            for (int k = 0; k < kBoxIters; k++)
+                if (oob & (1u << k))
+                    *reinterpret_cast<float4 *>(box + ((k * kTileWaves + wave) * 64 + lane) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // ---- one voxel gathered from the LDS box: coordinates, 4 paired reads, trilinear value (+ gradient)
+    auto gather = [&](const float *bp, float yn, float yid) -> Samp3 {
+        const float ix = fmaf(sx, yn, base_x);
+        const float iy = yid + fmaf(sy, yn, base_y);
+        const float iz = fmaf(sz, yn, base_z);
+        const int a = __mul24(floor_to_int(iz), kBH * kBW) + __mul24(floor_to_int(iy), kBW) + floor_to_int(ix);
+        const float *p = bp + a;
+        const f2 r00 = *reinterpret_cast<const f2u *>(p), r01 = *reinterpret_cast<const f2u *>(p + kBW);
+        const f2 r10 = *reinterpret_cast<const f2u *>(p + kBW * kBH), r11 = *reinterpret_cast<const f2u *>(p + kBW * kBH + kBW);
+        return lerp3_pairs<MODE == 0>(r00, r01, r10, r11, __builtin_amdgcn_fractf(ix), __builtin_amdgcn_fractf(iy), __builtin_amdgcn_fractf(iz));
+    };
+
+    int ty = ty_begin;
+    // ================= fast loop: full 16-row tiles whose box fits =================
+    // No per-lane branch around the accumulation: lanes outside a partial x / z tile work on the clamped
+    // column (x, z) = (X0, Z0) - every address stays valid - and their sums are discarded after the loop, so
+    // the 23 packed accumulators live in one set of registers with no copies at control-flow joins.
+    // The VALU is the busiest unit of this kernel (rocprof: ~70 % issue utilisation), so the loop is written to
+    // the instruction: addresses that are (uniform base + per-thread 32-bit offset) use the SGPR-base form of
+    // global_load (no VALU address arithmetic), per-row constants stay in SGPRs, the LDS address is a
+    // shift-add + two mad24 with SGPR strides.
+    {
+        const unsigned toffb = (unsigned)toff * 4u;
+        float sxv, syv, szv;   // VGPR copies of the uniform slopes: the per-row yn can then be the (single) SGPR operand
+        asm("v_mov_b32 %0, %1" : "=v"(sxv) : "s"(sx));
+        asm("v_mov_b32 %0, %1" : "=v"(syv) : "s"(sy));
+        asm("v_mov_b32 %0, %1" : "=v"(szv) : "s"(sz));
+        int ys_s, zs_s;        // LDS strides (bytes) pinned in SGPRs: gfx9 VOP3 takes no literal operand
+        asm("s_mov_b32 %0, %1" : "=s"(ys_s) : "i"(kBW * 4));
+        asm("s_mov_b32 %0, %1" : "=s"(zs_s) : "i"(kBW * kBH * 4));
+        const unsigned box_lds = (unsigned)(uintptr_t)box;   // LDS byte address of the box
+        typedef const __attribute__((address_space(3))) f2u *lds_f2;
+        for (; ty < ty_end; ty++) {
+            const int gl = (ty - ty_begin) & 63;
+            if (gl == 0) lane_geometry(ty);
+            const int pk = __builtin_amdgcn_readlane(g_pk, gl);
+            const int Y0 = ty * kTY;
+            if (!((pk >> 24) & 1) || Y0 + kTY > H) break;
+            const int ox = __builtin_amdgcn_readlane(g_ox, gl), oy = __builtin_amdgcn_readlane(g_oy, gl), oz = __builtin_amdgcn_readlane(g_oz, gl);
+            // row tables of this wave's 8 rows in lanes 0..7 (broadcast below with constant-lane v_readlane)
+            const float yn_l = ytab[Y0 + j0 + (lane & (kRows - 1))];
+            const float yid_l = unnorm<3>(yn_l, fH);
+            __builtin_amdgcn_s_setprio(TRX_STAGE_PRIO);
+            float tv[kRows];
+            const float *trow = tgt + (size_t)Y0 * W;   // uniform (toffb holds the row offset of this half)
+#pragma unroll
+            for (int j = 0; j < kRows; j++) {
+                if (TRX_DBG_SKIP == 3 || MODE == 3) tv[j] = 1.f;
+                else asm volatile("global_load_dword %0, %1, %2" : "=v"(tv[j]) : "v"(toffb), "s"(trow + (size_t)j * W) : "memory");
+            }
+            stage_box(pk, ox, oy, oz);   // ends with s_waitcnt vmcnt(0): the target column has landed too
+            asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]));
+            __syncthreads();
+            float yn_r[kRows], yid_r[kRows];
+#pragma unroll
+            for (int j = 0; j < kRows; j++) { yn_r[j] = lane_bcast(yn_l, j); yid_r[j] = lane_bcast(yid_l, j); }
+            if (TRX_DBG_SKIP != 1) {
+                const int bpb = (int)box_lds - ((oz * kBH + oy) * kBW + ox) * 4;   // LDS byte address of voxel (0,0,0) of the volume
+#pragma unroll
+                for (int j = 0; j < kRows; j++) {
+                    const float yn = yn_r[j];
+                    const float ix = fmaf(sxv, yn, base_x);
+                    const float iy = yid_r[j] + fmaf(syv, yn, base_y);
+                    const float iz = fmaf(szv, yn, base_z);
+                    int a0, a1, a2, a3;
+                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a0) : "v"(floor_to_int(ix)), "s"(bpb));
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a1) : "v"(floor_to_int(iy)), "s"(ys_s), "v"(a0));
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a2) : "v"(floor_to_int(iz)), "s"(zs_s), "v"(a1));
+                    asm("v_add_u32 %0, %1, %2" : "=v"(a3) : "s"(zs_s), "v"(a2));
+                    const f2 r00 = *(lds_f2)(unsigned)a2, r01 = *(lds_f2)(unsigned)(a2 + kBW * 4);
+                    const f2 r10 = *(lds_f2)(unsigned)a3, r11 = *(lds_f2)(unsigned)(a3 + kBW * 4);
+                    const Samp3 sm = lerp3_pairs<MODE == 0>(r00, r01, r10, r11, __builtin_amdgcn_fractf(ix), __builtin_amdgcn_fractf(iy),
+                                                            __builtin_amdgcn_fractf(iz));
+                    if constexpr (MODE == 3) { if (act) wout[(size_t)Y0 * W + (unsigned)(toff + j * W)] = sm.v; }
+                    else f1_accumulate_pk<MODE>(sm, tv[j], yn, acc);
+                }
+            }
+            __syncthreads();   // the box is overwritten by the next tile
+        }
+        if (!act) {
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc.AB[q][c] = (f2)(0.f);
+            acc.M01 = acc.M23 = (f2)(0.f);
+            acc.M4 = 0.f;
+        }
+    }
+
+    // ================= generic loop: partial last tile, tiles whose box does not fit, W % 4 != 0 =================
+    for (; ty < ty_end; ty++) {
         const int gl = (ty - ty_begin) & 63;
         if (gl == 0) lane_geometry(ty);
         const int Y0 = ty * kTY;
@@ -421,11 +554,10 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         const float yid_l = unnorm<3>(yn_l, fH);
         const int pk = __builtin_amdgcn_readlane(g_pk, gl);
         const int ox = __builtin_amdgcn_readlane(g_ox, gl), oy = __builtin_amdgcn_readlane(g_oy, gl), oz = __builtin_amdgcn_readlane(g_oz, gl);
-        const bool fits = (pk >> 24) & 1, interior = (pk >> 25) & 1;
+        const bool fits = (pk >> 24) & 1;
         const float *__restrict__ trow = tgt + (size_t)Y0 * W;   // uniform base of this tile's target rows
 
         if (fits) {
-            // ---- (1) target column into registers, box straight into LDS (LDS-DMA, no staging VGPRs) ----
             // staging waves outrank the co-resident block's gather waves: their loads should enter the memory
             // system as early as possible, the VALU work they displace is short
             __builtin_amdgcn_s_setprio(TRX_STAGE_PRIO);
@@ -433,46 +565,8 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
 #pragma unroll
             for (int j = 0; j < kRows; j++)
                 tv[j] = (TRX_DBG_SKIP == 3 || MODE == 3) ? 1.f : trow[(unsigned)(toff + (min(j0 + j, ny - 1) - j0) * W)];
-            const int lim = pk & 0xffffff;   // (ez-1) << 16 | (ey-1) << 8 | (ex4-1)
-            if (lim != prev_lim) {           // extents rarely change along a column: refresh the slot mask only then
-                prev_lim = lim;
-                needmask = 0;
-#pragma unroll
-                for (int k = 0; k < kBoxIters; k++)   // per-field compare (dz,dy,dx4) <= lim: no field of lim-d may borrow
-                    if ((((lim - dpk[k]) & 0x80808080) == 0) && ((dpk[k] >> 16) <= (lim >> 16))) needmask |= 1u << k;
-            }
-            const int obase = (oz * H + oy) * W + ox;
-            unsigned oob = 0;   // bit k: slot k of this thread is needed but lies outside the volume
-            // only the float4 slots inside the tile's actual pre-image extent (ex4 x ey x ez) are fetched:
-            // lanes outside it are masked off, so the bytes a CU ingests track the need, not the box capacity
-            if (interior) {
-                const float *__restrict__ mbase = mov + obase;    // uniform; obase >= 0 here
-#pragma unroll
-                for (int k = 0; k < kBoxIters; k++)
-                    if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2)
-                        __builtin_amdgcn_global_load_lds(mbase + (unsigned)rel[k], box + (k * kTileWaves + wave) * 256, 16, 0, 0);
-            } else {
-#pragma unroll
-                for (int k = 0; k < kBoxIters; k++)
-                    if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2) {
-                        const int d = dpk[k];
-                        const int gz = oz + (d >> 16), gy = oy + ((d >> 8) & 0xff), gx = ox + (d & 0xff) * 4;
-                        const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-                        const unsigned idx = inb ? (unsigned)(obase + rel[k]) : 0u;
-                        if (!inb) oob |= 1u << k;
-                        __builtin_amdgcn_global_load_lds(mov + idx, box + (k * kTileWaves + wave) * 256, 16, 0, 0);
-                    }
-            }
-            __builtin_amdgcn_s_setprio(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (oob) {   // zero padding: cells outside the volume (boundary tiles only)
-#pragma unroll
-                for (int k = 0; k < kBoxIters; k++)
-                    if (oob & (1u << k))
-                        *reinterpret_cast<float4 *>(box + ((k * kTileWaves + wave) * 64 + lane) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            stage_box(pk, ox, oy, oz);
             __syncthreads();
-            // ---- (2) gather from LDS ----------------------------------------------------------------
             // wave-uniform row constants of this wave's half (rows j0 .. j0+7) -> SGPRs.  The v_readlane MUST
             // run here, in uniform control flow: inside `if (act)` lanes 0..15 may be inactive (partial x tile)
             // and the compiler is free to sink the computation of yn_l / yid_l into that branch.
@@ -480,29 +574,14 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
 #pragma unroll
             for (int j = 0; j < kRows; j++) { yn_r[j] = lane_bcast(yn_l, j0 + j); yid_r[j] = lane_bcast(yid_l, j0 + j); }
             if (act && TRX_DBG_SKIP != 1) {
-                const float *bp = box - ((oz * kBH + oy) * kBW + ox);   // box address of voxel (0,0,0) of the volume
-                auto voxel = [&](int j) {
-                    const float yn = yn_r[j], yid = yid_r[j];
-                    const float ix = fmaf(sx, yn, base_x);
-                    const float iy = yid + fmaf(sy, yn, base_y);
-                    const float iz = fmaf(sz, yn, base_z);
-                    const int a = __mul24(floor_to_int(iz), kBH * kBW) + __mul24(floor_to_int(iy), kBW) + floor_to_int(ix);
-                    const float *p = bp + a;
-                    const f2 r00 = *reinterpret_cast<const f2u *>(p), r01 = *reinterpret_cast<const f2u *>(p + kBW);
-                    const f2 r10 = *reinterpret_cast<const f2u *>(p + kBW * kBH), r11 = *reinterpret_cast<const f2u *>(p + kBW * kBH + kBW);
-                    const Samp3 sm = lerp3_pairs<MODE == 0>(r00, r01, r10, r11, __builtin_amdgcn_fractf(ix), __builtin_amdgcn_fractf(iy),
-                                                            __builtin_amdgcn_fractf(iz));
-                    if constexpr (MODE == 3) wout[(size_t)Y0 * W + (unsigned)(toff + j * W)] = sm.v;
-                    else f1_accumulate_pk<MODE>(sm, tv[j], yn, acc);
-                };
-                if (ny == kTY) {
+                const float *bp = box - ((oz * kBH + oy) * kBW + ox);
 #pragma unroll
-                    for (int j = 0; j < kRows; j++) voxel(j);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < kRows; j++)
-                        if (j0 + j < ny) voxel(j);
-                }
+                for (int j = 0; j < kRows; j++)
+                    if (j0 + j < ny) {
+                        const Samp3 sm = gather(bp, yn_r[j], yid_r[j]);
+                        if constexpr (MODE == 3) wout[(size_t)Y0 * W + (unsigned)(toff + j * W)] = sm.v;
+                        else f1_accumulate_pk<MODE>(sm, tv[j], yn_r[j], acc);
+                    }
             }
             __syncthreads();   // the box is overwritten by the next tile
         } else if (act) {
