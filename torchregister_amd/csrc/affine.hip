@@ -179,12 +179,16 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
 // Blocks are persistent over a contiguous run of tiles of ONE pair and keep the 41 partial sums
 // in registers; thread (x, z) is fixed inside a tile so the xn / zn columns fold once per tile.
 // ------------------------------------------------------------------------------------------
-#ifndef TRX_TILE_Z
-#define TRX_TILE_Z 8      // output tile depth: 8 (512-thread blocks, 2 per CU) or 4 (256-thread blocks, 4 per CU)
-#endif
-constexpr int kTX = 32, kTY = 16, kTZ = TRX_TILE_Z;                 // output tile
-constexpr int kBW = 44, kBH = 24, kBD = (TRX_TILE_Z == 8) ? 14 : 8; // LDS box (floats); kBW % 4 == 0
+constexpr int kTX = 32, kTY = 16, kTZ = 8;         // output tile
+// LDS box (floats), kBW % 4 == 0.  One LDS-DMA piece (one global_load_lds_dwordx4 per wave) covers TWO z planes of the
+// box: 2 * kBH * kBW4 = 506 float4 slots for the 512 threads, so piece k of a thread is its piece-0 slot shifted by
+// 2k planes - one VGPR offset + one packed slot id per thread instead of one per piece.
+constexpr int kBW = 44, kBH = 23, kBD = 14;
 constexpr int kBW4 = kBW / 4;
+constexpr int kPlaneSlots = kBH * kBW4;              // 253 float4 per box plane
+constexpr int kPieces = kBD / 2;                     // 7 DMA pieces per tile
+constexpr int kPieceFloats = 2 * kBH * kBW;          // 2024 floats of LDS per piece
+static_assert(kBD % 2 == 0 && 2 * kPlaneSlots <= kTX * kTZ * 2, "one DMA piece = two box planes, one slot per thread");
 
 struct TileGeom {
     int ntx, nty, ntz, ntiles, blocks_per_pair, ysplit, tiles_per_seg;
@@ -244,9 +248,9 @@ __device__ __forceinline__ void f1_accumulate_pk(const Samp3 &sm, float yv, floa
 constexpr int kTileThreads = kTX * kTZ * 2;             // (32 x) x (kTZ z) x (2 halves of 8 rows): 512 or 256 threads
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kRows = kTY / 2;                           // rows per thread
-constexpr int kBoxSlots = kBW4 * kBH * kBD;              // 3696 float4 slots
-constexpr int kBoxIters = (kBoxSlots + kTileThreads - 1) / kTileThreads;   // 8 LDS-DMA pieces per wave
-constexpr int kBoxAlloc = kBoxIters * kTileThreads * 4;  // floats incl. the tail the last piece spills into (64 KiB)
+constexpr int kReduceScratch = kTileWaves * 16 * 65 + kTileWaves * 16;   // floats block_reduce_store_nw needs (aliases the box)
+// the 6 lanes past slot 505 of a piece are always masked, so the last piece needs no tail
+constexpr int kBoxAlloc = (kPieces * kPieceFloats > kReduceScratch) ? kPieces * kPieceFloats : kReduceScratch;   // 56.7 KB
 
 template <int NV, int NW>
 __device__ __forceinline__ void block_reduce_store_nw(const float (&vals)[NV], float *__restrict__ out, float *smem)
@@ -362,16 +366,18 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     const float corner_y = uni(hH * fmaf(t10, cxn, fmaf(t12, czn, t13)));
     const float corner_z = uni(unnorm<3>(czn, fD) + hD * fmaf(t20, cxn, fmaf(t22 - 1.0f, czn, t23)));
 
-    // LDS-DMA slot geometry of this thread (tile independent): slot k covers box float4 (dz, dy, dx4)
-    int rel[kBoxIters], dpk[kBoxIters];   // element offset inside the volume; packed (dz << 16 | dy << 8 | dx4)
-#pragma unroll
-    for (int k = 0; k < kBoxIters; k++) {
-        const int q4 = (k * kTileWaves + wave) * 64 + lane;
-        const int row = q4 / kBW4, dx4 = q4 - row * kBW4;
-        const int dz = row / kBH, dy = row - dz * kBH;
-        rel[k] = (dz * H + dy) * W + dx4 * 4;
-        dpk[k] = (dz << 16) | (dy << 8) | dx4;
-    }
+    // LDS-DMA slot of a thread in piece 0 (tile independent): box float4 (pz, dy, dx4), pz = 0 / 1.
+    // rb0 = its byte offset from the box origin voxel inside the volume, d0 = packed (dz << 16 | dy << 8 | dx4).
+    // Piece k: d = d0 + (2k << 16), byte offset rb0 + k * (2 H W 4).  The 6 spare lanes get dz = 100 (never needed).
+    auto slot_geom = [&](int ln, unsigned &rb0, int &d0) {
+        const int q = wave * 64 + ln;
+        const int pz = (q >= kPlaneSlots) ? 1 : 0, r = q - pz * kPlaneSlots;
+        const int dy = r / kBW4, dx4 = r - dy * kBW4;
+        const bool valid = q < 2 * kPlaneSlots;
+        rb0 = valid ? (unsigned)((pz * H + dy) * W + dx4 * 4) * 4u : 0u;
+        d0 = valid ? ((pz << 16) | (dy << 8) | dx4) : (100 << 16);
+    };
+    const unsigned piece_stride = (unsigned)(2 * H * W) * 4u;   // bytes between the pieces of one thread inside the volume
 
     F1Acc acc;
 #pragma unroll
@@ -408,64 +414,6 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         g_ox = ox; g_oy = oy; g_oz = oz;
         g_pk = fits ? ((ex4 - 1) | ((ey - 1) << 8) | ((ez - 1) << 16) | (1 << 24) | ((interior ? 1 : 0) << 25)) : 0;
     };
-    int prev_lim = -1;
-    unsigned needmask = 0;    // bit k: DMA slot k of this thread lies inside the needed extent of the current tile
-
-    // ---- box of one tile straight into LDS (LDS-DMA, no staging VGPRs); returns after the data has landed (this
-    // wave's part: the caller still needs the block barrier).  Only the float4 slots inside the tile's actual pre-image
-    // extent (ex4 x ey x ez) are fetched: lanes outside it are masked off, so the bytes a CU ingests track the need,
-    // not the box capacity.
-    auto stage_box = [&](int pk, int ox, int oy, int oz) {
-        const bool interior = (pk >> 25) & 1;
-        const int lim = pk & 0xffffff;   // (ez-1) << 16 | (ey-1) << 8 | (ex4-1)
-        if (lim != prev_lim) {           // extents rarely change along a column: refresh the slot mask only then
-            prev_lim = lim;
-            needmask = 0;
-#pragma unroll
-            for (int k = 0; k < kBoxIters; k++)   // per-field compare (dz,dy,dx4) <= lim: no field of lim-d may borrow
-                if ((((lim - dpk[k]) & 0x80808080) == 0) && ((dpk[k] >> 16) <= (lim >> 16))) needmask |= 1u << k;
-        }
-        const int obase = (oz * H + oy) * W + ox;
-        unsigned oob = 0;   // bit k: slot k of this thread is needed but lies outside the volume
-        if (interior) {
-            const float *__restrict__ mbase = mov + obase;    // uniform; obase >= 0 here
-#pragma unroll
-            for (int k = 0; k < kBoxIters; k++)
-                if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2)
-                    __builtin_amdgcn_global_load_lds(mbase + (unsigned)rel[k], box + (k * kTileWaves + wave) * 256, 16, 0, 0);
-        } else {
-#pragma unroll
-            for (int k = 0; k < kBoxIters; k++)
-                if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2) {
-                    const int d = dpk[k];
-                    const int gz = oz + (d >> 16), gy = oy + ((d >> 8) & 0xff), gx = ox + (d & 0xff) * 4;
-                    const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-                    const unsigned idx = inb ? (unsigned)(obase + rel[k]) : 0u;
-                    if (!inb) oob |= 1u << k;
-                    __builtin_amdgcn_global_load_lds(mov + idx, box + (k * kTileWaves + wave) * 256, 16, 0, 0);
-                }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (oob) {   // zero padding: cells outside the volume (boundary tiles only)
-#pragma unroll
-            for (int k = 0; k < kBoxIters; k++)
-                if (oob & (1u << k))
-                    *reinterpret_cast<float4 *>(box + ((k * kTileWaves + wave) * 64 + lane) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    // ---- one voxel gathered from the LDS box: coordinates, 4 paired reads, trilinear value (+ gradient)
-    auto gather = [&](const float *bp, float yn, float yid) -> Samp3 {
-        const float ix = fmaf(sx, yn, base_x);
-        const float iy = yid + fmaf(sy, yn, base_y);
-        const float iz = fmaf(sz, yn, base_z);
-        const int a = __mul24(floor_to_int(iz), kBH * kBW) + __mul24(floor_to_int(iy), kBW) + floor_to_int(ix);
-        const float *p = bp + a;
-        const f2 r00 = *reinterpret_cast<const f2u *>(p), r01 = *reinterpret_cast<const f2u *>(p + kBW);
-        const f2 r10 = *reinterpret_cast<const f2u *>(p + kBW * kBH), r11 = *reinterpret_cast<const f2u *>(p + kBW * kBH + kBW);
-        return lerp3_pairs<MODE == 0>(r00, r01, r10, r11, __builtin_amdgcn_fractf(ix), __builtin_amdgcn_fractf(iy), __builtin_amdgcn_fractf(iz));
-    };
-
     int ty = ty_begin;
     // ================= fast loop: full 16-row tiles whose box fits =================
     // No per-lane branch around the accumulation: lanes outside a partial x / z tile work on the clamped
@@ -477,6 +425,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     // shift-add + two mad24 with SGPR strides.
     {
         const unsigned toffb = (unsigned)toff * 4u;
+        const unsigned lane7b = (unsigned)(lane & (kRows - 1)) * 4u;
         float sxv, syv, szv;   // VGPR copies of the uniform slopes: the per-row yn can then be the (single) SGPR operand
         asm("v_mov_b32 %0, %1" : "=v"(sxv) : "s"(sx));
         asm("v_mov_b32 %0, %1" : "=v"(syv) : "s"(sy));
@@ -485,6 +434,26 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         asm("s_mov_b32 %0, %1" : "=s"(ys_s) : "i"(kBW * 4));
         asm("s_mov_b32 %0, %1" : "=s"(zs_s) : "i"(kBW * kBH * 4));
         const unsigned box_lds = (unsigned)(uintptr_t)box;   // LDS byte address of the box
+        unsigned rb0;                                        // byte offset of this thread's piece-0 DMA slot
+        {
+            int d0;
+            slot_geom(lane, rb0, d0);
+        }
+        unsigned long long m_ld[kPieces];                    // cached exec masks of the DMA pieces (wave-uniform)
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) m_ld[k] = 0;
+        unsigned m_oob = 0;                                  // bit k: slot k of this thread is needed but outside the volume
+        // Fetched extent = the LARGEST pre-image extent any tile of this theta can have (capped at the box): the exact
+        // extent of a tile flips between two values with the fractional position of its corner, and every change
+        // would invalidate the cached masks; one extra row / plane / float4 of DMA is cheaper than that.
+        int lim_blk;
+        {
+            const float slack2 = 0.1f;
+            const int ex4m = (((int)floorf(ext_hi[0] - ext_lo[0] + slack2) + 5) >> 2) + 1;   // hx1 - lx0 <= floor(span) + 2, + 3 of alignment
+            const int eym = (int)floorf(ext_hi[1] - ext_lo[1] + slack2) + 3, ezm = (int)floorf(ext_hi[2] - ext_lo[2] + slack2) + 3;
+            lim_blk = __builtin_amdgcn_readfirstlane(((min(ezm, kBD) - 1) << 16) | ((min(eym, kBH) - 1) << 8) | (min(ex4m, kBW4) - 1));
+        }
+        int m_lim = -1, m_lo = -1, m_hi = -1;
         typedef const __attribute__((address_space(3))) f2u *lds_f2;
         for (; ty < ty_end; ty++) {
             const int gl = (ty - ty_begin) & 63;
@@ -494,8 +463,8 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             if (!((pk >> 24) & 1) || Y0 + kTY > H) break;
             const int ox = __builtin_amdgcn_readlane(g_ox, gl), oy = __builtin_amdgcn_readlane(g_oy, gl), oz = __builtin_amdgcn_readlane(g_oz, gl);
             // row tables of this wave's 8 rows in lanes 0..7 (broadcast below with constant-lane v_readlane)
-            const float yn_l = ytab[Y0 + j0 + (lane & (kRows - 1))];
-            const float yid_l = unnorm<3>(yn_l, fH);
+            float yn_l;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(yn_l) : "v"(lane7b), "s"(ytab + Y0 + j0) : "memory");
             __builtin_amdgcn_s_setprio(TRX_STAGE_PRIO);
             float tv[kRows];
             const float *trow = tgt + (size_t)Y0 * W;   // uniform (toffb holds the row offset of this half)
@@ -504,8 +473,74 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                 if (TRX_DBG_SKIP == 3 || MODE == 3) tv[j] = 1.f;
                 else asm volatile("global_load_dword %0, %1, %2" : "=v"(tv[j]) : "v"(toffb), "s"(trow + (size_t)j * W) : "memory");
             }
-            stage_box(pk, ox, oy, oz);   // ends with s_waitcnt vmcnt(0): the target column has landed too
-            asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]));
+            // ---- box -> LDS.  Which float4 slots of this thread are fetched (needed by the tile AND inside the
+            // volume) is cached as one exec mask per DMA piece, keyed on the packed per-axis slot range [lo, hi];
+            // the key only changes where the column's pre-image crosses a volume face or the extent changes.
+            {
+                const int lim = lim_blk;         // (ez-1) << 16 | (ey-1) << 8 | (ex4-1)
+                const int loz = max(0, -oz), loy = max(0, -oy), lox = max(0, -(ox >> 2));
+                const int hiz = min(lim >> 16, D - 1 - oz), hiy = min((lim >> 8) & 0xff, H - 1 - oy), hix = min(lim & 0xff, ((W - ox) >> 2) - 1);
+                const bool none = (hiz < loz) || (hiy < loy) || (hix < lox);   // the whole pre-image lies outside the volume
+                const int lo = none ? 0x7f7f7f : ((loz << 16) | (loy << 8) | lox);
+                const int hi = none ? 0 : ((hiz << 16) | (hiy << 8) | hix);
+                if (lim != m_lim || lo != m_lo || hi != m_hi) {
+                    m_lim = lim; m_lo = lo; m_hi = hi;
+                    m_oob = 0;
+                    int ln = lane;   // opaque copy: keeps the slot decode inside this (rarely taken) branch
+                    asm volatile("" : "+v"(ln));
+                    unsigned rbx;
+                    int d0;
+                    slot_geom(ln, rbx, d0);
+#pragma unroll
+                    for (int k = 0; k < kPieces; k++) {   // per-field compares on the packed (dz, dy, dx4): no field may borrow
+                        const int d = d0 + (k << 17);
+                        const bool need = (((lim - d) & 0x80808080) == 0);
+                        const bool ld = need && (((hi - d) & 0x80808080) == 0) && (((d - lo) & 0x80808080) == 0);
+                        m_ld[k] = __builtin_amdgcn_ballot_w64(ld);
+                        if (need && !ld) m_oob |= 1u << k;
+                    }
+                }
+                if (TRX_DBG_SKIP != 2) {
+                    const float *mbase = mov + (ptrdiff_t)((oz * H + oy) * W + ox);   // uniform; may point below `mov` (those lanes are masked)
+                    unsigned long long sv;
+                    unsigned m0s;
+                    static_assert(kPieces == 7, "the DMA block below is written for 7 pieces");
+                    // one exec mask + one SGPR-base load per piece; s[100:101] walks the volume by two planes per piece
+#define TRX_DMA_NEXT(K)                                  \
+    "s_add_u32 s100, s100, %[vstr]\n\t"                  \
+    "s_addc_u32 s101, s101, 0\n\t"                       \
+    "s_add_u32 m0, m0, %[pstr]\n\t"                      \
+    "s_mov_b64 exec, %[k" #K "]\n\t"                     \
+    "global_load_lds_dwordx4 %[off], s[100:101]\n\t"
+                    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                                 "s_mov_b32 %[m0s], m0\n\t"
+                                 "s_mov_b64 s[100:101], %[base]\n\t"
+                                 "s_mov_b32 m0, %[lds]\n\t"
+                                 "s_mov_b64 exec, %[k0]\n\t"
+                                 "global_load_lds_dwordx4 %[off], s[100:101]\n\t"
+                                 TRX_DMA_NEXT(1) TRX_DMA_NEXT(2) TRX_DMA_NEXT(3) TRX_DMA_NEXT(4) TRX_DMA_NEXT(5) TRX_DMA_NEXT(6)
+                                 "s_mov_b64 exec, %[sv]\n\t"
+                                 "s_mov_b32 m0, %[m0s]"
+                                 : [sv] "=&s"(sv), [m0s] "=&s"(m0s)
+                                 : [lds] "s"(box_lds + (unsigned)wave * 1024u), [base] "s"(mbase), [pstr] "i"(kPieceFloats * 4),
+                                   [vstr] "s"(piece_stride), [off] "v"(rb0), [k0] "s"(m_ld[0]), [k1] "s"(m_ld[1]), [k2] "s"(m_ld[2]),
+                                   [k3] "s"(m_ld[3]), [k4] "s"(m_ld[4]), [k5] "s"(m_ld[5]), [k6] "s"(m_ld[6])
+                                 : "memory", "scc", "s100", "s101");
+#undef TRX_DMA_NEXT
+                }
+                if (m_oob) {   // zero padding: needed cells outside the volume (tiles at a volume face only)
+                    float zero;
+                    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));   // materialised here, not kept live across the loop
+#pragma unroll
+                    for (int k = 0; k < kPieces; k++)
+                        if (m_oob & (1u << k))
+                            *reinterpret_cast<float4 *>(box + k * kPieceFloats + (wave * 64 + lane) * 4) = make_float4(zero, zero, zero, zero);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // box pieces and the target column have landed
+            }
+            asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]), "+v"(yn_l));
+            const float yid_l = unnorm<3>(yn_l, fH);
             __syncthreads();
             float yn_r[kRows], yid_r[kRows];
 #pragma unroll
@@ -542,6 +577,74 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             acc.M4 = 0.f;
         }
     }
+
+    // slot geometry for the generic loop, recomputed here from an opaque copy of the lane id so that it is not
+    // live across the fast loop
+    unsigned rb0;
+    int d0;
+    {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        slot_geom(ln, rb0, d0);
+    }
+    int prev_lim = -1;
+    unsigned needmask = 0;    // bit k: DMA slot k of this thread lies inside the needed extent of the current tile
+
+    // ---- box of one tile straight into LDS (LDS-DMA, no staging VGPRs); returns after the data has landed (this
+    // wave's part: the caller still needs the block barrier).  Only the float4 slots inside the tile's actual pre-image
+    // extent (ex4 x ey x ez) are fetched: lanes outside it are masked off, so the bytes a CU ingests track the need,
+    // not the box capacity.
+    auto stage_box = [&](int pk, int ox, int oy, int oz) {
+        const bool interior = (pk >> 25) & 1;
+        const int lim = pk & 0xffffff;   // (ez-1) << 16 | (ey-1) << 8 | (ex4-1)
+        if (lim != prev_lim) {           // extents rarely change along a column: refresh the slot mask only then
+            prev_lim = lim;
+            needmask = 0;
+#pragma unroll
+            for (int k = 0; k < kPieces; k++)   // per-field compare (dz,dy,dx4) <= lim: no field of lim-d may borrow
+                if (((lim - (d0 + (k << 17))) & 0x80808080) == 0) needmask |= 1u << k;
+        }
+        const int obase = (oz * H + oy) * W + ox;
+        unsigned oob = 0;   // bit k: slot k of this thread is needed but lies outside the volume
+        if (interior) {
+            const char *__restrict__ mbase = reinterpret_cast<const char *>(mov + obase);    // uniform; obase >= 0 here
+#pragma unroll
+            for (int k = 0; k < kPieces; k++)
+                if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(mbase + (size_t)k * piece_stride + rb0),
+                                                     box + k * kPieceFloats + wave * 256, 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPieces; k++)
+                if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2) {
+                    const int d = d0 + (k << 17);
+                    const int gz = oz + (d >> 16), gy = oy + ((d >> 8) & 0xff), gx = ox + (d & 0xff) * 4;
+                    const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+                    const unsigned idx = inb ? (unsigned)(obase + (int)((rb0 + k * piece_stride) >> 2)) : 0u;
+                    if (!inb) oob |= 1u << k;
+                    __builtin_amdgcn_global_load_lds(mov + idx, box + k * kPieceFloats + wave * 256, 16, 0, 0);
+                }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (oob) {   // zero padding: cells outside the volume (boundary tiles only)
+#pragma unroll
+            for (int k = 0; k < kPieces; k++)
+                if (oob & (1u << k))
+                    *reinterpret_cast<float4 *>(box + k * kPieceFloats + (wave * 64 + lane) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // ---- one voxel gathered from the LDS box: coordinates, 4 paired reads, trilinear value (+ gradient)
+    auto gather = [&](const float *bp, float yn, float yid) -> Samp3 {
+        const float ix = fmaf(sx, yn, base_x);
+        const float iy = yid + fmaf(sy, yn, base_y);
+        const float iz = fmaf(sz, yn, base_z);
+        const int a = __mul24(floor_to_int(iz), kBH * kBW) + __mul24(floor_to_int(iy), kBW) + floor_to_int(ix);
+        const float *p = bp + a;
+        const f2 r00 = *reinterpret_cast<const f2u *>(p), r01 = *reinterpret_cast<const f2u *>(p + kBW);
+        const f2 r10 = *reinterpret_cast<const f2u *>(p + kBW * kBH), r11 = *reinterpret_cast<const f2u *>(p + kBW * kBH + kBW);
+        return lerp3_pairs<MODE == 0>(r00, r01, r10, r11, __builtin_amdgcn_fractf(ix), __builtin_amdgcn_fractf(iy), __builtin_amdgcn_fractf(iz));
+    };
 
     // ================= generic loop: partial last tile, tiles whose box does not fit, W % 4 != 0 =================
     for (; ty < ty_end; ty++) {
