@@ -103,6 +103,18 @@ int main(int argc, char **argv)
     dim3 tgrid(tgm.blocks_per_pair, B);
     rep("tile MODE1 (moments)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<1>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
     rep("tile MODE0 (full F1)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
+#if TRX_TIMING
+    {
+        std::vector<unsigned long long> tmv(4 * 8192);
+        CK(hipMemcpyFromSymbol(tmv.data(), HIP_SYMBOL(trx::trx_timing), tmv.size() * 8));
+        const size_t nb = std::min<size_t>(8192, (size_t)tgrid.x * tgrid.y);
+        double a[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < nb; i++) for (int k = 0; k < 4; k++) a[k] += (double)tmv[i * 4 + k];
+        const double tiles = (double)tgm.nty / tgm.ysplit;
+        printf("  timing per tile (s_memtime ticks, wave 0 avg over %zu blocks): issue+wait %.0f  barrier1 %.0f  gather %.0f  barrier2 %.0f\n",
+               nb, a[0] / nb / tiles, a[1] / nb / tiles, a[2] / nb / tiles, a[3] / nb / tiles);
+    }
+#endif
     // identity theta (all samples on voxel centres)
     const float id[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = id[i];

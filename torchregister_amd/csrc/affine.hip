@@ -214,6 +214,21 @@ static TileGeom tile_geom(const trx_volumes &v)
 #ifndef TRX_DBG_SKIP
 #define TRX_DBG_SKIP 0   // development ablation (tools/kbench.hip): 1 = no gather/compute, 2 = no box staging, 3 = no target loads
 #endif
+#ifndef TRX_STAGGER
+#define TRX_STAGGER 0
+#endif
+#ifndef TRX_STAGGER_MODE
+#define TRX_STAGGER_MODE 1
+#endif
+#ifndef TRX_TIMING
+#define TRX_TIMING 0      // development (tools/kbench.hip): per-block staging / gather cycle counts into trx_timing[]
+#endif
+#if TRX_TIMING
+__device__ unsigned long long trx_timing[4 * 8192];
+#endif
+#ifndef TRX_SWP_BARRIER
+#define TRX_SWP_BARRIER 0
+#endif
 #ifndef TRX_STAGE_PRIO
 #define TRX_STAGE_PRIO 3
 #endif
@@ -307,7 +322,11 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     // = out[B][channels][D][H][W]; blockIdx.y enumerates (pair, channel), channels share theta)
     constexpr int NQ = (MODE == 0) ? 3 : 0;
     constexpr int NP = (MODE == 0) ? np_full(3) : 5;
+#ifdef TRX_LDS_PAD   // development: inflate the LDS footprint to force one block per CU
+    __shared__ __attribute__((aligned(16))) float box[kBoxAlloc + TRX_LDS_PAD];
+#else
     __shared__ __attribute__((aligned(16))) float box[kBoxAlloc];
+#endif
     const int b = (MODE == 3) ? blockIdx.y / channels : blockIdx.y;
     const int ch = (MODE == 3) ? blockIdx.y - b * channels : 0;
     const int D = vol.D, H = vol.H, W = vol.W;
@@ -414,6 +433,18 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         g_ox = ox; g_oy = oy; g_oz = oz;
         g_pk = fits ? ((ex4 - 1) | ((ey - 1) << 8) | ((ez - 1) << 16) | (1 << 24) | ((interior ? 1 : 0) << 25)) : 0;
     };
+#if TRX_STAGGER
+    // development: phase-shift one of the two co-resident blocks of a CU ("staging / compute phases")
+    {
+        bool late;
+        if (TRX_STAGGER_MODE == 1) late = (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1) != 0;
+        else late = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4) & 1) != 0;   // HW_ID.TG_ID parity
+        if (late) {
+#pragma unroll
+            for (int i = 0; i < TRX_STAGGER; i += 16) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+#endif
     int ty = ty_begin;
     // ================= fast loop: full 16-row tiles whose box fits =================
     // No per-lane branch around the accumulation: lanes outside a partial x / z tile work on the clamped
@@ -454,14 +485,25 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             lim_blk = __builtin_amdgcn_readfirstlane(((min(ezm, kBD) - 1) << 16) | ((min(eym, kBH) - 1) << 8) | (min(ex4m, kBW4) - 1));
         }
         int m_lim = -1, m_lo = -1, m_hi = -1;
+#if TRX_TIMING
+        unsigned long long tm_acc[4] = {0, 0, 0, 0};   // wave 0: stage-wait, barrier-1 wait, gather, barrier-2 wait
+#endif
         typedef const __attribute__((address_space(3))) f2u *lds_f2;
-        for (; ty < ty_end; ty++) {
-            const int gl = (ty - ty_begin) & 63;
-            if (gl == 0) lane_geometry(ty);
+        // Tiles come in chunks of 64 (geometry: one tile per lane); the leading run of fast tiles of a chunk is a plain
+        // counted loop - no exit in the middle, so the accumulators stay in one register set.
+        while (ty < ty_end) {
+          lane_geometry(ty);
+          const int chunk = min(64, ty_end - ty);
+          const bool ok = (lane < chunk) && ((g_pk >> 24) & 1) && ((ty + lane + 1) * kTY <= H);
+          const unsigned long long bad = ~__builtin_amdgcn_ballot_w64(ok);
+          const int nf = bad ? __builtin_ctzll(bad) : 64;
+          for (int gl = 0; gl < nf; gl++) {
             const int pk = __builtin_amdgcn_readlane(g_pk, gl);
-            const int Y0 = ty * kTY;
-            if (!((pk >> 24) & 1) || Y0 + kTY > H) break;
+            const int Y0 = (ty + gl) * kTY;
             const int ox = __builtin_amdgcn_readlane(g_ox, gl), oy = __builtin_amdgcn_readlane(g_oy, gl), oz = __builtin_amdgcn_readlane(g_oz, gl);
+#if TRX_TIMING
+            const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
             // row tables of this wave's 8 rows in lanes 0..7 (broadcast below with constant-lane v_readlane)
             float yn_l;
             asm volatile("global_load_dword %0, %1, %2" : "=v"(yn_l) : "v"(lane7b), "s"(ytab + Y0 + j0) : "memory");
@@ -541,14 +583,21 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             }
             asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]), "+v"(yn_l));
             const float yid_l = unnorm<3>(yn_l, fH);
+#if TRX_TIMING
+            const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#if TRX_TIMING
+            const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+#endif
             float yn_r[kRows], yid_r[kRows];
 #pragma unroll
             for (int j = 0; j < kRows; j++) { yn_r[j] = lane_bcast(yn_l, j); yid_r[j] = lane_bcast(yid_l, j); }
             if (TRX_DBG_SKIP != 1) {
                 const int bpb = (int)box_lds - ((oz * kBH + oy) * kBW + ox) * 4;   // LDS byte address of voxel (0,0,0) of the volume
-#pragma unroll
-                for (int j = 0; j < kRows; j++) {
+                // software pipeline: the 4 LDS reads of row j+1 are issued before the arithmetic of row j
+                struct Fetch { f2 r00, r01, r10, r11; float fx, fy, fz; };
+                auto fetch = [&](int j) -> Fetch {
                     const float yn = yn_r[j];
                     const float ix = fmaf(sxv, yn, base_x);
                     const float iy = yid_r[j] + fmaf(syv, yn, base_y);
@@ -558,16 +607,46 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a1) : "v"(floor_to_int(iy)), "s"(ys_s), "v"(a0));
                     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a2) : "v"(floor_to_int(iz)), "s"(zs_s), "v"(a1));
                     asm("v_add_u32 %0, %1, %2" : "=v"(a3) : "s"(zs_s), "v"(a2));
-                    const f2 r00 = *(lds_f2)(unsigned)a2, r01 = *(lds_f2)(unsigned)(a2 + kBW * 4);
-                    const f2 r10 = *(lds_f2)(unsigned)a3, r11 = *(lds_f2)(unsigned)(a3 + kBW * 4);
-                    const Samp3 sm = lerp3_pairs<MODE == 0>(r00, r01, r10, r11, __builtin_amdgcn_fractf(ix), __builtin_amdgcn_fractf(iy),
-                                                            __builtin_amdgcn_fractf(iz));
+                    Fetch f;
+                    f.r00 = *(lds_f2)(unsigned)a2; f.r01 = *(lds_f2)(unsigned)(a2 + kBW * 4);
+                    f.r10 = *(lds_f2)(unsigned)a3; f.r11 = *(lds_f2)(unsigned)(a3 + kBW * 4);
+                    f.fx = __builtin_amdgcn_fractf(ix); f.fy = __builtin_amdgcn_fractf(iy); f.fz = __builtin_amdgcn_fractf(iz);
+                    return f;
+                };
+                Fetch cur = fetch(0);
+#pragma unroll
+                for (int j = 0; j < kRows; j++) {
+                    Fetch nxt;
+                    if (j + 1 < kRows) nxt = fetch(j + 1);
+#if TRX_SWP_BARRIER
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    const Samp3 sm = lerp3_pairs<MODE == 0>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
                     if constexpr (MODE == 3) { if (act) wout[(size_t)Y0 * W + (unsigned)(toff + j * W)] = sm.v; }
-                    else f1_accumulate_pk<MODE>(sm, tv[j], yn, acc);
+                    else f1_accumulate_pk<MODE>(sm, tv[j], yn_r[j], acc);
+                    if (j + 1 < kRows) cur = nxt;
                 }
             }
+#if TRX_TIMING
+            const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();   // the box is overwritten by the next tile
+#if TRX_TIMING
+            {
+                const unsigned long long tm4 = __builtin_amdgcn_s_memtime();
+                tm_acc[0] += tm1 - tm0; tm_acc[1] += tm2 - tm1; tm_acc[2] += tm3 - tm2; tm_acc[3] += tm4 - tm3;
+            }
+#endif
+          }
+          ty += nf;
+          if (nf < chunk) break;   // the generic loop takes over at tile ty (same 64-tile chunking, geometry already in g_*)
         }
+#if TRX_TIMING
+        if (tid == 0) {
+            const size_t bi = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            if (bi < 8192) for (int i = 0; i < 4; i++) trx_timing[bi * 4 + i] = tm_acc[i];
+        }
+#endif
         if (!act) {
 #pragma unroll
             for (int q = 0; q < 3; q++)
