@@ -151,8 +151,9 @@ def main():
                           "parallelism": f"{world} x independent shards, no collective"}}
         if world == 1:
             # ---- roofline leg: the fused F1 kernel alone, events on the launch stream ----------------
-            reps = 50
-            solver.accumulate_only()
+            reps = 200
+            for _ in range(50):           # the clocks settle ~40 launches after an idle gap (power management transient)
+                solver.accumulate_only()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

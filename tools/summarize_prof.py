@@ -10,9 +10,9 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 note = sys.argv[3] if len(sys.argv) > 3 else ""
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline  (MI355X; {note})",
+out = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline  (MI355X; {note})",
        "Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs"]
-rows = list(csv.DictReader(open(glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0])))
+rows = list(csv.DictReader(open(sorted(glob.glob(f"{src}/stats/*/*_kernel_stats.csv"), key=os.path.getmtime)[-1])))
 for r in rows:
     if "trx::" in r["Name"]:
         out.append(",".join([r["Name"].split("(")[0].replace(",", ";"), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]))
@@ -21,7 +21,7 @@ out.append(f"(torch kernels: synthetic-input generation and checks),,{oth:.0f},,
 res = {}
 out += ["", "# PMC passes (separate runs with --pmc only): average per dispatch", "Kernel,Counter,AvgPerDispatch,Dispatches"]
 for name in ("fetch", "write", "sq"):
-    fs = glob.glob(f"{src}/{name}/*/*_counter_collection.csv")
+    fs = sorted(glob.glob(f"{src}/{name}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1:]
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -214,12 +214,6 @@ static TileGeom tile_geom(const trx_volumes &v)
 #ifndef TRX_DBG_SKIP
 #define TRX_DBG_SKIP 0   // development ablation (tools/kbench.hip): 1 = no gather/compute, 2 = no box staging, 3 = no target loads
 #endif
-#ifndef TRX_STAGGER
-#define TRX_STAGGER 0
-#endif
-#ifndef TRX_STAGGER_MODE
-#define TRX_STAGGER_MODE 1
-#endif
 #ifndef TRX_TIMING
 #define TRX_TIMING 0      // development (tools/kbench.hip): per-block staging / gather cycle counts into trx_timing[]
 #endif
@@ -433,18 +427,6 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         g_ox = ox; g_oy = oy; g_oz = oz;
         g_pk = fits ? ((ex4 - 1) | ((ey - 1) << 8) | ((ez - 1) << 16) | (1 << 24) | ((interior ? 1 : 0) << 25)) : 0;
     };
-#if TRX_STAGGER
-    // development: phase-shift one of the two co-resident blocks of a CU ("staging / compute phases")
-    {
-        bool late;
-        if (TRX_STAGGER_MODE == 1) late = (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1) != 0;
-        else late = (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 16 << 6 | 4) & 1) != 0;   // HW_ID.TG_ID parity
-        if (late) {
-#pragma unroll
-            for (int i = 0; i < TRX_STAGGER; i += 16) __builtin_amdgcn_s_sleep(16);
-        }
-    }
-#endif
     int ty = ty_begin;
     // ================= fast loop: full 16-row tiles whose box fits =================
     // No per-lane branch around the accumulation: lanes outside a partial x / z tile work on the clamped
