@@ -47,6 +47,27 @@ def ncc_loss(y, yp, alpha=100.0):
     return (1 - ncc) * alpha
 
 
+def local_ncc_loss(y, yp, window=9, alpha=1.0, eps=1e-5):
+    """Box-window NCC (VoxelMorph-style) - the definition the HIP extension trx_lncc_loss_grad implements; the
+    reference has no local NCC (its NCCLoss, ref:src/TorchRegister/utils.py:182-205, is global), so this torch
+    composition IS the specification ("parity unpinned").  y = target, yp = warped, [B,1,*spatial]; returns the
+    mean over the batch of alpha * (1 - mean_q cc(q))."""
+    nd = y.dim() - 2
+    conv = F.conv3d if nd == 3 else F.conv2d
+    filt = torch.ones(1, 1, *([window] * nd), dtype=y.dtype, device=y.device)
+    n = float(window ** nd)
+
+    def box(x):
+        return conv(x, filt, padding=window // 2)
+
+    s_i, s_j, s_ii, s_jj, s_ij = box(y), box(yp), box(y * y), box(yp * yp), box(y * yp)
+    cross = s_ij - s_i * s_j / n
+    var_i = s_ii - s_i * s_i / n
+    var_j = s_jj - s_j * s_j / n
+    cc = cross * cross / (var_i * var_j + eps)
+    return alpha * (1 - cc.mean())
+
+
 def mse_loss(y, yp):
     return F.mse_loss(yp, y)
 

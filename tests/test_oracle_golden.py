@@ -216,3 +216,31 @@ def test_compose_trajectory_bitwise(trajectories):
     tgt = ph.blobs(tuple(g[f"{name}/shape"]), 1000 + seed)
     r = compose.affine_loop(torch.from_numpy(g[f"{name}/moving"]), tgt, lr, iters, w_ncc=1.0)
     assert np.allclose(r["losses"].numpy(), g[f"{name}/losses32"], rtol=1e-5)
+
+
+def test_local_ncc_definition_properties():
+    """The local-NCC specification (oracle/compose.py::local_ncc_loss, an extension with no reference counterpart):
+    cc = 1 for proportional intensities, invariance to the gain of the warped image (an offset is NOT invariant at the
+    border: the zero padding enters the window sums with n fixed), and agreement with an explicit loop on a tiny image."""
+    from oracle import compose
+    torch.manual_seed(3)
+    y = torch.rand(1, 1, 7, 8, 9, dtype=torch.float64)
+    assert compose.local_ncc_loss(y, 2.5 * y, eps=0.0).abs().item() < 1e-9
+    yp = torch.rand(1, 1, 7, 8, 9, dtype=torch.float64)
+    a, b = compose.local_ncc_loss(y, yp, 5, eps=0.0), compose.local_ncc_loss(y, 3.0 * yp, 5, eps=0.0)
+    assert abs(a.item() - b.item()) < 1e-9
+    # explicit loop, 2-D, window 3
+    y2, p2 = torch.rand(1, 1, 5, 6, dtype=torch.float64), torch.rand(1, 1, 5, 6, dtype=torch.float64)
+    cc = []
+    for i in range(5):
+        for j in range(6):
+            s = [0.0] * 5
+            for di in (-1, 0, 1):
+                for dj in (-1, 0, 1):
+                    ii, jj = i + di, j + dj
+                    if 0 <= ii < 5 and 0 <= jj < 6:
+                        u, v = y2[0, 0, ii, jj].item(), p2[0, 0, ii, jj].item()
+                        s = [s[0] + u, s[1] + v, s[2] + u * u, s[3] + v * v, s[4] + u * v]
+            c = s[4] - s[0] * s[1] / 9
+            cc.append(c * c / ((s[2] - s[0] ** 2 / 9) * (s[3] - s[1] ** 2 / 9) + 1e-5))
+    assert abs(compose.local_ncc_loss(y2, p2, 3).item() - (1 - sum(cc) / 30)) < 1e-12

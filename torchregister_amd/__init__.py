@@ -8,6 +8,6 @@ __version__ = "0.1.0"
 
 from ._engine import AffineSolver, FlowSolver, LossSpec, SlabFlowSolver  # noqa: F401
 from .torchregister import Register  # noqa: F401
-from .utils import (EPSILON, Attention_UNet, K_gauss, NCCLoss, NMI, NMILoss, PDF, PDF_xis, Regressor, SpatialTransformer, SSDLoss,  # noqa: F401
+from .utils import (EPSILON, Attention_UNet, K_gauss, LocalNCCLoss, NCCLoss, NMI, NMILoss, PDF, PDF_xis, Regressor, SpatialTransformer, SSDLoss,  # noqa: F401
                     Theta, attention_grid, get_pdf, norm, padNd)
 from .warpings import affine_register, flow_register, get_affine_warp, rigid_register  # noqa: F401

@@ -444,3 +444,27 @@ class SlabFlowSolver:
             if multi:
                 dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.group)   # 64 bytes per iteration
             self.apply(m)
+
+
+def local_ncc_loss_grad(target, warped, window=9, alpha=1.0, eps=1e-5, need_grad=True):
+    """Local-window NCC (extension, include/trx.h: trx_lncc_loss_grad): target / warped [B,1,*spatial] fp32 on the GPU.
+    Returns (loss [B], d loss / d warped (same shape as warped) or None)."""
+    lib = _lib.load()
+    if not (target.is_cuda and warped.is_cuda):
+        raise _lib.TrxError("local_ncc_loss_grad needs CUDA (HIP) tensors: there is no CPU fallback")
+    if target.shape != warped.shape or target.dim() not in (4, 5) or target.shape[1] != 1:
+        raise ValueError(f"expected two [B,1,*spatial] tensors of equal shape, got {tuple(target.shape)} and {tuple(warped.shape)}")
+    nd = target.dim() - 2
+    y, w = target.detach().contiguous().float(), warped.detach().contiguous().float()
+    B = y.shape[0]
+    D, H, W = (1, *y.shape[2:]) if nd == 2 else y.shape[2:]
+    loss = torch.empty(B, device=y.device)
+    grad = torch.empty_like(w) if need_grad else None
+    ws_bytes = lib.trx_lncc_workspace_bytes(nd, B, D, H, W)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=y.device)
+    with torch.cuda.device(y.device):
+        rc = lib.trx_lncc_loss_grad(_lib.ptr(y), _lib.ptr(w), nd, B, D, H, W, int(window), float(alpha), float(eps), _lib.ptr(loss),
+                                    _lib.ptr(grad), _lib.ptr(ws), ws_bytes, _lib.current_stream(y.device))
+    _lib.check(rc, "trx_lncc_loss_grad")
+    return loss, grad
+

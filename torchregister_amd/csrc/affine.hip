@@ -308,6 +308,11 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) { return __int_as
 // un-normalisation roundings (unnorm<3>), so at theta = identity the coordinates are BITWISE those of
 // the reference (every sample sits on a voxel there and the one-sided derivative depends on the last
 // bit); for any other theta this is the same affine map to within fp32 rounding, at 4 VALU ops / voxel.
+// s[100:101] (the DMA base walker of the fast loop) are outside the compiler's allocatable SGPR range on gfx950 - it warns
+// that it will not preserve them, which is exactly why they are safe to use; LDS addresses are 32-bit integers by construction.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 template <int MODE>
 __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_kernel(trx_volumes vol, const float *__restrict__ theta,
                                                                                         TileGeom tg, int channels, float *__restrict__ partials)
@@ -480,7 +485,6 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
           const unsigned long long bad = ~__builtin_amdgcn_ballot_w64(ok);
           const int nf = bad ? __builtin_ctzll(bad) : 64;
           for (int gl = 0; gl < nf; gl++) {
-            const int pk = __builtin_amdgcn_readlane(g_pk, gl);
             const int Y0 = (ty + gl) * kTY;
             const int ox = __builtin_amdgcn_readlane(g_ox, gl), oy = __builtin_amdgcn_readlane(g_oy, gl), oz = __builtin_amdgcn_readlane(g_oz, gl);
 #if TRX_TIMING
@@ -780,6 +784,8 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         }
     block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)b * tg.blocks_per_pair + blockIdx.x) * NP, box);
 }
+
+#pragma clang diagnostic pop
 
 // closed-form base coordinates for callers that pass no tables: (2i+1)/S - 1
 __global__ void fill_tables_kernel(float *__restrict__ tab, int W, int H, int D)

@@ -1,0 +1,264 @@
+// Local-window NCC (extension, SURVEY §8f.3 / north_star "NCC local-window sums"): loss and its gradient wrt the
+// warped image in two streaming kernels.  Not in the reference ("parity unpinned"): the definition is the box-window
+// NCC used by VoxelMorph-style registration, restated with torch ops in oracle/compose.py::local_ncc_loss,
+//
+//     S_X(q) = sum over the (2R+1)^nd window around q of X, zero padding outside the image, n = (2R+1)^nd
+//     c = S_IJ - S_I S_J / n,  a = S_II - S_I^2 / n,  b = S_JJ - S_J^2 / n,  cc(q) = c^2 / (a b + eps)
+//     loss = alpha * (1 - mean_q cc(q))
+//
+// and its derivative wrt J (I = target, J = warped) is again a set of box sums:
+//     dloss/dJ_p = -(alpha/N) * ( I_p box(P)_p - box(P uI)_p - J_p box(Q)_p + box(Q uJ)_p ),
+//     P = 2c/den, Q = 2 c^2 a / den^2, den = a b + eps, uI = S_I / n, uJ = S_J / n.
+//
+// Kernel 1 (lncc_fields_kernel): per voxel the 5 window sums -> cc (loss partial) and the 4 fields P, P uI, Q, Q uJ.
+// Kernel 2 (lncc_grad_kernel):   the 4 window sums of those fields, combined with I_p, J_p -> dloss/dJ.
+// Both walk a (32 x, 8 y) column of the volume along z: per plane the tile (+4 halo) goes to LDS, the x window is a
+// sliding sum over float4 reads (4 outputs per thread), the y window 2R+1 LDS reads per field, and the z window a
+// running sum over a register ring of the last 2R+1 plane sums (re-summed exactly once per ring turn, so rounding
+// does not drift along z).  Window sums are separable box filters - adds only; MFMA has nothing to contract here
+// (a banded-matrix formulation would spend 40 MACs where 9 adds do).
+// Algorithmic bytes: kernel 1 reads I, J (8) and writes 16; kernel 2 reads 16 + 8 and writes 4 -> 52 B / voxel.
+#include "trx_common.h"
+
+namespace trx {
+
+constexpr int kLX = 32, kLY = 8;            // output tile of a block in x, y
+constexpr int kLRows = kLY + 8, kLCols = kLX + 8;   // tile + halo 4 (the largest radius)
+
+// Window sums of NF fields over the x-y window for plane `zin` of the block's column -> P[NF] of thread (ox, oy).
+// fill(cell, z, gy, gx, inb) writes the NF fields of one tile cell (zeros when !inb) through cell[f * kLRows * kLCols].
+// All threads of the block must call this together.
+template <int R, int NF, typename Fill>
+__device__ __forceinline__ void plane_window_sums(int zin, int D, int H, int W, int X0, int Y0, Fill fill, float (*raw)[kLRows][kLCols],
+                                                  float (*xs)[kLX][kLRows + 1], float (&P)[NF])
+{
+    const int tid = threadIdx.x;
+    if (zin < 0 || zin >= D) {   // uniform: planes outside the volume are zero padding
+#pragma unroll
+        for (int f = 0; f < NF; f++) P[f] = 0.f;
+        return;
+    }
+    __syncthreads();   // the previous plane's LDS reads are done
+    for (int rc = tid; rc < kLRows * kLCols; rc += TRX_BLOCK) {
+        const int r = rc / kLCols, c = rc - r * kLCols;
+        const int gy = Y0 - 4 + r, gx = X0 - 4 + c;
+        const bool inb = ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+        fill(&raw[0][r][c], zin, gy, gx, inb);
+    }
+    __syncthreads();
+    // x window: thread (row, quad) produces outputs x = 4 quad .. 4 quad + 3 of its row from 12 consecutive inputs
+    if (tid < kLRows * (kLX / 4)) {
+        const int row = tid >> 3, q = tid & 7;
+        if (row >= 4 - R && row < kLY + 4 + R) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                float v[12];
+                const float4 *src = reinterpret_cast<const float4 *>(&raw[f][row][4 * q]);
+                const float4 a = src[0], b = src[1], c = src[2];
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 4 - R; k <= 4 + R; k++) s += v[k];
+                xs[f][4 * q][row] = s;
+#pragma unroll
+                for (int i = 1; i < 4; i++) {
+                    s += v[4 + R + i] - v[3 - R + i];
+                    xs[f][4 * q + i][row] = s;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int ox = tid & (kLX - 1), oy = tid >> 5;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = -R; k <= R; k++) s += xs[f][ox][oy + 4 + k];
+        P[f] = s;
+    }
+}
+
+// Walks the column along z, keeping the z window as a running sum over a register ring; emit(z, Z) is called for
+// every output plane with the full window sums Z[NF] of this thread's voxel.
+template <int R, int NF, typename Fill, typename Emit>
+__device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0, int Y0, Fill load, Emit emit, float (*raw)[kLRows][kLCols],
+                                            float (*xs)[kLX][kLRows + 1])
+{
+    if (nd == 2) {   // images: the window has no z extent
+        float P[NF];
+        plane_window_sums<R, NF>(0, 1, H, W, X0, Y0, load, raw, xs, P);
+        emit(0, P);
+        return;
+    }
+    constexpr int WN = 2 * R + 1;
+    float ring[WN][NF], Z[NF];
+#pragma unroll
+    for (int k = 0; k < WN; k++)
+#pragma unroll
+        for (int f = 0; f < NF; f++) ring[k][f] = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; f++) Z[f] = 0.f;
+    for (int base = 0; base < D + R; base += WN) {
+#pragma unroll
+        for (int k = 0; k < WN; k++) {
+            const int zin = base + k;
+            if (zin < D + R) {
+                float P[NF];
+                plane_window_sums<R, NF>(zin, D, H, W, X0, Y0, load, raw, xs, P);
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+                    if (k == 0) {   // once per ring turn: exact re-summation instead of the running update
+                        ring[0][f] = P[f];
+                        float s = 0.f;
+#pragma unroll
+                        for (int j = 0; j < WN; j++) s += ring[j][f];
+                        Z[f] = s;
+                    } else {
+                        Z[f] += P[f] - ring[k][f];
+                        ring[k][f] = P[f];
+                    }
+                }
+                if (zin - R >= 0) emit(zin - R, Z);
+            }
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(TRX_BLOCK) void lncc_fields_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
+                                                               int W, float eps, float *__restrict__ fields, float *__restrict__ partials)
+{
+    __shared__ __attribute__((aligned(16))) float raw[5][kLRows][kLCols];   // I, J, I^2, J^2, I J of the tile (+halo)
+    __shared__ float xs[5][kLX][kLRows + 1];
+    const int b = blockIdx.z, X0 = blockIdx.x * kLX, Y0 = blockIdx.y * kLY;
+    const size_t n = (size_t)D * H * W;
+    const float *__restrict__ I = tgt + (size_t)b * n, *__restrict__ J = wrp + (size_t)b * n;
+    float *__restrict__ F = fields + (size_t)b * 4 * n;
+    const int tid = threadIdx.x, x = X0 + (tid & (kLX - 1)), y = Y0 + (tid >> 5);
+    const bool live = (x < W) && (y < H);
+    const float wn = (nd == 3) ? (float)((2 * R + 1) * (2 * R + 1) * (2 * R + 1)) : (float)((2 * R + 1) * (2 * R + 1));
+    const float inv_n = 1.0f / wn;
+    float lsum = 0.f;
+    constexpr int FS = kLRows * kLCols;
+    // the 5 product fields are formed while the tile is copied to LDS: the window passes then only add
+    auto load = [&](float *cell, int z, int gy, int gx, bool inb) {
+        float i = 0.f, j = 0.f;
+        if (inb) {
+            const size_t o = ((size_t)z * H + gy) * W + gx;
+            i = I[o]; j = J[o];
+        }
+        cell[0] = i; cell[FS] = j; cell[2 * FS] = i * i; cell[3 * FS] = j * j; cell[4 * FS] = i * j;
+    };
+    auto emit = [&](int z, const float (&Z)[5]) {
+        if (!live) return;
+        const float Is = Z[0], Js = Z[1];
+        const float c = Z[4] - Is * Js * inv_n, a = Z[2] - Is * Is * inv_n, bv = Z[3] - Js * Js * inv_n;
+        const float den = a * bv + eps, rden = 1.0f / den;
+        const float Pq = 2.0f * c * rden, Qq = Pq * c * a * rden;
+        lsum += c * c * rden;
+        const size_t o = ((size_t)z * H + y) * W + x;
+        F[o] = Pq; F[n + o] = Pq * (Is * inv_n); F[2 * n + o] = Qq; F[3 * n + o] = Qq * (Js * inv_n);
+    };
+    column_walk<R, 5>(nd, D, H, W, X0, Y0, load, emit, raw, xs);
+    float v[1] = {lsum};
+    block_reduce_store<1>(v, partials + ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+}
+
+template <int R>
+__global__ __launch_bounds__(TRX_BLOCK) void lncc_grad_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
+                                                             int W, float scale, const float *__restrict__ fields, float *__restrict__ grad)
+{
+    __shared__ __attribute__((aligned(16))) float raw[4][kLRows][kLCols];
+    __shared__ float xs[4][kLX][kLRows + 1];
+    const int b = blockIdx.z, X0 = blockIdx.x * kLX, Y0 = blockIdx.y * kLY;
+    const size_t n = (size_t)D * H * W;
+    const float *__restrict__ I = tgt + (size_t)b * n, *__restrict__ J = wrp + (size_t)b * n;
+    const float *__restrict__ F = fields + (size_t)b * 4 * n;
+    float *__restrict__ G = grad + (size_t)b * n;
+    const int tid = threadIdx.x, x = X0 + (tid & (kLX - 1)), y = Y0 + (tid >> 5);
+    const bool live = (x < W) && (y < H);
+    constexpr int FS = kLRows * kLCols;
+    auto load = [&](float *cell, int z, int gy, int gx, bool inb) {
+        const size_t o = inb ? ((size_t)z * H + gy) * W + gx : 0;
+#pragma unroll
+        for (int f = 0; f < 4; f++) cell[f * FS] = inb ? F[(size_t)f * n + o] : 0.f;
+    };
+    auto emit = [&](int z, const float (&Z)[4]) {
+        if (!live) return;
+        const size_t o = ((size_t)z * H + y) * W + x;
+        G[o] = scale * (I[o] * Z[0] - Z[1] - J[o] * Z[2] + Z[3]);
+    };
+    column_walk<R, 4>(nd, D, H, W, X0, Y0, load, emit, raw, xs);
+}
+
+// loss[b] = alpha * (1 - sum(partials) / N), partials reduced in fp64 in a fixed order
+__global__ __launch_bounds__(TRX_BLOCK) void lncc_finalize_kernel(const float *__restrict__ partials, int nblk, double nvox, float alpha, float *__restrict__ loss)
+{
+    __shared__ double red[TRX_BLOCK];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < nblk; i += TRX_BLOCK) s += (double)partials[(size_t)b * nblk + i];
+    red[tid] = s;
+    __syncthreads();
+    for (int w = TRX_BLOCK / 2; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) loss[b] = (float)((double)alpha * (1.0 - red[0] / nvox));
+}
+
+template <int R>
+static int launch_lncc(const float *target, const float *warped, int nd, int B, int D, int H, int W, float alpha, float eps, float *loss, float *grad,
+                       float *fields, float *partials, hipStream_t s)
+{
+    dim3 grid((W + kLX - 1) / kLX, (H + kLY - 1) / kLY, B), block(TRX_BLOCK);
+    hipLaunchKernelGGL((lncc_fields_kernel<R>), grid, block, 0, s, target, warped, nd, D, H, W, eps, fields, partials);
+    TRX_CHECK_LAUNCH();
+    const double nvox = (double)D * H * W;
+    if (loss) {
+        hipLaunchKernelGGL(lncc_finalize_kernel, dim3(B), block, 0, s, partials, (int)(grid.x * grid.y), nvox, alpha, loss);
+        TRX_CHECK_LAUNCH();
+    }
+    if (grad) {
+        hipLaunchKernelGGL((lncc_grad_kernel<R>), grid, block, 0, s, target, warped, nd, D, H, W, (float)(-(double)alpha / nvox), fields, grad);
+        TRX_CHECK_LAUNCH();
+    }
+    return TRX_OK;
+}
+
+static size_t lncc_partials_bytes(int B, int H, int W)
+{
+    const size_t nb = (size_t)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY);
+    return ((size_t)B * nb * sizeof(float) + 255) & ~(size_t)255;
+}
+
+}  // namespace trx
+
+using namespace trx;
+
+extern "C" size_t trx_lncc_workspace_bytes(int ndim, int B, int D, int H, int W)
+{
+    if ((ndim != 2 && ndim != 3) || B < 1 || D < 1 || H < 1 || W < 1 || (ndim == 2 && D != 1)) return 0;
+    return lncc_partials_bytes(B, H, W) + (size_t)4 * B * D * H * W * sizeof(float);
+}
+
+extern "C" int trx_lncc_loss_grad(const float *target, const float *warped, int ndim, int B, int D, int H, int W, int window, float alpha,
+                                  float eps, float *loss, float *grad, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!target || !warped || !workspace || (!loss && !grad)) return TRX_ERR_ARG;
+    if ((ndim != 2 && ndim != 3) || (ndim == 2 && D != 1)) return TRX_ERR_NDIM;
+    if (B < 1 || B > 65535 || D < 1 || H < 1 || W < 1 || (double)D * H * W >= 2147483648.0) return TRX_ERR_ARG;
+    if (window != 3 && window != 5 && window != 7 && window != 9) return TRX_ERR_ARG;
+    if (workspace_bytes < trx_lncc_workspace_bytes(ndim, B, D, H, W)) return TRX_ERR_WORKSPACE;
+    float *partials = (float *)workspace;
+    float *fields = (float *)((char *)workspace + lncc_partials_bytes(B, H, W));
+    hipStream_t s = (hipStream_t)stream;
+    switch (window) {
+    case 3: return launch_lncc<1>(target, warped, ndim, B, D, H, W, alpha, eps, loss, grad, fields, partials, s);
+    case 5: return launch_lncc<2>(target, warped, ndim, B, D, H, W, alpha, eps, loss, grad, fields, partials, s);
+    case 7: return launch_lncc<3>(target, warped, ndim, B, D, H, W, alpha, eps, loss, grad, fields, partials, s);
+    default: return launch_lncc<4>(target, warped, ndim, B, D, H, W, alpha, eps, loss, grad, fields, partials, s);
+    }
+}

@@ -50,6 +50,40 @@ class NCCLoss(nn.Module):
         return (1 - self.NCC) * self.alpha
 
 
+class _LocalNCCFn(torch.autograd.Function):
+    """loss [B] = local-window NCC of (target, warped) through the HIP kernels; gradient wrt warped only."""
+
+    @staticmethod
+    def forward(ctx, y, yp, window, alpha, eps):
+        from . import _engine
+        loss, grad = _engine.local_ncc_loss_grad(y, yp, window, alpha, eps, need_grad=yp.requires_grad)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        (grad,) = ctx.saved_tensors
+        if grad is None:
+            return None, None, None, None, None
+        return None, grad * gl.view(-1, *([1] * (grad.dim() - 1))), None, None, None
+
+
+class LocalNCCLoss(nn.Module):
+    """alpha * (1 - mean of the squared local NCC over `window`^nd boxes) - the box-window NCC of VoxelMorph-style
+    registration.  EXTENSION: the reference's NCCLoss is global; this criterion exists only here (north_star,
+    SURVEY 8f.3) and is defined by oracle/compose.py::local_ncc_loss.  Runs on the GPU only (HIP kernels
+    trx_lncc_loss_grad); call order (target, warped) like every criterion of the package; batch mean."""
+
+    def __init__(self, window=9, alpha=1.0, eps=1e-5):
+        super().__init__()
+        if window not in (3, 5, 7, 9):
+            raise ValueError("window must be 3, 5, 7 or 9")
+        self.window, self.alpha, self.eps = int(window), float(alpha), float(eps)
+
+    def forward(self, y, yp):
+        return _LocalNCCFn.apply(y, yp, self.window, self.alpha, self.eps).mean()
+
+
 class SSDLoss(nn.Module):
     """alpha * sum((y - yp)^2) (ref:utils.py:208-221)."""
 
