@@ -42,7 +42,7 @@ def _pair(shape, B=1):
     return tgt, wrp + 0.02 * ph.vol(tuple(wrp.shape[2:]), 0.23, "cos")
 
 
-CASES = [((20, 18, 44), 9, 1), ((9, 33, 36), 9, 2), ((12, 40, 70), 5, 1), ((7, 7, 7), 9, 1), ((16, 16, 32), 3, 1), ((24, 40, 33), 7, 1),
+CASES = [((70, 20, 36), 9, 1), ((97, 12, 33), 5, 2), ((20, 18, 44), 9, 1), ((9, 33, 36), 9, 2), ((12, 40, 70), 5, 1), ((7, 7, 7), 9, 1), ((16, 16, 32), 3, 1), ((24, 40, 33), 7, 1),
          ((40, 52), 9, 2), ((33, 70), 5, 1), ((8, 8), 9, 1)]
 
 

@@ -37,3 +37,10 @@ rep("affine_warp 1ch (8 pairs)", timeit(lambda: eng.affine_warp(th.expand(8, 3, 
 s = tr.AffineSolver(mov, tgt, loss=tr.LossSpec(w_ncc=1.0), lr=1e-6, capacity=64)
 rep("affine step (1 pair)", timeit(lambda: s.run(1)), 8 * N)
 rep("affine loss-only (1 pair)", timeit(lambda: s.eval_loss()), 8 * N)
+# local-window NCC (extension): loss + gradient wrt the warped volume, 52 B/voxel algorithmic
+wrp = eng.affine_warp(torch.eye(3, 4, device=dev)[None], mov)
+for win in (9, 5):
+    rep(f"local NCC w={win} loss+grad (1 pair)", timeit(lambda: eng.local_ncc_loss_grad(tgt, wrp, win)), 52 * N)
+rep("local NCC w=9 loss only (1 pair)", timeit(lambda: eng.local_ncc_loss_grad(tgt, wrp, 9, need_grad=False)), 24 * N)
+tgt8, wrp8 = tgt.expand(8, 1, *shape).contiguous(), wrp.expand(8, 1, *shape).contiguous()
+rep("local NCC w=9 loss+grad (8 pairs)", timeit(lambda: eng.local_ncc_loss_grad(tgt8, wrp8, 9), 5), 52 * N * 8)

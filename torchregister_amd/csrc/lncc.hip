@@ -83,9 +83,9 @@ __device__ __forceinline__ void plane_window_sums(int zin, int D, int H, int W, 
 // Walks the column along z, keeping the z window as a running sum over a register ring; emit(z, Z) is called for
 // every output plane with the full window sums Z[NF] of this thread's voxel.
 template <int R, int NF, typename Fill, typename Emit>
-__device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0, int Y0, Fill load, Emit emit, float (*raw)[kLRows][kLCols],
-                                            float (*xs)[kLX][kLRows + 1])
-{
+__device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0, int Y0, int z0, int z1, Fill load, Emit emit,
+                                            float (*raw)[kLRows][kLCols], float (*xs)[kLX][kLRows + 1])
+{   // output planes [z0, z1) of the column (a z segment: small batches split columns so that the chip is filled)
     if (nd == 2) {   // images: the window has no z extent
         float P[NF];
         plane_window_sums<R, NF>(0, 1, H, W, X0, Y0, load, raw, xs, P);
@@ -100,11 +100,11 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
         for (int f = 0; f < NF; f++) ring[k][f] = 0.f;
 #pragma unroll
     for (int f = 0; f < NF; f++) Z[f] = 0.f;
-    for (int base = 0; base < D + R; base += WN) {
+    for (int base = z0 - R; base < z1 + R; base += WN) {
 #pragma unroll
         for (int k = 0; k < WN; k++) {
             const int zin = base + k;
-            if (zin < D + R) {
+            if (zin < z1 + R) {
                 float P[NF];
                 plane_window_sums<R, NF>(zin, D, H, W, X0, Y0, load, raw, xs, P);
 #pragma unroll
@@ -120,7 +120,7 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
                         ring[k][f] = P[f];
                     }
                 }
-                if (zin - R >= 0) emit(zin - R, Z);
+                if (zin - R >= z0) emit(zin - R, Z);
             }
         }
     }
@@ -128,11 +128,12 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
 
 template <int R>
 __global__ __launch_bounds__(TRX_BLOCK) void lncc_fields_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
-                                                               int W, float eps, float *__restrict__ fields, float *__restrict__ partials)
+                                                               int W, int zsplit, float eps, float *__restrict__ fields, float *__restrict__ partials)
 {
     __shared__ __attribute__((aligned(16))) float raw[5][kLRows][kLCols];   // I, J, I^2, J^2, I J of the tile (+halo)
     __shared__ float xs[5][kLX][kLRows + 1];
-    const int b = blockIdx.z, X0 = blockIdx.x * kLX, Y0 = blockIdx.y * kLY;
+    const int b = blockIdx.z / zsplit, seg = blockIdx.z - b * zsplit, X0 = blockIdx.x * kLX, Y0 = blockIdx.y * kLY;
+    const int zlen = (D + zsplit - 1) / zsplit, z0 = seg * zlen, z1 = min(D, z0 + zlen);
     const size_t n = (size_t)D * H * W;
     const float *__restrict__ I = tgt + (size_t)b * n, *__restrict__ J = wrp + (size_t)b * n;
     float *__restrict__ F = fields + (size_t)b * 4 * n;
@@ -161,18 +162,19 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_fields_kernel(const float *__r
         const size_t o = ((size_t)z * H + y) * W + x;
         F[o] = Pq; F[n + o] = Pq * (Is * inv_n); F[2 * n + o] = Qq; F[3 * n + o] = Qq * (Js * inv_n);
     };
-    column_walk<R, 5>(nd, D, H, W, X0, Y0, load, emit, raw, xs);
+    column_walk<R, 5>(nd, D, H, W, X0, Y0, z0, z1, load, emit, raw, xs);
     float v[1] = {lsum};
-    block_reduce_store<1>(v, partials + ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    block_reduce_store<1>(v, partials + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 template <int R>
 __global__ __launch_bounds__(TRX_BLOCK) void lncc_grad_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
-                                                             int W, float scale, const float *__restrict__ fields, float *__restrict__ grad)
+                                                             int W, int zsplit, float scale, const float *__restrict__ fields, float *__restrict__ grad)
 {
     __shared__ __attribute__((aligned(16))) float raw[4][kLRows][kLCols];
     __shared__ float xs[4][kLX][kLRows + 1];
-    const int b = blockIdx.z, X0 = blockIdx.x * kLX, Y0 = blockIdx.y * kLY;
+    const int b = blockIdx.z / zsplit, seg = blockIdx.z - b * zsplit, X0 = blockIdx.x * kLX, Y0 = blockIdx.y * kLY;
+    const int zlen = (D + zsplit - 1) / zsplit, z0 = seg * zlen, z1 = min(D, z0 + zlen);
     const size_t n = (size_t)D * H * W;
     const float *__restrict__ I = tgt + (size_t)b * n, *__restrict__ J = wrp + (size_t)b * n;
     const float *__restrict__ F = fields + (size_t)b * 4 * n;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_grad_kernel(const float *__res
         const size_t o = ((size_t)z * H + y) * W + x;
         G[o] = scale * (I[o] * Z[0] - Z[1] - J[o] * Z[2] + Z[3]);
     };
-    column_walk<R, 4>(nd, D, H, W, X0, Y0, load, emit, raw, xs);
+    column_walk<R, 4>(nd, D, H, W, X0, Y0, z0, z1, load, emit, raw, xs);
 }
 
 // loss[b] = alpha * (1 - sum(partials) / N), partials reduced in fp64 in a fixed order
@@ -209,28 +211,39 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_finalize_kernel(const float *_
     if (tid == 0) loss[b] = (float)((double)alpha * (1.0 - red[0] / nvox));
 }
 
+// z segments per column: enough blocks for >= ~4 per CU, each segment at least 32 planes deep (it re-reads 2R halo planes)
+static int lncc_zsplit(int nd, int B, int D, int H, int W)
+{
+    if (nd == 2) return 1;
+    const long cols = (long)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * B;
+    long z = (1024 + cols - 1) / cols;
+    if (z > D / 32) z = D / 32;
+    return (int)(z < 1 ? 1 : z);
+}
+
 template <int R>
 static int launch_lncc(const float *target, const float *warped, int nd, int B, int D, int H, int W, float alpha, float eps, float *loss, float *grad,
                        float *fields, float *partials, hipStream_t s)
 {
-    dim3 grid((W + kLX - 1) / kLX, (H + kLY - 1) / kLY, B), block(TRX_BLOCK);
-    hipLaunchKernelGGL((lncc_fields_kernel<R>), grid, block, 0, s, target, warped, nd, D, H, W, eps, fields, partials);
+    const int zsplit = lncc_zsplit(nd, B, D, H, W);
+    dim3 grid((W + kLX - 1) / kLX, (H + kLY - 1) / kLY, B * zsplit), block(TRX_BLOCK);
+    hipLaunchKernelGGL((lncc_fields_kernel<R>), grid, block, 0, s, target, warped, nd, D, H, W, zsplit, eps, fields, partials);
     TRX_CHECK_LAUNCH();
     const double nvox = (double)D * H * W;
     if (loss) {
-        hipLaunchKernelGGL(lncc_finalize_kernel, dim3(B), block, 0, s, partials, (int)(grid.x * grid.y), nvox, alpha, loss);
+        hipLaunchKernelGGL(lncc_finalize_kernel, dim3(B), block, 0, s, partials, (int)(grid.x * grid.y) * zsplit, nvox, alpha, loss);
         TRX_CHECK_LAUNCH();
     }
     if (grad) {
-        hipLaunchKernelGGL((lncc_grad_kernel<R>), grid, block, 0, s, target, warped, nd, D, H, W, (float)(-(double)alpha / nvox), fields, grad);
+        hipLaunchKernelGGL((lncc_grad_kernel<R>), grid, block, 0, s, target, warped, nd, D, H, W, zsplit, (float)(-(double)alpha / nvox), fields, grad);
         TRX_CHECK_LAUNCH();
     }
     return TRX_OK;
 }
 
-static size_t lncc_partials_bytes(int B, int H, int W)
+static size_t lncc_partials_bytes(int nd, int B, int D, int H, int W)
 {
-    const size_t nb = (size_t)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY);
+    const size_t nb = (size_t)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * lncc_zsplit(nd, B, D, H, W);
     return ((size_t)B * nb * sizeof(float) + 255) & ~(size_t)255;
 }
 
@@ -241,7 +254,7 @@ using namespace trx;
 extern "C" size_t trx_lncc_workspace_bytes(int ndim, int B, int D, int H, int W)
 {
     if ((ndim != 2 && ndim != 3) || B < 1 || D < 1 || H < 1 || W < 1 || (ndim == 2 && D != 1)) return 0;
-    return lncc_partials_bytes(B, H, W) + (size_t)4 * B * D * H * W * sizeof(float);
+    return lncc_partials_bytes(ndim, B, D, H, W) + (size_t)4 * B * D * H * W * sizeof(float);
 }
 
 extern "C" int trx_lncc_loss_grad(const float *target, const float *warped, int ndim, int B, int D, int H, int W, int window, float alpha,
@@ -253,7 +266,7 @@ extern "C" int trx_lncc_loss_grad(const float *target, const float *warped, int 
     if (window != 3 && window != 5 && window != 7 && window != 9) return TRX_ERR_ARG;
     if (workspace_bytes < trx_lncc_workspace_bytes(ndim, B, D, H, W)) return TRX_ERR_WORKSPACE;
     float *partials = (float *)workspace;
-    float *fields = (float *)((char *)workspace + lncc_partials_bytes(B, H, W));
+    float *fields = (float *)((char *)workspace + lncc_partials_bytes(ndim, B, D, H, W));
     hipStream_t s = (hipStream_t)stream;
     switch (window) {
     case 3: return launch_lncc<1>(target, warped, ndim, B, D, H, W, alpha, eps, loss, grad, fields, partials, s);
