@@ -41,9 +41,19 @@ def _require_gpu(t, name):
         raise TypeError(f"{name} must be float32, got {t.dtype}")
 
 
+_TABLES = {}
+
+
 def base_tables(spatial, device):
-    """affine_grid's base coordinates, built with ATen's own CPU expression (bit-exact), on device."""
-    return [(torch.linspace(-1, 1, int(s), dtype=torch.float32) * (int(s) - 1) / int(s)).to(device) for s in spatial]
+    """affine_grid's base coordinates, built with ATen's own CPU expression (bit-exact), on device.  Cached per
+    (size, device): the tables are read-only and every warp / solver of that size shares them (no H2D copy per call)."""
+    out = []
+    for s in spatial:
+        key = (int(s), str(device))
+        if key not in _TABLES:
+            _TABLES[key] = (torch.linspace(-1, 1, int(s), dtype=torch.float32) * (int(s) - 1) / int(s)).to(device)
+        out.append(_TABLES[key])
+    return out
 
 
 class _Batch:

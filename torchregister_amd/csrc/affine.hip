@@ -753,19 +753,52 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             }
             __syncthreads();   // the box is overwritten by the next tile
         } else if (act) {
-            // large deformation (or W % 4 != 0): gather straight from global memory
-#pragma unroll 1
-            for (int j = j0; j < min(j0 + kRows, ny); j++) {
-                const float yn = ytab[Y0 + j];
-                const float ix = fmaf(sx, yn, base_x);
-                const float iy = unnorm<3>(yn, fH) + fmaf(sy, yn, base_y);
-                const float iz = fmaf(sz, yn, base_z);
-                const Samp3 sm = sample3(mov, D, H, W, ix, iy, iz);
-                if constexpr (MODE == 3) {
-                    wout[(size_t)Y0 * W + (unsigned)(toff + (j - j0) * W)] = sm.v;
+            // large deformation (or W % 4 != 0): gather straight from global memory (L2), two rows in flight:
+            // the 4 pair loads + the target of row j+1 are issued before the arithmetic of row j
+            struct GFetch { f2 r00, r01, r10, r11; float fx, fy, fz, yn, yv; };
+            auto gfetch = [&](int j) -> GFetch {
+                GFetch g;
+                g.yn = ytab[Y0 + j];
+                const float ix = fmaf(sx, g.yn, base_x);
+                const float iy = unnorm<3>(g.yn, fH) + fmaf(sy, g.yn, base_y);
+                const float iz = fmaf(sz, g.yn, base_z);
+                const float flx = floorf(ix), fly = floorf(iy), flz = floorf(iz);
+                g.fx = ix - flx; g.fy = iy - fly; g.fz = iz - flz;
+                const int x0 = (int)flx, y0 = (int)fly, z0 = (int)flz;
+                const bool interior = ((unsigned)x0 < (unsigned)(W - 1)) & ((unsigned)y0 < (unsigned)(H - 1)) & ((unsigned)z0 < (unsigned)(D - 1));
+                if (__all(interior)) {
+                    const float *p = mov + ((size_t)z0 * H + y0) * W + x0, *q = p + (size_t)H * W;
+                    g.r00 = *reinterpret_cast<const f2u *>(p); g.r01 = *reinterpret_cast<const f2u *>(p + W);
+                    g.r10 = *reinterpret_cast<const f2u *>(q); g.r11 = *reinterpret_cast<const f2u *>(q + W);
                 } else {
-                    const float yv = trow[(unsigned)(toff + (j - j0) * W)];
-                    f1_accumulate_pk<MODE>(sm, yv, yn, acc);
+                    const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+                    const bool bx0 = (unsigned)x0 < (unsigned)W, bx1 = (unsigned)x1 < (unsigned)W;
+                    const bool by0 = (unsigned)y0 < (unsigned)H, by1 = (unsigned)y1 < (unsigned)H;
+                    const bool bz0 = (unsigned)z0 < (unsigned)D, bz1 = (unsigned)z1 < (unsigned)D;
+                    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+                    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+                    const int cz0 = min(max(z0, 0), D - 1), cz1 = min(max(z1, 0), D - 1);
+                    const float *a00 = mov + ((size_t)cz0 * H + cy0) * W, *a01 = mov + ((size_t)cz0 * H + cy1) * W;
+                    const float *a10 = mov + ((size_t)cz1 * H + cy0) * W, *a11 = mov + ((size_t)cz1 * H + cy1) * W;
+                    g.r00 = f2{(bz0 & by0 & bx0) ? a00[cx0] : 0.f, (bz0 & by0 & bx1) ? a00[cx1] : 0.f};
+                    g.r01 = f2{(bz0 & by1 & bx0) ? a01[cx0] : 0.f, (bz0 & by1 & bx1) ? a01[cx1] : 0.f};
+                    g.r10 = f2{(bz1 & by0 & bx0) ? a10[cx0] : 0.f, (bz1 & by0 & bx1) ? a10[cx1] : 0.f};
+                    g.r11 = f2{(bz1 & by1 & bx0) ? a11[cx0] : 0.f, (bz1 & by1 & bx1) ? a11[cx1] : 0.f};
+                }
+                g.yv = (MODE == 3) ? 0.f : trow[(unsigned)(toff + (j - j0) * W)];
+                return g;
+            };
+            const int jend = min(j0 + kRows, ny);
+            if (j0 < jend) {
+                GFetch cur = gfetch(j0);
+#pragma unroll 1
+                for (int j = j0; j < jend; j++) {
+                    GFetch nxt = cur;
+                    if (j + 1 < jend) nxt = gfetch(j + 1);
+                    const Samp3 sm = lerp3_pairs<MODE == 0>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
+                    if constexpr (MODE == 3) wout[(size_t)Y0 * W + (unsigned)(toff + (j - j0) * W)] = sm.v;
+                    else f1_accumulate_pk<MODE>(sm, cur.yv, cur.yn, acc);
+                    cur = nxt;
                 }
             }
         }
