@@ -68,7 +68,8 @@ int main(int argc, char **argv)
 {
     int B = argc > 1 ? atoi(argv[1]) : 8, S = argc > 2 ? atoi(argv[2]) : 256;
     int tb = argc > 3 ? atoi(argv[3]) : trx::kTargetBlocks;
-    size_t nvox = (size_t)S * S * S, n = nvox * B;
+    const int Wx = argc > 4 ? atoi(argv[4]) : S;   // optional row length (volume S x S x Wx) to probe pitch effects
+    size_t nvox = (size_t)S * S * Wx, n = nvox * B;
     std::vector<float> h(n);
     srand(1);
     for (size_t i = 0; i < n; i++) h[i] = (float)rand() / RAND_MAX;
@@ -83,12 +84,12 @@ int main(int argc, char **argv)
     CK(hipMalloc(&theta, B * 12 * 4));
     CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
     float *tab;
-    CK(hipMalloc(&tab, 3 * S * 4));
-    hipLaunchKernelGGL(trx::fill_tables_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, tab, S, S, S);
-    trx_volumes vol = {mov, tgt, nvox, nvox, 3, B, S, S, S, tab, tab + S, tab + 2 * S};
+    CK(hipMalloc(&tab, (2 * S + Wx) * 4));
+    hipLaunchKernelGGL(trx::fill_tables_kernel, dim3((std::max(S, Wx) + 255) / 256), dim3(256), 0, 0, tab, Wx, S, S);
+    trx_volumes vol = {mov, tgt, nvox, nvox, 3, B, S, S, Wx, tab, tab + Wx, tab + Wx + S};
     trx::AffineGeom g = trx::affine_geom(vol, tb);
     CK(hipMalloc(&partials, (size_t)B * g.nblk * 41 * 4 + 4096));
-    printf("B=%d S=%d geom TX=%d TY=%d RPT=%d nblk=%d\n", B, S, g.TX, g.TY, g.RPT, g.nblk);
+    printf("B=%d S=%d W=%d geom TX=%d TY=%d RPT=%d nblk=%d\n", B, S, Wx, g.TX, g.TY, g.RPT, g.nblk);
     dim3 grid(g.nblk, B), block(256);
     const double alg = 8.0 * nvox;  // bytes per pair-iteration
     auto rep = [&](const char *name, float us) {

@@ -179,16 +179,31 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
 // Blocks are persistent over a contiguous run of tiles of ONE pair and keep the 41 partial sums
 // in registers; thread (x, z) is fixed inside a tile so the xn / zn columns fold once per tile.
 // ------------------------------------------------------------------------------------------
-constexpr int kTX = 32, kTY = 16, kTZ = 8;         // output tile
-// LDS box (floats), kBW % 4 == 0.  One LDS-DMA piece (one global_load_lds_dwordx4 per wave) covers TWO z planes of the
-// box: 2 * kBH * kBW4 = 506 float4 slots for the 512 threads, so piece k of a thread is its piece-0 slot shifted by
-// 2k planes - one VGPR offset + one packed slot id per thread instead of one per piece.
-constexpr int kBW = 44, kBH = 23, kBD = 14;
+#ifndef TRX_TILE_CFG
+#define TRX_TILE_CFG 0
+#endif
+// Two geometries of the tile kernel:
+//  cfg 0: 512-thread blocks, tile 32 x 16 y 8 z, ONE 56.7 KB box, 2 blocks per CU (staging of one block overlaps the gather
+//         of the other), 7 DMA pieces of two box planes each;
+//  cfg 1: 1024-thread blocks, tile 32 x 16 y 16 z, TWO 81.3 KB boxes (all 160 KB of a CU's LDS), 1 block per CU: the DMA
+//         of tile t+1 runs during the gather of tile t inside the block, one barrier per tile, and the deeper tile cuts the
+//         z-halo share of the bytes a CU ingests from 13/8 to 21/16; 6 DMA pieces of four box planes each.
+// LDS box (floats), kBW % 4 == 0.  One LDS-DMA piece (one global_load_lds_dwordx4 per wave) covers kPP z planes of the
+// box - at most one float4 slot per thread - so piece k of a thread is its piece-0 slot shifted by k * kPP planes: one VGPR
+// offset + one packed slot id per thread instead of one per piece.
+#if TRX_TILE_CFG == 0
+constexpr int kTX = 32, kTY = 16, kTZ = 8;
+constexpr int kBW = 44, kBH = 23, kBD = 14, kPP = 2, kBufs = 1;
+#else
+constexpr int kTX = 32, kTY = 16, kTZ = 16;
+constexpr int kBW = 44, kBH = 22, kBD = 21, kPP = 4, kBufs = 2;
+#endif
 constexpr int kBW4 = kBW / 4;
-constexpr int kPlaneSlots = kBH * kBW4;              // 253 float4 per box plane
-constexpr int kPieces = kBD / 2;                     // 7 DMA pieces per tile
-constexpr int kPieceFloats = 2 * kBH * kBW;          // 2024 floats of LDS per piece
-static_assert(kBD % 2 == 0 && 2 * kPlaneSlots <= kTX * kTZ * 2, "one DMA piece = two box planes, one slot per thread");
+constexpr int kPlaneSlots = kBH * kBW4;              // float4 slots per box plane
+constexpr int kPieces = (kBD + kPP - 1) / kPP;       // DMA pieces per tile
+constexpr int kPieceFloats = kPP * kBH * kBW;        // floats of LDS per piece
+constexpr int kBoxFloats = kBW * kBH * kBD;          // one box; lanes of the last piece past it are always masked
+static_assert(kPP * kPlaneSlots <= kTX * kTZ * 2, "one DMA piece: at most one slot per thread");
 
 struct TileGeom {
     int ntx, nty, ntz, ntiles, blocks_per_pair, ysplit, tiles_per_seg;
@@ -223,6 +238,9 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #ifndef TRX_SWP_BARRIER
 #define TRX_SWP_BARRIER 0
 #endif
+#ifndef TRX_DMA_SPREAD
+#define TRX_DMA_SPREAD 1   // cfg 1: issue the next tile's DMA pieces between the rows of the gather (0: all at once before it)
+#endif
 #ifndef TRX_STAGE_PRIO
 #define TRX_STAGE_PRIO 3
 #endif
@@ -254,12 +272,11 @@ __device__ __forceinline__ void f1_accumulate_pk(const Samp3 &sm, float yv, floa
     }
 }
 
-constexpr int kTileThreads = kTX * kTZ * 2;             // (32 x) x (kTZ z) x (2 halves of 8 rows): 512 or 256 threads
+constexpr int kTileThreads = kTX * kTZ * 2;             // (32 x) x (kTZ z) x (2 halves of 8 rows): 512 or 1024 threads
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kRows = kTY / 2;                           // rows per thread
 constexpr int kReduceScratch = kTileWaves * 16 * 65 + kTileWaves * 16;   // floats block_reduce_store_nw needs (aliases the box)
-// the 6 lanes past slot 505 of a piece are always masked, so the last piece needs no tail
-constexpr int kBoxAlloc = (kPieces * kPieceFloats > kReduceScratch) ? kPieces * kPieceFloats : kReduceScratch;   // 56.7 KB
+constexpr int kBoxAlloc = (kBufs * kBoxFloats > kReduceScratch) ? kBufs * kBoxFloats : kReduceScratch;   // 56.7 KB / 162.6 KB
 
 template <int NV, int NW>
 __device__ __forceinline__ void block_reduce_store_nw(const float (&vals)[NV], float *__restrict__ out, float *smem)
@@ -384,18 +401,20 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     const float corner_y = uni(hH * fmaf(t10, cxn, fmaf(t12, czn, t13)));
     const float corner_z = uni(unnorm<3>(czn, fD) + hD * fmaf(t20, cxn, fmaf(t22 - 1.0f, czn, t23)));
 
-    // LDS-DMA slot of a thread in piece 0 (tile independent): box float4 (pz, dy, dx4), pz = 0 / 1.
+    // LDS-DMA slot of a thread in piece 0 (tile independent): box float4 (pz, dy, dx4), pz = 0 .. kPP-1.
     // rb0 = its byte offset from the box origin voxel inside the volume, d0 = packed (dz << 16 | dy << 8 | dx4).
-    // Piece k: d = d0 + (2k << 16), byte offset rb0 + k * (2 H W 4).  The 6 spare lanes get dz = 100 (never needed).
+    // Piece k: d = d0 + (kPP k << 16), byte offset rb0 + k * (kPP H W 4).  Spare lanes get dz = 100 (never needed).
     auto slot_geom = [&](int ln, unsigned &rb0, int &d0) {
         const int q = wave * 64 + ln;
-        const int pz = (q >= kPlaneSlots) ? 1 : 0, r = q - pz * kPlaneSlots;
+        const int pz = q / kPlaneSlots, r = q - pz * kPlaneSlots;
         const int dy = r / kBW4, dx4 = r - dy * kBW4;
-        const bool valid = q < 2 * kPlaneSlots;
+        const bool valid = q < kPP * kPlaneSlots;
         rb0 = valid ? (unsigned)((pz * H + dy) * W + dx4 * 4) * 4u : 0u;
         d0 = valid ? ((pz << 16) | (dy << 8) | dx4) : (100 << 16);
     };
-    const unsigned piece_stride = (unsigned)(2 * H * W) * 4u;   // bytes between the pieces of one thread inside the volume
+    const unsigned piece_stride = (unsigned)(kPP * H * W) * 4u;   // bytes between the pieces of one thread inside the volume
+    constexpr int kDShift = (kPP == 2) ? 17 : 18;                  // d of piece k = d0 + (k << kDShift)
+    static_assert(kPP == 2 || kPP == 4, "piece planes");
 
     F1Acc acc;
 #pragma unroll
@@ -484,145 +503,231 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
           const bool ok = (lane < chunk) && ((g_pk >> 24) & 1) && ((ty + lane + 1) * kTY <= H);
           const unsigned long long bad = ~__builtin_amdgcn_ballot_w64(ok);
           const int nf = bad ? __builtin_ctzll(bad) : 64;
-          for (int gl = 0; gl < nf; gl++) {
-            const int Y0 = (ty + gl) * kTY;
-            const int ox = __builtin_amdgcn_readlane(g_ox, gl), oy = __builtin_amdgcn_readlane(g_oy, gl), oz = __builtin_amdgcn_readlane(g_oz, gl);
-#if TRX_TIMING
-            const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
-#endif
-            // row tables of this wave's 8 rows in lanes 0..7 (broadcast below with constant-lane v_readlane)
-            float yn_l;
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(yn_l) : "v"(lane7b), "s"(ytab + Y0 + j0) : "memory");
-            __builtin_amdgcn_s_setprio(TRX_STAGE_PRIO);
-            float tv[kRows];
-            const float *trow = tgt + (size_t)Y0 * W;   // uniform (toffb holds the row offset of this half)
+          // ---- box of fast tile `g` of this chunk -> LDS buffer `buf`: refresh the cached exec masks if the tile's slot
+          // range changed, issue the DMA pieces (no wait), zero-fill needed cells that lie outside the volume.
+          const char *dma_base = nullptr;   // of the box prepared last by issue_box (for piece-wise issue)
+          unsigned dma_lds = 0;
+          auto issue_box = [&](int g, int buf, bool spread) {
+              const int ox = __builtin_amdgcn_readlane(g_ox, g), oy = __builtin_amdgcn_readlane(g_oy, g), oz = __builtin_amdgcn_readlane(g_oz, g);
+              const int lim = lim_blk;         // (ez-1) << 16 | (ey-1) << 8 | (ex4-1)
+              const int loz = max(0, -oz), loy = max(0, -oy), lox = max(0, -(ox >> 2));
+              const int hiz = min(lim >> 16, D - 1 - oz), hiy = min((lim >> 8) & 0xff, H - 1 - oy), hix = min(lim & 0xff, ((W - ox) >> 2) - 1);
+              const bool none = (hiz < loz) || (hiy < loy) || (hix < lox);   // the whole pre-image lies outside the volume
+              const int lo = none ? 0x7f7f7f : ((loz << 16) | (loy << 8) | lox);
+              const int hi = none ? 0 : ((hiz << 16) | (hiy << 8) | hix);
+              if (lim != m_lim || lo != m_lo || hi != m_hi) {
+                  m_lim = lim; m_lo = lo; m_hi = hi;
+                  m_oob = 0;
+                  int ln = lane;   // opaque copy: keeps the slot decode inside this (rarely taken) branch
+                  asm volatile("" : "+v"(ln));
+                  unsigned rbx;
+                  int d0;
+                  slot_geom(ln, rbx, d0);
 #pragma unroll
-            for (int j = 0; j < kRows; j++) {
-                if (TRX_DBG_SKIP == 3 || MODE == 3) tv[j] = 1.f;
-                else asm volatile("global_load_dword %0, %1, %2" : "=v"(tv[j]) : "v"(toffb), "s"(trow + (size_t)j * W) : "memory");
-            }
-            // ---- box -> LDS.  Which float4 slots of this thread are fetched (needed by the tile AND inside the
-            // volume) is cached as one exec mask per DMA piece, keyed on the packed per-axis slot range [lo, hi];
-            // the key only changes where the column's pre-image crosses a volume face or the extent changes.
-            {
-                const int lim = lim_blk;         // (ez-1) << 16 | (ey-1) << 8 | (ex4-1)
-                const int loz = max(0, -oz), loy = max(0, -oy), lox = max(0, -(ox >> 2));
-                const int hiz = min(lim >> 16, D - 1 - oz), hiy = min((lim >> 8) & 0xff, H - 1 - oy), hix = min(lim & 0xff, ((W - ox) >> 2) - 1);
-                const bool none = (hiz < loz) || (hiy < loy) || (hix < lox);   // the whole pre-image lies outside the volume
-                const int lo = none ? 0x7f7f7f : ((loz << 16) | (loy << 8) | lox);
-                const int hi = none ? 0 : ((hiz << 16) | (hiy << 8) | hix);
-                if (lim != m_lim || lo != m_lo || hi != m_hi) {
-                    m_lim = lim; m_lo = lo; m_hi = hi;
-                    m_oob = 0;
-                    int ln = lane;   // opaque copy: keeps the slot decode inside this (rarely taken) branch
-                    asm volatile("" : "+v"(ln));
-                    unsigned rbx;
-                    int d0;
-                    slot_geom(ln, rbx, d0);
-#pragma unroll
-                    for (int k = 0; k < kPieces; k++) {   // per-field compares on the packed (dz, dy, dx4): no field may borrow
-                        const int d = d0 + (k << 17);
-                        const bool need = (((lim - d) & 0x80808080) == 0);
-                        const bool ld = need && (((hi - d) & 0x80808080) == 0) && (((d - lo) & 0x80808080) == 0);
-                        m_ld[k] = __builtin_amdgcn_ballot_w64(ld);
-                        if (need && !ld) m_oob |= 1u << k;
-                    }
-                }
-                if (TRX_DBG_SKIP != 2) {
-                    const float *mbase = mov + (ptrdiff_t)((oz * H + oy) * W + ox);   // uniform; may point below `mov` (those lanes are masked)
-                    unsigned long long sv;
-                    unsigned m0s;
-                    static_assert(kPieces == 7, "the DMA block below is written for 7 pieces");
-                    // one exec mask + one SGPR-base load per piece; s[100:101] walks the volume by two planes per piece
+                  for (int k = 0; k < kPieces; k++) {   // per-field compares on the packed (dz, dy, dx4): no field may borrow
+                      const int d = d0 + (k << kDShift);
+                      const bool need = (((lim - d) & 0x80808080) == 0);
+                      const bool ld = need && (((hi - d) & 0x80808080) == 0) && (((d - lo) & 0x80808080) == 0);
+                      m_ld[k] = __builtin_amdgcn_ballot_w64(ld);
+                      if (need && !ld) m_oob |= 1u << k;
+                  }
+              }
+              dma_base = reinterpret_cast<const char *>(mov + (ptrdiff_t)((oz * H + oy) * W + ox));   // uniform; may point below `mov` (those lanes are masked)
+              dma_lds = box_lds + (unsigned)buf * (kBoxFloats * 4u) + (unsigned)wave * 1024u;
+              if (TRX_DBG_SKIP != 2 && !spread) {
+                  const float *mbase = reinterpret_cast<const float *>(dma_base);
+                  const unsigned lds0 = dma_lds;
+                  unsigned long long sv;
+                  unsigned m0s;
+                  static_assert(kPieces == 6 || kPieces == 7, "the DMA block below is written for 6 or 7 pieces");
+                  // one exec mask + one SGPR-base load per piece; s[100:101] walks the volume by kPP planes per piece
 #define TRX_DMA_NEXT(K)                                  \
     "s_add_u32 s100, s100, %[vstr]\n\t"                  \
     "s_addc_u32 s101, s101, 0\n\t"                       \
     "s_add_u32 m0, m0, %[pstr]\n\t"                      \
     "s_mov_b64 exec, %[k" #K "]\n\t"                     \
     "global_load_lds_dwordx4 %[off], s[100:101]\n\t"
-                    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                                 "s_mov_b32 %[m0s], m0\n\t"
-                                 "s_mov_b64 s[100:101], %[base]\n\t"
-                                 "s_mov_b32 m0, %[lds]\n\t"
-                                 "s_mov_b64 exec, %[k0]\n\t"
-                                 "global_load_lds_dwordx4 %[off], s[100:101]\n\t"
-                                 TRX_DMA_NEXT(1) TRX_DMA_NEXT(2) TRX_DMA_NEXT(3) TRX_DMA_NEXT(4) TRX_DMA_NEXT(5) TRX_DMA_NEXT(6)
-                                 "s_mov_b64 exec, %[sv]\n\t"
-                                 "s_mov_b32 m0, %[m0s]"
-                                 : [sv] "=&s"(sv), [m0s] "=&s"(m0s)
-                                 : [lds] "s"(box_lds + (unsigned)wave * 1024u), [base] "s"(mbase), [pstr] "i"(kPieceFloats * 4),
-                                   [vstr] "s"(piece_stride), [off] "v"(rb0), [k0] "s"(m_ld[0]), [k1] "s"(m_ld[1]), [k2] "s"(m_ld[2]),
-                                   [k3] "s"(m_ld[3]), [k4] "s"(m_ld[4]), [k5] "s"(m_ld[5]), [k6] "s"(m_ld[6])
-                                 : "memory", "scc", "s100", "s101");
+#define TRX_DMA_HEAD                                     \
+    "s_mov_b64 %[sv], exec\n\t"                          \
+    "s_mov_b32 %[m0s], m0\n\t"                           \
+    "s_mov_b64 s[100:101], %[base]\n\t"                  \
+    "s_mov_b32 m0, %[lds]\n\t"                           \
+    "s_mov_b64 exec, %[k0]\n\t"                          \
+    "global_load_lds_dwordx4 %[off], s[100:101]\n\t"     \
+    TRX_DMA_NEXT(1) TRX_DMA_NEXT(2) TRX_DMA_NEXT(3) TRX_DMA_NEXT(4) TRX_DMA_NEXT(5)
+#define TRX_DMA_TAIL "s_mov_b64 exec, %[sv]\n\t" "s_mov_b32 m0, %[m0s]"
+                  if constexpr (kPieces == 7) {
+                      asm volatile(TRX_DMA_HEAD TRX_DMA_NEXT(6) TRX_DMA_TAIL
+                                   : [sv] "=&s"(sv), [m0s] "=&s"(m0s)
+                                   : [lds] "s"(lds0), [base] "s"(mbase), [pstr] "i"(kPieceFloats * 4), [vstr] "s"(piece_stride), [off] "v"(rb0),
+                                     [k0] "s"(m_ld[0]), [k1] "s"(m_ld[1]), [k2] "s"(m_ld[2]), [k3] "s"(m_ld[3]), [k4] "s"(m_ld[4]),
+                                     [k5] "s"(m_ld[5]), [k6] "s"(m_ld[kPieces - 1])
+                                   : "memory", "scc", "s100", "s101");
+                  } else {
+                      asm volatile(TRX_DMA_HEAD TRX_DMA_TAIL
+                                   : [sv] "=&s"(sv), [m0s] "=&s"(m0s)
+                                   : [lds] "s"(lds0), [base] "s"(mbase), [pstr] "i"(kPieceFloats * 4), [vstr] "s"(piece_stride), [off] "v"(rb0),
+                                     [k0] "s"(m_ld[0]), [k1] "s"(m_ld[1]), [k2] "s"(m_ld[2]), [k3] "s"(m_ld[3]), [k4] "s"(m_ld[4]),
+                                     [k5] "s"(m_ld[5])
+                                   : "memory", "scc", "s100", "s101");
+                  }
 #undef TRX_DMA_NEXT
-                }
-                if (m_oob) {   // zero padding: needed cells outside the volume (tiles at a volume face only)
-                    float zero;
-                    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));   // materialised here, not kept live across the loop
+#undef TRX_DMA_HEAD
+#undef TRX_DMA_TAIL
+              }
+              if (m_oob) {   // zero padding: needed cells outside the volume (tiles at a volume face only)
+                  float zero;
+                  asm volatile("v_mov_b32 %0, 0" : "=v"(zero));   // materialised here, not kept live across the loop
 #pragma unroll
-                    for (int k = 0; k < kPieces; k++)
-                        if (m_oob & (1u << k))
-                            *reinterpret_cast<float4 *>(box + k * kPieceFloats + (wave * 64 + lane) * 4) = make_float4(zero, zero, zero, zero);
-                }
-                __builtin_amdgcn_s_setprio(0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // box pieces and the target column have landed
-            }
-            asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]), "+v"(yn_l));
-            const float yid_l = unnorm<3>(yn_l, fH);
+                  for (int k = 0; k < kPieces; k++)
+                      if (m_oob & (1u << k))
+                          *reinterpret_cast<float4 *>(box + buf * kBoxFloats + k * kPieceFloats + (wave * 64 + lane) * 4) = make_float4(zero, zero, zero, zero);
+              }
+          };
+          // one DMA piece of the box prepared by issue_box(.., spread = true): issued between the rows of the gather so that
+          // the TA drains the pieces (64 B/clk per CU) while the VALU works, instead of every wave queueing all of them first
+          auto issue_piece = [&](int k) {
+              if (TRX_DBG_SKIP == 2) return;
+              unsigned long long sv;
+              unsigned m0s;
+              asm volatile("s_mov_b64 %[sv], exec\n\t"
+                           "s_mov_b32 %[m0s], m0\n\t"
+                           "s_mov_b32 m0, %[lds]\n\t"
+                           "s_mov_b64 exec, %[mk]\n\t"
+                           "global_load_lds_dwordx4 %[off], %[base]\n\t"
+                           "s_mov_b64 exec, %[sv]\n\t"
+                           "s_mov_b32 m0, %[m0s]"
+                           : [sv] "=&s"(sv), [m0s] "=&s"(m0s)
+                           : [lds] "s"(dma_lds + (unsigned)k * (kPieceFloats * 4u)), [base] "s"(dma_base + (size_t)k * piece_stride), [off] "v"(rb0),
+                             [mk] "s"(m_ld[k])
+                           : "memory");
+          };
+          // ---- the 8 rows of this thread in fast tile `g`, gathered from LDS buffer `buf`.  tnext != nullptr: after row j is
+          // consumed, row j of the tile at `tnext` is fetched into the same register (target prefetch without extra VGPRs).
+          auto gather_tile = [&](int g, int buf, float yn_l, float yid_l, float (&tv)[kRows], const float *tnext, bool dma_next) {
+              const int Y0 = (ty + g) * kTY;
+              const int ox = __builtin_amdgcn_readlane(g_ox, g), oy = __builtin_amdgcn_readlane(g_oy, g), oz = __builtin_amdgcn_readlane(g_oz, g);
+              float yn_r[kRows], yid_r[kRows];
+#pragma unroll
+              for (int j = 0; j < kRows; j++) { yn_r[j] = lane_bcast(yn_l, j); yid_r[j] = lane_bcast(yid_l, j); }
+              if (TRX_DBG_SKIP == 1) return;
+              const int bpb = (int)box_lds + buf * (kBoxFloats * 4) - ((oz * kBH + oy) * kBW + ox) * 4;   // LDS byte address of voxel (0,0,0) of the volume
+              // software pipeline: the 4 LDS reads of row j+1 are issued before the arithmetic of row j
+              struct Fetch { f2 r00, r01, r10, r11; float fx, fy, fz; };
+              auto fetch = [&](int j) -> Fetch {
+                  const float yn = yn_r[j];
+                  const float ix = fmaf(sxv, yn, base_x);
+                  const float iy = yid_r[j] + fmaf(syv, yn, base_y);
+                  const float iz = fmaf(szv, yn, base_z);
+                  int a0, a1, a2, a3;
+                  asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a0) : "v"(floor_to_int(ix)), "s"(bpb));
+                  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a1) : "v"(floor_to_int(iy)), "s"(ys_s), "v"(a0));
+                  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a2) : "v"(floor_to_int(iz)), "s"(zs_s), "v"(a1));
+                  asm("v_add_u32 %0, %1, %2" : "=v"(a3) : "s"(zs_s), "v"(a2));
+                  Fetch f;
+                  f.r00 = *(lds_f2)(unsigned)a2; f.r01 = *(lds_f2)(unsigned)(a2 + kBW * 4);
+                  f.r10 = *(lds_f2)(unsigned)a3; f.r11 = *(lds_f2)(unsigned)(a3 + kBW * 4);
+                  f.fx = __builtin_amdgcn_fractf(ix); f.fy = __builtin_amdgcn_fractf(iy); f.fz = __builtin_amdgcn_fractf(iz);
+                  return f;
+              };
+              Fetch cur = fetch(0);
+#pragma unroll
+              for (int j = 0; j < kRows; j++) {
+                  Fetch nxt;
+                  if (j + 1 < kRows) nxt = fetch(j + 1);
+                  if (kBufs == 2 && j < kPieces && dma_next) issue_piece(j);
+                  const Samp3 sm = lerp3_pairs<MODE == 0>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
+                  if constexpr (MODE == 3) { if (act) wout[(size_t)Y0 * W + (unsigned)(toff + j * W)] = sm.v; }
+                  else f1_accumulate_pk<MODE>(sm, tv[j], yn_r[j], acc);
+                  if (kBufs == 2 && TRX_DBG_SKIP != 3 && MODE != 3)
+                      asm volatile("global_load_dword %0, %1, %2" : "=v"(tv[j]) : "v"(toffb), "s"(tnext + (size_t)j * W));
+                  if (j + 1 < kRows) cur = nxt;
+              }
+          };
+          auto load_targets = [&](int g, float (&tv)[kRows]) {
+              const float *trow = tgt + (size_t)(ty + g) * kTY * W;   // uniform (toffb holds the row offset of this half)
+#pragma unroll
+              for (int j = 0; j < kRows; j++) {
+                  if (TRX_DBG_SKIP == 3 || MODE == 3) tv[j] = 1.f;
+                  else asm volatile("global_load_dword %0, %1, %2" : "=v"(tv[j]) : "v"(toffb), "s"(trow + (size_t)j * W) : "memory");
+              }
+          };
+          float tv[kRows];
+          if constexpr (kBufs == 1) {
+            // one box, two blocks per CU: burst - wait - barrier - gather - barrier
+            for (int gl = 0; gl < nf; gl++) {
 #if TRX_TIMING
-            const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+              const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
 #endif
+              // row tables of this wave's 8 rows in lanes 0..7 (broadcast in gather_tile with constant-lane v_readlane)
+              float yn_l;
+              asm volatile("global_load_dword %0, %1, %2" : "=v"(yn_l) : "v"(lane7b), "s"(ytab + (ty + gl) * kTY + j0) : "memory");
+              __builtin_amdgcn_s_setprio(TRX_STAGE_PRIO);
+              load_targets(gl, tv);
+              issue_box(gl, 0, false);
+              __builtin_amdgcn_s_setprio(0);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // box pieces and the target column have landed
+              asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]), "+v"(yn_l));
+              const float yid_l = unnorm<3>(yn_l, fH);
+#if TRX_TIMING
+              const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+#endif
+              __syncthreads();
+#if TRX_TIMING
+              const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+#endif
+              gather_tile(gl, 0, yn_l, yid_l, tv, nullptr, false);
+#if TRX_TIMING
+              const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
+#endif
+              __syncthreads();   // the box is overwritten by the next tile
+#if TRX_TIMING
+              {
+                  const unsigned long long tm4 = __builtin_amdgcn_s_memtime();
+                  tm_acc[0] += tm1 - tm0; tm_acc[1] += tm2 - tm1; tm_acc[2] += tm3 - tm2; tm_acc[3] += tm4 - tm3;
+              }
+#endif
+            }
+          } else {
+            // two boxes, one block per CU: the DMA of tile g+1 (and, row by row, its target column) is in flight while
+            // tile g is gathered; one barrier per tile (it also tells that every wave is done with the other box)
+            if (nf > 0) {
+                load_targets(0, tv);
+                issue_box(0, 0, false);
+            }
+            for (int gl = 0; gl < nf; gl++) {
+#if TRX_TIMING
+              const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+#endif
+              float yn_l;
+              asm volatile("global_load_dword %0, %1, %2" : "=v"(yn_l) : "v"(lane7b), "s"(ytab + (ty + gl) * kTY + j0) : "memory");
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's box pieces (issued one tile ago) and target column
+              asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]), "+v"(yn_l));
+              const float yid_l = unnorm<3>(yn_l, fH);
+#if TRX_TIMING
+              const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+#endif
+              __syncthreads();
+#if TRX_TIMING
+              const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+#endif
+              const int gn = (gl + 1 < nf) ? gl + 1 : gl;
+              if (gl + 1 < nf) issue_box(gl + 1, (gl + 1) & 1, TRX_DMA_SPREAD);
+#if TRX_TIMING
+              const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
+#endif
+              gather_tile(gl, gl & 1, yn_l, yid_l, tv, tgt + (size_t)(ty + gn) * kTY * W, TRX_DMA_SPREAD && gl + 1 < nf);
+#if TRX_TIMING
+              {
+                  const unsigned long long tm4 = __builtin_amdgcn_s_memtime();
+                  tm_acc[0] += tm1 - tm0; tm_acc[1] += tm2 - tm1; tm_acc[2] += tm3 - tm2; tm_acc[3] += tm4 - tm3;
+              }
+#endif
+            }
+            // the prefetch issued during the last tile is still in flight: its destination registers must not be reused,
+            // and the generic loop below must not overwrite box 0 while a slower wave still gathers from it
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]) : : "memory");
             __syncthreads();
-#if TRX_TIMING
-            const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
-#endif
-            float yn_r[kRows], yid_r[kRows];
-#pragma unroll
-            for (int j = 0; j < kRows; j++) { yn_r[j] = lane_bcast(yn_l, j); yid_r[j] = lane_bcast(yid_l, j); }
-            if (TRX_DBG_SKIP != 1) {
-                const int bpb = (int)box_lds - ((oz * kBH + oy) * kBW + ox) * 4;   // LDS byte address of voxel (0,0,0) of the volume
-                // software pipeline: the 4 LDS reads of row j+1 are issued before the arithmetic of row j
-                struct Fetch { f2 r00, r01, r10, r11; float fx, fy, fz; };
-                auto fetch = [&](int j) -> Fetch {
-                    const float yn = yn_r[j];
-                    const float ix = fmaf(sxv, yn, base_x);
-                    const float iy = yid_r[j] + fmaf(syv, yn, base_y);
-                    const float iz = fmaf(szv, yn, base_z);
-                    int a0, a1, a2, a3;
-                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a0) : "v"(floor_to_int(ix)), "s"(bpb));
-                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a1) : "v"(floor_to_int(iy)), "s"(ys_s), "v"(a0));
-                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a2) : "v"(floor_to_int(iz)), "s"(zs_s), "v"(a1));
-                    asm("v_add_u32 %0, %1, %2" : "=v"(a3) : "s"(zs_s), "v"(a2));
-                    Fetch f;
-                    f.r00 = *(lds_f2)(unsigned)a2; f.r01 = *(lds_f2)(unsigned)(a2 + kBW * 4);
-                    f.r10 = *(lds_f2)(unsigned)a3; f.r11 = *(lds_f2)(unsigned)(a3 + kBW * 4);
-                    f.fx = __builtin_amdgcn_fractf(ix); f.fy = __builtin_amdgcn_fractf(iy); f.fz = __builtin_amdgcn_fractf(iz);
-                    return f;
-                };
-                Fetch cur = fetch(0);
-#pragma unroll
-                for (int j = 0; j < kRows; j++) {
-                    Fetch nxt;
-                    if (j + 1 < kRows) nxt = fetch(j + 1);
-#if TRX_SWP_BARRIER
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
-                    const Samp3 sm = lerp3_pairs<MODE == 0>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
-                    if constexpr (MODE == 3) { if (act) wout[(size_t)Y0 * W + (unsigned)(toff + j * W)] = sm.v; }
-                    else f1_accumulate_pk<MODE>(sm, tv[j], yn_r[j], acc);
-                    if (j + 1 < kRows) cur = nxt;
-                }
-            }
-#if TRX_TIMING
-            const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
-#endif
-            __syncthreads();   // the box is overwritten by the next tile
-#if TRX_TIMING
-            {
-                const unsigned long long tm4 = __builtin_amdgcn_s_memtime();
-                tm_acc[0] += tm1 - tm0; tm_acc[1] += tm2 - tm1; tm_acc[2] += tm3 - tm2; tm_acc[3] += tm4 - tm3;
-            }
-#endif
           }
           ty += nf;
           if (nf < chunk) break;   // the generic loop takes over at tile ty (same 64-tile chunking, geometry already in g_*)
@@ -667,7 +772,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             needmask = 0;
 #pragma unroll
             for (int k = 0; k < kPieces; k++)   // per-field compare (dz,dy,dx4) <= lim: no field of lim-d may borrow
-                if (((lim - (d0 + (k << 17))) & 0x80808080) == 0) needmask |= 1u << k;
+                if (((lim - (d0 + (k << kDShift))) & 0x80808080) == 0) needmask |= 1u << k;
         }
         const int obase = (oz * H + oy) * W + ox;
         unsigned oob = 0;   // bit k: slot k of this thread is needed but lies outside the volume
@@ -682,7 +787,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
 #pragma unroll
             for (int k = 0; k < kPieces; k++)
                 if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2) {
-                    const int d = d0 + (k << 17);
+                    const int d = d0 + (k << kDShift);
                     const int gz = oz + (d >> 16), gy = oy + ((d >> 8) & 0xff), gx = ox + (d & 0xff) * 4;
                     const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
                     const unsigned idx = inb ? (unsigned)(obase + (int)((rb0 + k * piece_stride) >> 2)) : 0u;
