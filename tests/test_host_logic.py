@@ -48,6 +48,50 @@ def test_argument_validation_without_gpu():
     assert lib.trx_affine_step(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(st), ctypes.c_void_p(16), 1 << 30, None) == -1
 
 
+def test_more_argument_validation_without_gpu():
+    """Workspace-size, optimiser-kind and extension entry points: every error path returns its status before any launch."""
+    from torchregister_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    v = _lib.Volumes()
+    v.moving, v.target, v.ndim, v.B, v.D, v.H, v.W = 16, 16, 3, 1, 8, 8, 8
+    need = lib.trx_affine_workspace_bytes(ctypes.byref(v))
+    lc, oc, st = _lib.LossCfg(), _lib.OptCfg(), _lib.AffineState()
+    for f in ("param", "theta", "best_theta", "best_loss", "best_idx", "step"):
+        setattr(st, f, 16)
+    oc.kind = 7                                                           # neither SGD nor Adam
+    assert lib.trx_affine_step(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(st), P(16), need, None) == -1
+    oc.kind = 1                                                           # Adam without moment buffers
+    assert lib.trx_affine_step(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(st), P(16), need, None) == -1
+    oc.kind = 0
+    assert lib.trx_affine_step(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(st), P(16), need - 1, None) == -3
+    assert lib.trx_affine_run(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(st), -1, P(16), need, None) == -1
+    assert lib.trx_affine_accumulate(ctypes.byref(v), P(16), P(16), 0, None) == -3
+    assert lib.trx_affine_loss(ctypes.byref(v), ctypes.byref(lc), P(16), None, P(16), need, None) == -1
+    # a volume of 2^31 voxels is refused (32-bit voxel indices inside one volume)
+    big = _lib.Volumes()
+    big.moving, big.target, big.ndim, big.B, big.D, big.H, big.W = 16, 16, 3, 1, 2048, 1024, 1024
+    assert lib.trx_affine_workspace_bytes(ctypes.byref(big)) == 0
+    assert lib.trx_flow_workspace_bytes(ctypes.byref(big)) == 0
+    # flow entry points
+    fs = _lib.FlowState()
+    assert lib.trx_flow_workspace_bytes(ctypes.byref(v)) > 0
+    assert lib.trx_flow_step(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(fs), P(16), 1 << 30, None) == -1   # null flow
+    assert lib.trx_flow_warp(ctypes.byref(v), None, 1, P(16), None) == -1
+    # local-window NCC extension
+    assert lib.trx_lncc_workspace_bytes(4, 1, 8, 8, 8) == 0
+    assert lib.trx_lncc_workspace_bytes(2, 1, 3, 8, 8) == 0               # 2-D needs D == 1
+    n = lib.trx_lncc_workspace_bytes(3, 2, 8, 8, 8)
+    assert n >= 4 * 2 * 512 * 4
+    args = (P(16), P(16), 3, 2, 8, 8, 8)
+    assert lib.trx_lncc_loss_grad(*args, 9, 1.0, 1e-5, P(16), P(16), P(16), n - 1, None) == -3
+    assert lib.trx_lncc_loss_grad(*args, 4, 1.0, 1e-5, P(16), P(16), P(16), n, None) == -1     # even window
+    assert lib.trx_lncc_loss_grad(*args, 9, 1.0, 1e-5, None, None, P(16), n, None) == -1        # nothing to compute
+    assert lib.trx_lncc_loss_grad(P(16), P(16), 5, 2, 8, 8, 8, 9, 1.0, 1e-5, P(16), P(16), P(16), n, None) == -2
+    for code, word in ((-1, b"arg"), (-2, b"dim"), (-4, b"HIP"), (-5, b"loss-curve")):
+        assert word.lower() in lib.trx_status_string(code).lower()
+
+
 def test_cpu_tensors_fail_loudly():
     import torchregister_amd as tr
     reg = tr.Register("affine")

@@ -285,6 +285,7 @@ static int check_vol_flow(const trx_volumes *v, bool need_target)
     if (v->ndim != 2 && v->ndim != 3) return TRX_ERR_NDIM;
     if (v->B < 1 || v->D < 1 || v->H < 1 || v->W < 1 || v->B > 65535) return TRX_ERR_ARG;
     if (v->ndim == 2 && v->D != 1) return TRX_ERR_NDIM;
+    if ((size_t)v->D * v->H * v->W >= ((size_t)1 << 31)) return TRX_ERR_ARG;   // same limit as the affine path (include/trx.h)
     return TRX_OK;
 }
 
