@@ -81,21 +81,20 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_moments_kernel(trx_volumes vol
             const int pos[3] = {ND == 3 ? z : y, ND == 3 ? y : x, x};
             const int ext[3] = {ND == 3 ? D : H, ND == 3 ? H : W, W};
 #pragma unroll
-            for (int dd = 0; dd < ND; dd++)
-                if (pos[dd] + 1 < ext[dd]) {
+            for (int dd = 0; dd < ND; dd++) {
+                // forward difference; at the far face the neighbour index is the voxel itself (difference 0, no branch)
+                const bool inner = pos[dd] + 1 < ext[dd];
+                const size_t nb = i + (inner ? dstride[dd] : 0);
+                const bool halo = (ND == 3 && dd == 0 && !inner && slab.halo_hi != nullptr);   // across the slab boundary: the lower slab counts it
 #pragma unroll
-                    for (int c = 0; c < ND; c++) {
-                        const float df = fl[c * nvox + i + dstride[dd]] - fl[c * nvox + i];
-                        vals[5 + dd] = fmaf(df, df, vals[5 + dd]);
-                    }
-                } else if (ND == 3 && dd == 0 && slab.halo_hi) {   // the difference across the slab boundary belongs to the lower slab
-                    const size_t hw = (size_t)H * W, pi = (size_t)y * W + x;
-#pragma unroll
-                    for (int c = 0; c < ND; c++) {
-                        const float df = slab.halo_hi[c * hw + pi] - fl[c * nvox + i];
-                        vals[5 + dd] = fmaf(df, df, vals[5 + dd]);
-                    }
+                for (int c = 0; c < ND; c++) {
+                    const float f0 = fl[c * nvox + i];
+                    float fn = fl[c * nvox + nb];
+                    if (halo) fn = slab.halo_hi[c * ((size_t)H * W) + (size_t)y * W + x];
+                    const float df = fn - f0;
+                    vals[5 + dd] = fmaf(df, df, vals[5 + dd]);
                 }
+            }
         }
     }
     block_reduce_store<kFlowNP, 8>(vals, partials + ((size_t)b * gridDim.x + blockIdx.x) * kFlowNP);
@@ -206,12 +205,15 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
                 const int ext[3] = {ND == 3 ? D : H, ND == 3 ? H : W, W};
 #pragma unroll
                 for (int dd = 0; dd < ND; dd++) {
-                    float a = 0.f;
-                    if (pos[dd] > 0) a += f0 - fl[ch * nvox + i - dstride[dd]];
-                    else if (ND == 3 && dd == 0 && slab.halo_lo) a += f0 - slab.halo_lo[ch * (size_t)H * W + (size_t)y * W + x];
-                    if (pos[dd] + 1 < ext[dd]) a -= fl[ch * nvox + i + dstride[dd]] - f0;
-                    else if (ND == 3 && dd == 0 && slab.halo_hi) a -= slab.halo_hi[ch * (size_t)H * W + (size_t)y * W + x] - f0;
-                    g = fmaf(c.sm[dd], a, g);
+                    // (f0 - f[lo]) - (f[hi] - f0); at a face the neighbour index is the voxel itself (term 0, no branch)
+                    const bool has_lo = pos[dd] > 0, has_hi = pos[dd] + 1 < ext[dd];
+                    float flo = fl[ch * nvox + i - (has_lo ? dstride[dd] : 0)];
+                    float fhi = fl[ch * nvox + i + (has_hi ? dstride[dd] : 0)];
+                    if (ND == 3 && dd == 0) {   // Z-slab partition: the neighbour plane lives on another rank
+                        if (!has_lo && slab.halo_lo) flo = slab.halo_lo[ch * (size_t)H * W + (size_t)y * W + x];
+                        if (!has_hi && slab.halo_hi) fhi = slab.halo_hi[ch * (size_t)H * W + (size_t)y * W + x];
+                    }
+                    g = fmaf(c.sm[dd], (f0 - flo) - (fhi - f0), g);
                 }
             }
             if constexpr (MODE == 1) {
