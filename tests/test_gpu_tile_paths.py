@@ -50,7 +50,7 @@ THETAS = {
     "zoom_out": rot_theta(0.0, 0.0, 0.0, (1.6, 1.5, 1.7), (0.0, 0.0, 0.0)),
     "flip": np.array([[-1.0, 0.02, 0, 0.01], [0.01, 1.0, 0, 0], [0, 0, -0.98, 0.02]]),
 }
-SHAPES = [(40, 36, 44), (16, 48, 64), (24, 20, 30), (9, 33, 68), (64, 64, 64)]
+SHAPES = [(40, 36, 44), (16, 48, 64), (24, 20, 30), (9, 33, 68), (64, 64, 64), (23, 37, 46), (18, 16, 33)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)

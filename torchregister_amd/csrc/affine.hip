@@ -361,7 +361,6 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     const float t10 = th[4], t11 = th[5], t12 = th[6], t13 = th[7];
     const float t20 = th[8], t21 = th[9], t22 = th[10], t23 = th[11];
     const float sx = uni(hW * t01), sy = uni(hH * (t11 - 1.0f)), sz = uni(hD * t21);
-    const bool vec_ok = ((W & 3) == 0) && ((((size_t)mov) & 15) == 0);
 
     // XCD-aware column order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
     // contiguous slab of columns so that the halo re-reads of neighbouring columns hit the same L2.
@@ -414,6 +413,18 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     };
     const unsigned piece_stride = (unsigned)(kPP * H * W) * 4u;   // bytes between the pieces of one thread inside the volume
     constexpr int kDShift = (kPP == 2) ? 17 : 18;                  // d of piece k = d0 + (k << kDShift)
+    // A needed float4 slot that the DMA does not fetch - outside the volume, or straddling its +x face when W % 4 != 0
+    // (global_load_lds_dwordx4 itself takes any 4-byte aligned address) - is filled element by element with zero padding.
+    auto fill_slot = [&](float *dst, int gz, int gy, int gx) {
+        const bool rowin = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H);
+        const float *row = mov + ((size_t)(rowin ? gz : 0) * H + (rowin ? gy : 0)) * W;
+        float4 v;
+        v.x = (rowin && (unsigned)(gx + 0) < (unsigned)W) ? row[gx + 0] : 0.f;
+        v.y = (rowin && (unsigned)(gx + 1) < (unsigned)W) ? row[gx + 1] : 0.f;
+        v.z = (rowin && (unsigned)(gx + 2) < (unsigned)W) ? row[gx + 2] : 0.f;
+        v.w = (rowin && (unsigned)(gx + 3) < (unsigned)W) ? row[gx + 3] : 0.f;
+        *reinterpret_cast<float4 *>(dst) = v;
+    };
     static_assert(kPP == 2 || kPP == 4, "piece planes");
 
     F1Acc acc;
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         const float yn0 = ytab[ty * kTY], yid0 = unnorm<3>(yn0, fH);
         const float cx = fmaf(sx, yn0, corner_x), cy = yid0 + fmaf(sy, yn0, corner_y), cz = fmaf(sz, yn0, corner_z);
         const float slack = 0.05f;   // fp32 rounding + table non-uniformity of interior points vs the corner + extent bound
-        bool fits = vec_ok && (fabsf(cx) < 1.0e6f) && (fabsf(cy) < 1.0e6f) && (fabsf(cz) < 1.0e6f);   // also rejects NaN
+        bool fits = (fabsf(cx) < 1.0e6f) && (fabsf(cy) < 1.0e6f) && (fabsf(cz) < 1.0e6f);   // also rejects NaN
         int ox = 0, oy = 0, oz = 0, ex4 = 0, ey = 0, ez = 0;
         bool interior = false;
         if (fits) {
@@ -500,7 +511,10 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         while (ty < ty_end) {
           lane_geometry(ty);
           const int chunk = min(64, ty_end - ty);
-          const bool ok = (lane < chunk) && ((g_pk >> 24) & 1) && ((ty + lane + 1) * kTY <= H);
+          // W % 4 != 0: a tile whose needed extent reaches the float4 that straddles x = W goes to the generic loop (its
+          // stage_box fills that slot element by element); with ox % 4 == 0 this only concerns the columns at the +x face
+          const bool xpart = ((W & 3) != 0) && (g_ox + 4 * ((lim_blk & 0xff) + 1) > W - (W & 3));
+          const bool ok = (lane < chunk) && ((g_pk >> 24) & 1) && ((ty + lane + 1) * kTY <= H) && !xpart;
           const unsigned long long bad = ~__builtin_amdgcn_ballot_w64(ok);
           const int nf = bad ? __builtin_ctzll(bad) : 64;
           // ---- box of fast tile `g` of this chunk -> LDS buffer `buf`: refresh the cached exec masks if the tile's slot
@@ -789,7 +803,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                 if ((needmask & (1u << k)) && TRX_DBG_SKIP != 2) {
                     const int d = d0 + (k << kDShift);
                     const int gz = oz + (d >> 16), gy = oy + ((d >> 8) & 0xff), gx = ox + (d & 0xff) * 4;
-                    const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+                    const bool inb = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H) && (gx >= 0) && (gx + 4 <= W);   // whole slot inside
                     const unsigned idx = inb ? (unsigned)(obase + (int)((rb0 + k * piece_stride) >> 2)) : 0u;
                     if (!inb) oob |= 1u << k;
                     __builtin_amdgcn_global_load_lds(mov + idx, box + k * kPieceFloats + wave * 256, 16, 0, 0);
@@ -797,11 +811,13 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         }
         __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (oob) {   // zero padding: cells outside the volume (boundary tiles only)
+        if (oob) {   // slots the DMA skipped (boundary tiles only): zero padding / partial rows
 #pragma unroll
             for (int k = 0; k < kPieces; k++)
-                if (oob & (1u << k))
-                    *reinterpret_cast<float4 *>(box + k * kPieceFloats + (wave * 64 + lane) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (oob & (1u << k)) {
+                    const int d = d0 + (k << kDShift);
+                    fill_slot(box + k * kPieceFloats + (wave * 64 + lane) * 4, oz + (d >> 16), oy + ((d >> 8) & 0xff), ox + (d & 0xff) * 4);
+                }
         }
     };
     // ---- one voxel gathered from the LDS box: coordinates, 4 paired reads, trilinear value (+ gradient)
