@@ -215,9 +215,11 @@ static TileGeom tile_geom(const trx_volumes &v)
     t.ntx = (v.W + kTX - 1) / kTX; t.nty = (v.H + kTY - 1) / kTY; t.ntz = (v.D + kTZ - 1) / kTZ;
     t.ntiles = t.ntx * t.nty * t.ntz;
     // one block per (x-tile, z-tile) column walking y; small batches split every column into y segments
-    // so that at least ~1024 blocks (two rounds of 2 blocks on each of 256 CUs) exist
+    // so that at least ~512 blocks (one round of 2 blocks on each of 256 CUs) exist: measured best for 1-2 pairs of
+    // 128^3 / 256^3 (kbench sweep: 1 x 256^3 47 us at 512 blocks, 53 us at 1024, 64 us at 2048)
     const int ncol = t.ntx * t.ntz;
-    int ys = (1024 + v.B * ncol - 1) / (v.B * ncol);
+    static const int target = [] { const char *e = getenv("TRX_TILE_TARGET_BLOCKS"); return e ? atoi(e) : 512; }();   // development knob; 512 = one round of 2 blocks on each of the 256 CUs
+    int ys = (target + v.B * ncol - 1) / (v.B * ncol);
     if (ys < 1) ys = 1;
     if (ys > t.nty) ys = t.nty;
     t.tiles_per_seg = (t.nty + ys - 1) / ys;
