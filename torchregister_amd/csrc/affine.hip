@@ -493,6 +493,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
 #pragma unroll
         for (int k = 0; k < kPieces; k++) m_ld[k] = 0;
         unsigned m_oob = 0;                                  // bit k: slot k of this thread is needed but outside the volume
+        unsigned m_part = 0;                                 // bit k: slot k straddles x = W (W % 4 != 0): zero its tail after landing
         // Fetched extent = the LARGEST pre-image extent any tile of this theta can have (capped at the box): the exact
         // extent of a tile flips between two values with the fractional position of its corner, and every change
         // would invalidate the cached masks; one extra row / plane / float4 of DMA is cheaper than that.
@@ -513,9 +514,11 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         while (ty < ty_end) {
           lane_geometry(ty);
           const int chunk = min(64, ty_end - ty);
-          // W % 4 != 0: a tile whose needed extent reaches the float4 that straddles x = W goes to the generic loop (its
-          // stage_box fills that slot element by element); with ox % 4 == 0 this only concerns the columns at the +x face
-          const bool xpart = ((W & 3) != 0) && (g_ox + 4 * ((lim_blk & 0xff) + 1) > W - (W & 3));
+          // W % 4 != 0: a tile whose needed extent reaches the float4 that straddles x = W (only columns at the +x face)
+          // (the straddling float4 of a row is fetched whole, i.e. up to 12 bytes into the next row - except on the last row
+          // of the volume, where that would leave the allocation: that one tile per pair goes to the generic loop)
+          const bool xpart = ((W & 3) != 0) && (g_ox + 4 * ((lim_blk & 0xff) + 1) > W - (W & 3)) &&
+                             (g_oy + ((lim_blk >> 8) & 0xff) >= H - 1) && (g_oz + (lim_blk >> 16) >= D - 1);
           const bool ok = (lane < chunk) && ((g_pk >> 24) & 1) && ((ty + lane + 1) * kTY <= H) && !xpart;
           const unsigned long long bad = ~__builtin_amdgcn_ballot_w64(ok);
           const int nf = bad ? __builtin_ctzll(bad) : 64;
@@ -527,13 +530,15 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
               const int ox = __builtin_amdgcn_readlane(g_ox, g), oy = __builtin_amdgcn_readlane(g_oy, g), oz = __builtin_amdgcn_readlane(g_oz, g);
               const int lim = lim_blk;         // (ez-1) << 16 | (ey-1) << 8 | (ex4-1)
               const int loz = max(0, -oz), loy = max(0, -oy), lox = max(0, -(ox >> 2));
-              const int hiz = min(lim >> 16, D - 1 - oz), hiy = min((lim >> 8) & 0xff, H - 1 - oy), hix = min(lim & 0xff, ((W - ox) >> 2) - 1);
+              const int hiz = min(lim >> 16, D - 1 - oz), hiy = min((lim >> 8) & 0xff, H - 1 - oy), hix = min(lim & 0xff, ((W - ox + 3) >> 2) - 1);   // includes the float4 straddling x = W (W % 4 != 0)
               const bool none = (hiz < loz) || (hiy < loy) || (hix < lox);   // the whole pre-image lies outside the volume
               const int lo = none ? 0x7f7f7f : ((loz << 16) | (loy << 8) | lox);
               const int hi = none ? 0 : ((hiz << 16) | (hiy << 8) | hix);
               if (lim != m_lim || lo != m_lo || hi != m_hi) {
                   m_lim = lim; m_lo = lo; m_hi = hi;
                   m_oob = 0;
+                  m_part = 0;
+                  const int part_x = (W & 3) ? ((W - ox) >> 2) : -1;   // float4 index of the slot straddling x = W
                   int ln = lane;   // opaque copy: keeps the slot decode inside this (rarely taken) branch
                   asm volatile("" : "+v"(ln));
                   unsigned rbx;
@@ -546,6 +551,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                       const bool ld = need && (((hi - d) & 0x80808080) == 0) && (((d - lo) & 0x80808080) == 0);
                       m_ld[k] = __builtin_amdgcn_ballot_w64(ld);
                       if (need && !ld) m_oob |= 1u << k;
+                      if (ld && (d & 0xff) == part_x) m_part |= 1u << k;   // fetched whole; its tail past x = W is zeroed after landing
                   }
               }
               dma_base = reinterpret_cast<const char *>(mov + (ptrdiff_t)((oz * H + oy) * W + ox));   // uniform; may point below `mov` (those lanes are masked)
@@ -599,6 +605,15 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                       if (m_oob & (1u << k))
                           *reinterpret_cast<float4 *>(box + buf * kBoxFloats + k * kPieceFloats + (wave * 64 + lane) * 4) = make_float4(zero, zero, zero, zero);
               }
+          };
+          // W % 4 != 0: the float4 that straddles the +x face was fetched whole (its tail belongs to the next row): zero the tail
+          auto zero_tails = [&](int buf) {
+#pragma unroll
+              for (int k = 0; k < kPieces; k++)
+                  if (m_part & (1u << k)) {
+                      float *sl = box + buf * kBoxFloats + k * kPieceFloats + (wave * 64 + lane) * 4;
+                      for (int e = W & 3; e < 4; e++) sl[e] = 0.f;
+                  }
           };
           // one DMA piece of the box prepared by issue_box(.., spread = true): issued between the rows of the gather so that
           // the TA drains the pieces (64 B/clk per CU) while the VALU works, instead of every wave queueing all of them first
@@ -683,6 +698,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
               issue_box(gl, 0, false);
               __builtin_amdgcn_s_setprio(0);
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // box pieces and the target column have landed
+              if (m_part) zero_tails(0);
               asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]), "+v"(yn_l));
               const float yid_l = unnorm<3>(yn_l, fH);
 #if TRX_TIMING
@@ -718,6 +734,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
               float yn_l;
               asm volatile("global_load_dword %0, %1, %2" : "=v"(yn_l) : "v"(lane7b), "s"(ytab + (ty + gl) * kTY + j0) : "memory");
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's box pieces (issued one tile ago) and target column
+              if (m_part) zero_tails(gl & 1);
               asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]), "+v"(yn_l));
               const float yid_l = unnorm<3>(yn_l, fH);
 #if TRX_TIMING
