@@ -25,25 +25,45 @@ namespace trx {
 constexpr int kLX = 32, kLY = 8;            // output tile of a block in x, y
 constexpr int kLRows = kLY + 8, kLCols = kLX + 8;   // tile + halo 4 (the largest radius)
 
-// Window sums of NF fields over the x-y window for plane `zin` of the block's column -> P[NF] of thread (ox, oy).
-// fill(cell, z, gy, gx, inb) writes the NF fields of one tile cell (zeros when !inb) through cell[f * kLRows * kLCols].
+constexpr int kLCells = (kLRows * kLCols + TRX_BLOCK - 1) / TRX_BLOCK;   // tile cells per thread (3)
+
+// The raw inputs of one plane of the block's tile (+halo), held in registers between the global loads and the LDS
+// commit: the loads of plane z+1 are issued before the window passes of plane z, so their latency is hidden.
+template <int NL>
+struct PlaneRegs {
+    float v[kLCells][NL];
+};
+
+// Issue the global loads of plane `zin` (zeros outside the volume).  fetch(z, gy, gx, out[NL]) reads one in-volume cell.
+template <int NL, typename Fetch>
+__device__ __forceinline__ void plane_fetch(int zin, int D, int H, int W, int X0, int Y0, Fetch fetch, PlaneRegs<NL> &r)
+{
+    const bool zin_ok = (zin >= 0) && (zin < D);   // uniform
+#pragma unroll
+    for (int c = 0; c < kLCells; c++) {
+        const int rc = threadIdx.x + c * TRX_BLOCK;
+        const int row = rc / kLCols, col = rc - row * kLCols;
+        const int gy = Y0 - 4 + row, gx = X0 - 4 + col;
+        const bool inb = zin_ok && (rc < kLRows * kLCols) && ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
+#pragma unroll
+        for (int f = 0; f < NL; f++) r.v[c][f] = 0.f;
+        if (inb) fetch(zin, gy, gx, r.v[c]);
+    }
+}
+
+// Window sums of NF fields over the x-y window of the plane held in `r` -> P[NF] of thread (ox, oy).
+// expand(cell, in[NL]) writes the NF fields of one tile cell through cell[f * kLRows * kLCols].
 // All threads of the block must call this together.
-template <int R, int NF, typename Fill>
-__device__ __forceinline__ void plane_window_sums(int zin, int D, int H, int W, int X0, int Y0, Fill fill, float (*raw)[kLRows][kLCols],
+template <int R, int NF, int NL, typename Expand>
+__device__ __forceinline__ void plane_window_sums(const PlaneRegs<NL> &r, Expand expand, float (*raw)[kLRows][kLCols],
                                                   float (*xs)[kLX][kLRows + 1], float (&P)[NF])
 {
     const int tid = threadIdx.x;
-    if (zin < 0 || zin >= D) {   // uniform: planes outside the volume are zero padding
-#pragma unroll
-        for (int f = 0; f < NF; f++) P[f] = 0.f;
-        return;
-    }
     __syncthreads();   // the previous plane's LDS reads are done
-    for (int rc = tid; rc < kLRows * kLCols; rc += TRX_BLOCK) {
-        const int r = rc / kLCols, c = rc - r * kLCols;
-        const int gy = Y0 - 4 + r, gx = X0 - 4 + c;
-        const bool inb = ((unsigned)gy < (unsigned)H) && ((unsigned)gx < (unsigned)W);
-        fill(&raw[0][r][c], zin, gy, gx, inb);
+#pragma unroll
+    for (int c = 0; c < kLCells; c++) {
+        const int rc = tid + c * TRX_BLOCK;
+        if (rc < kLRows * kLCols) expand(&raw[0][0][0] + rc, r.v[c]);
     }
     __syncthreads();
     // x window: thread (row, quad) produces outputs x = 4 quad .. 4 quad + 3 of its row from 12 consecutive inputs
@@ -82,13 +102,15 @@ __device__ __forceinline__ void plane_window_sums(int zin, int D, int H, int W, 
 
 // Walks the column along z, keeping the z window as a running sum over a register ring; emit(z, Z) is called for
 // every output plane with the full window sums Z[NF] of this thread's voxel.
-template <int R, int NF, typename Fill, typename Emit>
-__device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0, int Y0, int z0, int z1, Fill load, Emit emit,
+template <int R, int NF, int NL, typename Fetch, typename Expand, typename Emit>
+__device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0, int Y0, int z0, int z1, Fetch fetch, Expand expand, Emit emit,
                                             float (*raw)[kLRows][kLCols], float (*xs)[kLX][kLRows + 1])
 {   // output planes [z0, z1) of the column (a z segment: small batches split columns so that the chip is filled)
+    PlaneRegs<NL> regs;
     if (nd == 2) {   // images: the window has no z extent
         float P[NF];
-        plane_window_sums<R, NF>(0, 1, H, W, X0, Y0, load, raw, xs, P);
+        plane_fetch<NL>(0, 1, H, W, X0, Y0, fetch, regs);
+        plane_window_sums<R, NF, NL>(regs, expand, raw, xs, P);
         emit(0, P);
         return;
     }
@@ -100,13 +122,22 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
         for (int f = 0; f < NF; f++) ring[k][f] = 0.f;
 #pragma unroll
     for (int f = 0; f < NF; f++) Z[f] = 0.f;
+    plane_fetch<NL>(z0 - R, D, H, W, X0, Y0, fetch, regs);
     for (int base = z0 - R; base < z1 + R; base += WN) {
 #pragma unroll
         for (int k = 0; k < WN; k++) {
             const int zin = base + k;
             if (zin < z1 + R) {
                 float P[NF];
-                plane_window_sums<R, NF>(zin, D, H, W, X0, Y0, load, raw, xs, P);
+                if (zin >= 0 && zin < D) {   // uniform
+                    PlaneRegs<NL> cur = regs;
+                    plane_fetch<NL>(zin + 1, D, H, W, X0, Y0, fetch, regs);   // next plane in flight during this plane's passes
+                    plane_window_sums<R, NF, NL>(cur, expand, raw, xs, P);
+                } else {                     // planes outside the volume are zero padding
+                    plane_fetch<NL>(zin + 1, D, H, W, X0, Y0, fetch, regs);
+#pragma unroll
+                    for (int f = 0; f < NF; f++) P[f] = 0.f;
+                }
 #pragma unroll
                 for (int f = 0; f < NF; f++) {
                     if (k == 0) {   // once per ring turn: exact re-summation instead of the running update
@@ -144,12 +175,12 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_fields_kernel(const float *__r
     float lsum = 0.f;
     constexpr int FS = kLRows * kLCols;
     // the 5 product fields are formed while the tile is copied to LDS: the window passes then only add
-    auto load = [&](float *cell, int z, int gy, int gx, bool inb) {
-        float i = 0.f, j = 0.f;
-        if (inb) {
-            const size_t o = ((size_t)z * H + gy) * W + gx;
-            i = I[o]; j = J[o];
-        }
+    auto fetch = [&](int z, int gy, int gx, float (&o)[2]) {
+        const size_t off = ((size_t)z * H + gy) * W + gx;
+        o[0] = I[off]; o[1] = J[off];
+    };
+    auto expand = [&](float *cell, const float (&in)[2]) {
+        const float i = in[0], j = in[1];
         cell[0] = i; cell[FS] = j; cell[2 * FS] = i * i; cell[3 * FS] = j * j; cell[4 * FS] = i * j;
     };
     auto emit = [&](int z, const float (&Z)[5]) {
@@ -162,9 +193,16 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_fields_kernel(const float *__r
         const size_t o = ((size_t)z * H + y) * W + x;
         F[o] = Pq; F[n + o] = Pq * (Is * inv_n); F[2 * n + o] = Qq; F[3 * n + o] = Qq * (Js * inv_n);
     };
-    column_walk<R, 5>(nd, D, H, W, X0, Y0, z0, z1, load, emit, raw, xs);
-    float v[1] = {lsum};
-    block_reduce_store<1>(v, partials + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    column_walk<R, 5, 2>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, emit, raw, xs);
+    // block sum of the cc partials in a fixed order: butterfly inside each wave, then the 4 wave sums through LDS
+    // (a generic block_reduce_store would add 16 KB of static LDS and halve the blocks per CU)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) lsum += __shfl_xor(lsum, m, 64);
+    __syncthreads();                       // the last plane's xs reads are done: reuse xs as scratch
+    float *ws = &xs[0][0][0];
+    if ((tid & 63) == 0) ws[tid >> 6] = lsum;
+    __syncthreads();
+    if (tid == 0) partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
 template <int R>
@@ -182,17 +220,21 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_grad_kernel(const float *__res
     const int tid = threadIdx.x, x = X0 + (tid & (kLX - 1)), y = Y0 + (tid >> 5);
     const bool live = (x < W) && (y < H);
     constexpr int FS = kLRows * kLCols;
-    auto load = [&](float *cell, int z, int gy, int gx, bool inb) {
-        const size_t o = inb ? ((size_t)z * H + gy) * W + gx : 0;
+    auto fetch = [&](int z, int gy, int gx, float (&o)[4]) {
+        const size_t off = ((size_t)z * H + gy) * W + gx;
 #pragma unroll
-        for (int f = 0; f < 4; f++) cell[f * FS] = inb ? F[(size_t)f * n + o] : 0.f;
+        for (int f = 0; f < 4; f++) o[f] = F[(size_t)f * n + off];
+    };
+    auto expand = [&](float *cell, const float (&in)[4]) {
+#pragma unroll
+        for (int f = 0; f < 4; f++) cell[f * FS] = in[f];
     };
     auto emit = [&](int z, const float (&Z)[4]) {
         if (!live) return;
         const size_t o = ((size_t)z * H + y) * W + x;
         G[o] = scale * (I[o] * Z[0] - Z[1] - J[o] * Z[2] + Z[3]);
     };
-    column_walk<R, 4>(nd, D, H, W, X0, Y0, z0, z1, load, emit, raw, xs);
+    column_walk<R, 4, 4>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, emit, raw, xs);
 }
 
 // loss[b] = alpha * (1 - sum(partials) / N), partials reduced in fp64 in a fixed order
