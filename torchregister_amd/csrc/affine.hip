@@ -167,17 +167,18 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
 }
 
 // ------------------------------------------------------------------------------------------
-// LDS-tiled 3-D variant of the F1 pass (the fast path for near-identity transforms).
+// LDS-tiled 3-D variant of the F1 pass (the path the headline number runs).
 //
-// A 256-thread block owns output tiles of 32(x) x 16(y) x 8(z) voxels.  The pre-image of a tile
-// under the affine map is a small parallelepiped; its bounding box (x origin aligned to 4 voxels)
-// is staged once into LDS with coalesced 16-byte loads (zero-filled outside the volume, which IS
-// grid_sample's zero padding), then all 8-corner gathers are ds_read2_b32 from LDS with
-// compile-time strides and no bounds checks.  Tiles whose box exceeds the LDS budget (large
-// rotations / zoom-out), or volumes with W % 4 != 0, take the global-gather path (sample3) inside
-// the same kernel, so results never depend on which path ran beyond fp32 rounding.
-// Blocks are persistent over a contiguous run of tiles of ONE pair and keep the 41 partial sums
-// in registers; thread (x, z) is fixed inside a tile so the xn / zn columns fold once per tile.
+// A block owns one (32 x, 8 z) COLUMN of the volume and walks it along y in tiles of 16 rows.  The pre-image
+// of a tile under the affine map is a small parallelepiped; its bounding box (x origin aligned to 4 voxels)
+// is staged into LDS by LDS-DMA (global_load_lds_dwordx4, masked to the needed, in-volume float4 slots; cells
+// outside the volume are zero-filled, which IS grid_sample's zero padding), then all 8-corner gathers are
+// ds_read2_b32 from LDS with fixed strides and no bounds checks.  Full tiles whose box fits run in the fast
+// loop; partial tiles, tiles whose box exceeds the LDS budget (large rotations / zoom-out) and the one tile per
+// pair that holds the volume's last row when W % 4 != 0 run in the generic loop behind it, which also holds
+// the global-gather fallback - results never depend on which path ran beyond fp32 rounding.
+// Thread (x, z) is fixed for the whole column, so only sum(q grad) and sum(q grad yn) live in registers and
+// the xn / zn columns of the 41 sums are one multiply at the very end.
 // ------------------------------------------------------------------------------------------
 #ifndef TRX_TILE_CFG
 #define TRX_TILE_CFG 0
