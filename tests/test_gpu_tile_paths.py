@@ -125,3 +125,18 @@ def test_partial_x_tiles_identity_mse(eng, shape):
         torch.cuda.synchronize()
         ref = ((mov.double() - tgt.double()) ** 2).mean(dim=(1, 2, 3, 4)).numpy()
         assert np.allclose(s.losses[:, 0].cpu().numpy(), ref, rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("shape", [(24, 48, 38), (17, 35, 70), (40, 32, 33)])
+def test_forward_warp_rows_not_multiple_of_4(eng, shape):
+    """Forward warp through the tile kernel (MODE 3) when W % 4 != 0, two channels (the float4 straddling x = W is
+    fetched whole and its tail zeroed; the last row of the LAST channel must not be over-read): vs the C oracle in fp64,
+    including a theta that puts samples on and beyond the +x face."""
+    x = torch.cat([ph.blobs(shape, 90) + 0.1 * ph.vol(shape, 0.013, "sin"), ph.vol(shape, 0.23, "cos")], dim=1)
+    for th64 in (generic(THETAS["star"]), generic(rot_theta(0.03, -0.02, 0.05, (1.2, 1.1, 1.15), (0.1, -0.05, 0.02)))):
+        th = torch.tensor(th64, dtype=torch.float32)[None]
+        w = eng.affine_warp(th.cuda(), x.cuda()).cpu().numpy()
+        for c in range(2):
+            r64 = oracle.c_affine_warp(x[0, c].double().numpy(), th[0].double().numpy(), oracle.base_tables(shape, np.float64))
+            r32 = oracle.c_affine_warp(x[0, c].numpy(), th[0].numpy(), oracle.base_tables(shape, np.float32))
+            assert np.max(np.abs(w[0, c] - r32)) <= max(2e-6, 2.0 * np.max(np.abs(r32 - r64)))   # fp32 floor, as in test_gpu_affine.py
