@@ -15,3 +15,11 @@ def test_random_sweep():
     import fuzz_affine
     fails, worst = fuzz_affine.run(60, 2024, grad_bar=3e-4, verbose=True)
     assert fails == 0, worst
+
+
+def test_random_sweep_flow_and_local_ncc():
+    """Dense-flow loss + dL/dflow vs the C oracle, local-window NCC loss + gradient vs its torch-conv specification:
+    random 2-D / 3-D shapes, flow amplitudes 0.3 .. 6 voxels, windows 3..9, batches (tools/fuzz_flow_lncc.py)."""
+    import fuzz_flow_lncc
+    fails, worst = fuzz_flow_lncc.run(40, 11, verbose=True)
+    assert fails == 0, worst

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the dense-flow loss/gradient kernels (vs the C oracle in fp64) and of the local-window NCC
+extension (vs its torch-conv specification in fp64).   python tools/fuzz_flow_lncc.py [cases] [seed]"""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle
+from oracle import compose
+import phantoms as ph
+import torchregister_amd._engine as eng
+from fuzz_affine import smooth
+
+
+def smooth_nd(shape, f):
+    if len(shape) == 3:
+        return smooth(shape, f)
+    ax = [torch.arange(n, dtype=torch.float64) for n in shape]
+    return (torch.sin(f * ax[0])[:, None] + torch.cos(1.3 * f * ax[1] + 0.5)[None, :]).float().view(1, 1, *shape)
+
+
+def run(n, seed, verbose=True):
+    rng = np.random.default_rng(seed)
+    fails = 0
+    worst = {"flow_loss": 0.0, "flow_grad": 0.0, "lncc_loss": 0.0, "lncc_grad": 0.0}
+    for it in range(n):
+        nd = 3 if rng.random() < 0.7 else 2
+        shape = tuple(int(v) for v in rng.integers(3, 40 if nd == 3 else 90, nd))
+        tgt = ph.blobs(shape, 300 + it) + 0.05 * smooth_nd(shape, 0.31)
+        mov = ph.blobs(shape, 700 + it) + 0.1 * smooth_nd(shape, 0.23)
+        amp = float(rng.choice([0.3, 1.5, 6.0]))
+        flow = torch.tensor(amp * rng.standard_normal((1, nd) + shape), dtype=torch.float32)
+        flow = flow + 0.37          # keep samples off exact voxel positions
+        kw = dict(w_ncc=float(rng.uniform(0, 1)), w_mse=float(rng.uniform(0, 1)))
+        terms, dfl = eng.flow_loss_grad(mov.cuda(), tgt.cuda(), flow.cuda(), eng.LossSpec(**kw))
+        args = lambda dt: (mov[0, 0].numpy().astype(dt), tgt[0, 0].numpy().astype(dt), flow[0].numpy().astype(dt), oracle.wts(**kw))
+        t64, _, d64, _ = oracle.c_flow_loss_grad(*args(np.float64))
+        t32, _, d32, _ = oracle.c_flow_loss_grad(*args(np.float32))
+        el = abs(terms[0, 0].item() - t64) / max(1.0, abs(t64))
+        gmax = max(np.max(np.abs(d64)), 1e-12)
+        eg = np.max(np.abs(dfl[0].cpu().numpy() - d64)) / gmax
+        gbar = max(2e-4, 2.0 * np.max(np.abs(d32 - d64)) / gmax)
+        worst["flow_loss"] = max(worst["flow_loss"], el); worst["flow_grad"] = max(worst["flow_grad"], eg / gbar)
+        bad = el > 2e-5 or eg > gbar
+        # local NCC on (target, warped)
+        win = int(rng.choice([3, 5, 7, 9]))
+        B = int(rng.integers(1, 3))
+        y = torch.cat([tgt] * B); w = torch.cat([mov + 0.01 * b for b in range(B)])
+        loss, grad = eng.local_ncc_loss_grad(y.cuda(), w.cuda(), win, 1.7)
+        w64 = w.double().requires_grad_()
+        l64 = sum(compose.local_ncc_loss(y[b:b + 1].double(), w64[b:b + 1], win, 1.7) for b in range(B))
+        (g64,) = torch.autograd.grad(l64, w64)
+        w32 = w.clone().requires_grad_()
+        l32 = sum(compose.local_ncc_loss(y[b:b + 1], w32[b:b + 1], win, 1.7) for b in range(B))
+        (g32,) = torch.autograd.grad(l32, w32)
+        ell = abs(loss.sum().item() - l64.item()) / max(1.0, abs(l64.item()))
+        lbar = max(2e-5, 2.0 * abs(l32.item() - l64.item()) / max(1.0, abs(l64.item())))
+        gm = max(g64.abs().max().item(), 1e-12)
+        egl = (grad.cpu().double() - g64).abs().max().item() / gm
+        glbar = max(2e-4, 2.0 * (g32.double() - g64).abs().max().item() / gm)
+        worst["lncc_loss"] = max(worst["lncc_loss"], ell / lbar); worst["lncc_grad"] = max(worst["lncc_grad"], egl / glbar)
+        bad = bad or ell > lbar or egl > glbar
+        if bad:
+            fails += 1
+            if verbose:
+                print(f"FAIL case {it}: shape {shape} amp {amp} kw {kw} win {win} B {B}: flow loss {el:.2e} grad {eg:.2e}/{gbar:.2e}; lncc loss {ell:.2e}/{lbar:.2e} grad {egl:.2e}/{glbar:.2e}")
+    if verbose:
+        print(f"{n} cases, {fails} failures; worst (error / bar): {worst}")
+    return fails, worst
+
+
+if __name__ == "__main__":
+    f, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    sys.exit(1 if f else 0)
