@@ -215,12 +215,32 @@ static TileGeom tile_geom(const trx_volumes &v)
     TileGeom t;
     t.ntx = (v.W + kTX - 1) / kTX; t.nty = (v.H + kTY - 1) / kTY; t.ntz = (v.D + kTZ - 1) / kTZ;
     t.ntiles = t.ntx * t.nty * t.ntz;
-    // one block per (x-tile, z-tile) column walking y; small batches split every column into y segments
-    // so that at least ~512 blocks (one round of 2 blocks on each of 256 CUs) exist: measured best for 1-2 pairs of
-    // 128^3 / 256^3 (kbench sweep: 1 x 256^3 47 us at 512 blocks, 53 us at 1024, 64 us at 2048)
+    // One block per (x-tile, z-tile) column walking y; columns are split into y segments where that fills the chip better
+    // (512 block slots: 2 blocks on each of 256 CUs).  Measured with tools/kbench.hip (TRX_TILE_TARGET_BLOCKS sweeps):
+    //  - few columns (<= 512 blocks): one round of ~512 blocks, but at least 2 tiles per block
+    //    (1 x 256^3: 47 us at 512 blocks, 53 at 256 and 1024; 1 x 128^3: 12.1 us at 256 blocks x 2 tiles, 13.6 at 512 x 1);
+    //  - many columns: the split (1..4) that minimises  (slot rounds * 512 / blocks) * (1 + 1.5 / tiles per block)  - the
+    //    idle tail of the last round against the per-block prologue / epilogue (8 x 182^3: 181 us unsplit, 173 us split in 2).
     const int ncol = t.ntx * t.ntz;
-    static const int target = [] { const char *e = getenv("TRX_TILE_TARGET_BLOCKS"); return e ? atoi(e) : 512; }();   // development knob; 512 = one round of 2 blocks on each of the 256 CUs
-    int ys = (target + v.B * ncol - 1) / (v.B * ncol);
+    static const int target = [] { const char *e = getenv("TRX_TILE_TARGET_BLOCKS"); return e ? atoi(e) : 0; }();   // development override
+    const long cols = (long)v.B * ncol;
+    int ys = 1;
+    if (target > 0) {
+        ys = (int)((target + cols - 1) / cols);
+    } else if (cols <= 512) {
+        ys = (int)((512 + cols - 1) / cols);
+        const int cap = t.nty / 2 > 1 ? t.nty / 2 : 1;
+        if (ys > cap && cols * cap >= 256) ys = cap;   // (tiny volumes: as many blocks as there are tiles - 1 x 64^3: 8.9 vs 12.1 us)
+    } else {
+        double best = 1e30;
+        for (int c = 1; c <= 4 && c <= t.nty; c++) {
+            const int tps = (t.nty + c - 1) / c, segs = (t.nty + tps - 1) / tps;
+            const double blocks = (double)cols * segs;
+            const double rounds = (double)(((long)blocks + 511) / 512);
+            const double waste = rounds * 512.0 / blocks * (1.0 + 1.5 / tps);
+            if (waste < best - 1e-9) { best = waste; ys = c; }
+        }
+    }
     if (ys < 1) ys = 1;
     if (ys > t.nty) ys = t.nty;
     t.tiles_per_seg = (t.nty + ys - 1) / ys;
