@@ -264,6 +264,12 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #ifndef TRX_DMA_SPREAD
 #define TRX_DMA_SPREAD 1   // cfg 1: issue the next tile's DMA pieces between the rows of the gather (0: all at once before it)
 #endif
+#ifndef TRX_TGT_POLICY
+#define TRX_TGT_POLICY ""   // cache policy suffix of the target loads (development)
+#endif
+#ifndef TRX_BOX_POLICY
+#define TRX_BOX_POLICY ""   // cache policy suffix of the box DMA (development: " nt", " sc1")
+#endif
 #ifndef TRX_STAGE_PRIO
 #define TRX_STAGE_PRIO 3
 #endif
@@ -589,14 +595,14 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     "s_addc_u32 s101, s101, 0\n\t"                       \
     "s_add_u32 m0, m0, %[pstr]\n\t"                      \
     "s_mov_b64 exec, %[k" #K "]\n\t"                     \
-    "global_load_lds_dwordx4 %[off], s[100:101]\n\t"
+    "global_load_lds_dwordx4 %[off], s[100:101]" TRX_BOX_POLICY "\n\t"
 #define TRX_DMA_HEAD                                     \
     "s_mov_b64 %[sv], exec\n\t"                          \
     "s_mov_b32 %[m0s], m0\n\t"                           \
     "s_mov_b64 s[100:101], %[base]\n\t"                  \
     "s_mov_b32 m0, %[lds]\n\t"                           \
     "s_mov_b64 exec, %[k0]\n\t"                          \
-    "global_load_lds_dwordx4 %[off], s[100:101]\n\t"     \
+    "global_load_lds_dwordx4 %[off], s[100:101]" TRX_BOX_POLICY "\n\t"     \
     TRX_DMA_NEXT(1) TRX_DMA_NEXT(2) TRX_DMA_NEXT(3) TRX_DMA_NEXT(4) TRX_DMA_NEXT(5)
 #define TRX_DMA_TAIL "s_mov_b64 exec, %[sv]\n\t" "s_mov_b32 m0, %[m0s]"
                   if constexpr (kPieces == 7) {
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
 #pragma unroll
               for (int j = 0; j < kRows; j++) {
                   if (TRX_DBG_SKIP == 3 || MODE == 3) tv[j] = 1.f;
-                  else asm volatile("global_load_dword %0, %1, %2" : "=v"(tv[j]) : "v"(toffb), "s"(trow + (size_t)j * W) : "memory");
+                  else asm volatile("global_load_dword %0, %1, %2" TRX_TGT_POLICY : "=v"(tv[j]) : "v"(toffb), "s"(trow + (size_t)j * W) : "memory");
               }
           };
           float tv[kRows];
