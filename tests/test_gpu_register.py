@@ -221,3 +221,35 @@ def test_register_fully_default_criterion_with_nmi(tr, trajectories):
     mine = reg.losses.cpu().numpy().ravel()
     assert np.max(np.abs(mine - gl)) <= 2e-3 * np.max(np.abs(gl)), (mine, gl)
     assert np.max(np.abs(reg.theta.cpu().numpy() - g[f"{name}/best_theta"])) <= 2e-3
+
+
+def test_readme_pipeline_rigid_affine_flow():
+    """The usage of ref:README.md:58-83 through the drop-in import name: rigid -> affine -> flow, each stage registering the
+    previous stage's warp (`reg(moving)`), default criterion (MSE + NCC + NMI weights, ref:torchregister.py:52-60) for the
+    parametric stages.  Checks the plumbing end to end: every stage lowers the mismatch to the target."""
+    import TorchRegister as tr
+    shape = (40, 48, 44)
+    target = ph.blobs(shape, 77).cuda()
+    th = torch.tensor([[0.98, -0.06, 0.03, 0.04], [0.07, 1.03, -0.02, -0.03], [-0.02, 0.03, 0.97, 0.02]])
+    moving = tr.get_affine_warp(th[None].cuda(), target) + 0.0
+
+    def mismatch(x):
+        return torch.mean((x - target) ** 2).item()
+
+    m0 = mismatch(moving)
+    torch.manual_seed(3)
+    warping = tr.Register(mode='rigid', device='cuda', debug=False, init=torch.zeros(6))
+    warping.optim(moving, target, max_epochs=60, lr=2e-3)
+    warped1 = warping(moving)
+    assert warped1.shape == moving.shape and mismatch(warped1) < m0
+    warping = tr.Register(mode='affine', device='cuda', debug=False)
+    warping.optim(warped1.detach(), target, max_epochs=60, lr=2e-3)
+    warped2 = warping(warped1.detach())
+    assert mismatch(warped2) < mismatch(warped1)
+    assert tuple(warping.theta.shape) == (1, 3, 4)
+    warping = tr.Register(mode='flow', device='cuda', debug=False, criterion=[tr.NCCLoss()], weight=[1.0], flow_model='direct')
+    warping.optim(warped2.detach(), target, lr=2.0, max_epochs=60)
+    warped3 = warping(warped2.detach())
+    assert mismatch(warped3) < mismatch(warped2)
+    assert tuple(warping.theta.shape) == (1, 3, *shape)          # the flow field, voxel units (ref:README.md:80)
+    assert torch.isfinite(tr.norm(torch.abs(warping.theta))).all()
