@@ -186,6 +186,17 @@ size_t trx_lncc_workspace_bytes(int ndim, int B, int D, int H, int W);
 int trx_lncc_loss_grad(const float *target, const float *warped, int ndim, int B, int D, int H, int W, int window, float alpha,
                        float eps, float *loss, float *grad, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Parzen-window PDF of the reference's NMI loss (ref:utils.py:18-37 K_gauss / PDF_xis / PDF).
+ * signals [N][S], xis [N][bins] (bins <= 1024), h > 0:
+ *   pdf[n][k] = (1/h) * mean_i K((signals[n][i] - xis[n][k]) / h),  K(u) = exp(-u*u/2) / (2 pi)   (the reference's constant)
+ * trx_kde_pdf_backward: grad_signals[n][i] = sum_k grad_pdf[n][k] * d pdf[n][k] / d signals[n][i]  (xis carry no gradient:
+ * the reference builds them from .item() values, ref:utils.py:40-48).  No [N][S][bins] tensor is ever formed. */
+size_t trx_kde_workspace_bytes(int N, long S, int bins);
+int trx_kde_pdf(const float *signals, const float *xis, int N, long S, int bins, float h, float *pdf, void *workspace,
+                size_t workspace_bytes, void *stream);
+int trx_kde_pdf_backward(const float *signals, const float *xis, const float *grad_pdf, int N, long S, int bins, float h,
+                         float *grad_signals, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,66 @@
+"""GPU parity of the Parzen-window PDF kernels (trx_kde_pdf / trx_kde_pdf_backward) that stand in for the reference's
+PDF_xis (ref:utils.py:24-30) inside NMI: against the reference's own formulation (the [N, S, bins] difference tensor)
+evaluated with torch in fp64 on the CPU; bar = max(floor, 2 x the fp32 run's own gap).  Floors: pdf 2e-6 rel (fp32 sums of thousands of exp2 terms), gradient
+1e-5 of max."""
+import numpy as np
+import pytest
+import torch
+
+import phantoms as ph
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_pdf(signals, xis, h):
+    diff = signals.unsqueeze(-1) - xis.unsqueeze(1)
+    return (1 / h) * torch.mean((1 / (2 * torch.pi)) * torch.exp(-((diff / h) ** 2) / 2), dim=1)
+
+
+@pytest.mark.parametrize("N,S,bins,h", [(1, 1000, 256, 3.0), (3, 4096 + 17, 256, 0.1), (2, 30000, 64, 0.5), (8, 5000, 256, 3.0), (1, 7, 5, 1.0)])
+def test_kde_pdf_forward_backward(N, S, bins, h):
+    import torchregister_amd.utils as U
+    g = torch.Generator().manual_seed(S + bins)
+    sig = torch.rand(N, S, generator=g) * 1.5 - 0.2
+    hi, lo = sig.max().item(), sig.min().item()
+    xis = torch.linspace(hi, lo, bins).repeat(N, 1)
+    wts = torch.rand(N, bins, generator=g) - 0.3          # arbitrary downstream gradient
+    outs = {}
+    for dt in (torch.float32, torch.float64):
+        s = sig.detach().clone().to(dt).requires_grad_()
+        p = _ref_pdf(s, xis.to(dt), h)
+        (p * wts.to(dt)).sum().backward()
+        outs[dt] = (p.detach().numpy(), s.grad.numpy())
+    sc = sig.detach().clone().cuda().requires_grad_()
+    pc = U.PDF_xis(sc, xis.cuda(), h)
+    (pc * wts.cuda()).sum().backward()
+    p32, g32 = outs[torch.float32]
+    p64, g64 = outs[torch.float64]
+    ep, bp = np.max(np.abs(pc.detach().cpu().numpy() - p64)), max(2e-6 * np.max(np.abs(p64)), 2 * np.max(np.abs(p32 - p64)))
+    eg, bg = np.max(np.abs(sc.grad.cpu().numpy() - g64)), max(1e-5 * np.max(np.abs(g64)), 2 * np.max(np.abs(g32 - g64)))
+    assert ep <= bp, (ep, bp)
+    assert eg <= bg, (eg, bg)
+
+
+def test_nmi_loss_matches_torch_formulation():
+    """NMILoss (ref:utils.py:224-259) on 2-D images: the HIP-backed PDF inside NMI vs the all-torch formulation in fp64."""
+    import torchregister_amd.utils as U
+    shape = (64, 80)
+    y = ph.blobs(shape, 5)
+    yp = (ph.blobs(shape, 6) + 0.1 * ph.vol(shape, 0.37, "sin")).requires_grad_()
+    crit = U.NMILoss()
+    # reference formulation on the CPU (PDF_xis takes the torch branch for CPU tensors) in fp64 and in fp32: |NMI - 1| * 1000 of
+    # the nearly flat PDFs that bandwidth 3 produces is ill-conditioned, the fp32 run's own gap sets the bar
+    refs = {}
+    for dt in (torch.float32, torch.float64):
+        ypr = yp.detach().to(dt).clone().requires_grad_()
+        r = crit(y.to(dt), ypr)
+        r.backward()
+        refs[dt] = (r.item(), ypr.grad.double())
+    ypc = yp.detach().cuda().requires_grad_()
+    got = crit(y.cuda(), ypc)
+    got.backward()
+    l32, g32 = refs[torch.float32]
+    l64, g64 = refs[torch.float64]
+    assert abs(got.item() - l64) <= max(1e-5 * abs(l64), 2 * abs(l32 - l64)), (got.item(), l32, l64)
+    gmax = g64.abs().max().item()
+    assert (ypc.grad.cpu().double() - g64).abs().max().item() <= max(1e-4 * gmax, 2 * (g32 - g64).abs().max().item())

@@ -478,3 +478,31 @@ def local_ncc_loss_grad(target, warped, window=9, alpha=1.0, eps=1e-5, need_grad
     _lib.check(rc, "trx_lncc_loss_grad")
     return loss, grad
 
+
+def kde_pdf(signals, xis, h):
+    """Parzen-window PDF (include/trx.h: trx_kde_pdf): signals [N,S], xis [N,bins] fp32 on the GPU -> pdf [N,bins]."""
+    lib = _lib.load()
+    if not (signals.is_cuda and xis.is_cuda):
+        raise _lib.TrxError("kde_pdf needs CUDA (HIP) tensors: there is no CPU fallback")
+    sig, x = signals.detach().contiguous().float(), xis.detach().contiguous().float()
+    N, S = sig.shape
+    bins = x.shape[1]
+    pdf = torch.empty(N, bins, device=sig.device)
+    ws_bytes = lib.trx_kde_workspace_bytes(N, S, bins)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=sig.device)
+    with torch.cuda.device(sig.device):
+        rc = lib.trx_kde_pdf(_lib.ptr(sig), _lib.ptr(x), N, S, bins, float(h), _lib.ptr(pdf), _lib.ptr(ws), ws_bytes, _lib.current_stream(sig.device))
+    _lib.check(rc, "trx_kde_pdf")
+    return pdf
+
+
+def kde_pdf_backward(signals, xis, grad_pdf, h):
+    lib = _lib.load()
+    sig, x, g = signals.detach().contiguous().float(), xis.detach().contiguous().float(), grad_pdf.contiguous().float()
+    N, S = sig.shape
+    out = torch.empty_like(sig)
+    with torch.cuda.device(sig.device):
+        rc = lib.trx_kde_pdf_backward(_lib.ptr(sig), _lib.ptr(x), _lib.ptr(g), N, S, x.shape[1], float(h), _lib.ptr(out), _lib.current_stream(sig.device))
+    _lib.check(rc, "trx_kde_pdf_backward")
+    return out
+

@@ -1,0 +1,129 @@
+// Parzen-window (KDE) marginal "PDF" of the reference's NMI loss as two HIP kernels:
+//   pdf[n][k] = (1/h) * mean_i K((s[n][i] - x[n][k]) / h),   K(u) = exp(-u^2 / 2) / (2 pi)        (ref:utils.py:18-37;
+// the 1/(2 pi) instead of 1/sqrt(2 pi) is the reference's), and its backward wrt the samples.  The reference evaluates
+// this by materialising the [N, S, bins] difference tensor (8 GB for its own 3-D setting of 8 patches x 100^3 samples
+// x 256 bins - SURVEY Q5: it cannot run there); here a block keeps a chunk of samples in LDS and thread k owns bin k.
+// Everything downstream of the PDFs (normalisation, entropies, NMI, |NMI - 1|) is tiny and stays in torch.
+// Bound: VALU (one exp per (sample, bin) pair: S * bins per PDF); bytes are negligible (4 B per sample).
+#include "trx_common.h"
+
+namespace trx {
+
+constexpr int kKdeChunk = 4096;   // samples per block (16 KB of LDS)
+
+// partial[n][chunk][k] = sum over the chunk of exp(-((s - x_k)/h)^2 / 2)
+__global__ __launch_bounds__(256) void kde_pdf_partial_kernel(const float *__restrict__ sig, const float *__restrict__ xis, long S, int bins, float inv_h,
+                                                              double *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) float s[kKdeChunk];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const long i0 = (long)chunk * kKdeChunk;
+    const int cnt = (int)min((long)kKdeChunk, S - i0);
+    const float *__restrict__ src = sig + (long)n * S + i0;
+    for (int i = tid; i < kKdeChunk; i += 256) s[i] = (i < cnt) ? src[i] : 0.f;
+    __syncthreads();
+    constexpr float kLog2e = 1.4426950408889634f;
+    for (int k = tid; k < bins; k += 256) {
+        const float x = xis[(long)n * bins + k];
+        // fp32 sums of 16 terms, carried in fp64 (fp64 adds are full rate on this part): the NMI downstream amplifies the
+        // relative error of these sums by ~10^4 (|NMI - 1| of nearly flat PDFs), a plain fp32 running sum is not enough
+        double acc = 0.0;
+        const int c16 = cnt & ~15;
+        for (int i = 0; i < c16; i += 16) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(&s[i + j]);   // same address in every lane: LDS broadcast
+                const float u0 = (v.x - x) * inv_h, u1 = (v.y - x) * inv_h, u2 = (v.z - x) * inv_h, u3 = (v.w - x) * inv_h;
+                a0 += exp2f(-0.5f * kLog2e * u0 * u0); a1 += exp2f(-0.5f * kLog2e * u1 * u1);
+                a2 += exp2f(-0.5f * kLog2e * u2 * u2); a3 += exp2f(-0.5f * kLog2e * u3 * u3);
+            }
+            acc += (double)((a0 + a1) + (a2 + a3));
+        }
+        {
+            float a0 = 0.f;
+            for (int i = c16; i < cnt; i++) {
+                const float u = (s[i] - x) * inv_h;
+                a0 += exp2f(-0.5f * kLog2e * u * u);
+            }
+            acc += (double)a0;
+        }
+        partial[((long)n * gridDim.x + chunk) * bins + k] = acc;
+    }
+}
+
+// pdf[n][k] = scale * sum over chunks (fixed order, fp64)
+__global__ __launch_bounds__(256) void kde_pdf_finalize_kernel(const double *__restrict__ partial, int nchunk, int bins, double scale, float *__restrict__ pdf)
+{
+    const int n = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= bins) return;
+    double a = 0.0;
+    for (int c = 0; c < nchunk; c++) a += partial[((long)n * nchunk + c) * bins + k];
+    pdf[(long)n * bins + k] = (float)(a * scale);
+}
+
+// grad_s[n][i] = sum_k g[n][k] * d pdf[n][k] / d s[n][i] = scale * sum_k g_k * exp(-u^2/2) * (-u) / h,  u = (s_i - x_k) / h
+__global__ __launch_bounds__(256) void kde_pdf_backward_kernel(const float *__restrict__ sig, const float *__restrict__ xis, const float *__restrict__ gpdf, long S,
+                                                               int bins, float inv_h, float scale, float *__restrict__ gsig)
+{
+    __shared__ float xs[1024], gs[1024];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    for (int k = tid; k < bins; k += 256) { xs[k] = xis[(long)n * bins + k]; gs[k] = gpdf[(long)n * bins + k]; }
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + tid;
+    if (i >= S) return;
+    const float v = sig[(long)n * S + i];
+    constexpr float kLog2e = 1.4426950408889634f;
+    float a0 = 0.f, a1 = 0.f;
+    int k = 0;
+    for (; k + 1 < bins; k += 2) {
+        const float u0 = (v - xs[k]) * inv_h, u1 = (v - xs[k + 1]) * inv_h;
+        a0 = fmaf(gs[k] * u0, exp2f(-0.5f * kLog2e * u0 * u0), a0);
+        a1 = fmaf(gs[k + 1] * u1, exp2f(-0.5f * kLog2e * u1 * u1), a1);
+    }
+    if (k < bins) {
+        const float u0 = (v - xs[k]) * inv_h;
+        a0 = fmaf(gs[k] * u0, exp2f(-0.5f * kLog2e * u0 * u0), a0);
+    }
+    gsig[(long)n * S + i] = -scale * inv_h * (a0 + a1);
+}
+
+static int kde_nchunk(long S) { return (int)((S + kKdeChunk - 1) / kKdeChunk); }
+
+}  // namespace trx
+
+using namespace trx;
+
+extern "C" size_t trx_kde_workspace_bytes(int N, long S, int bins)
+{
+    if (N < 1 || S < 1 || bins < 1 || bins > 1024) return 0;
+    return (size_t)N * kde_nchunk(S) * bins * sizeof(double);
+}
+
+extern "C" int trx_kde_pdf(const float *signals, const float *xis, int N, long S, int bins, float h, float *pdf, void *workspace,
+                           size_t workspace_bytes, void *stream)
+{
+    if (!signals || !xis || !pdf || !workspace) return TRX_ERR_ARG;
+    if (N < 1 || N > 65535 || S < 1 || bins < 1 || bins > 1024 || !(h > 0.f)) return TRX_ERR_ARG;
+    if (workspace_bytes < trx_kde_workspace_bytes(N, S, bins)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = kde_nchunk(S);
+    hipLaunchKernelGGL(kde_pdf_partial_kernel, dim3(nchunk, N), dim3(256), 0, s, signals, xis, S, bins, 1.0f / h, (double *)workspace);
+    TRX_CHECK_LAUNCH();
+    const double scale = 1.0 / ((double)h * (double)S * 6.283185307179586);   // (1/h) * (1/S) * 1/(2 pi)
+    hipLaunchKernelGGL(kde_pdf_finalize_kernel, dim3((bins + 255) / 256, N), dim3(256), 0, s, (const double *)workspace, nchunk, bins, scale, pdf);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+extern "C" int trx_kde_pdf_backward(const float *signals, const float *xis, const float *grad_pdf, int N, long S, int bins, float h,
+                                    float *grad_signals, void *stream)
+{
+    if (!signals || !xis || !grad_pdf || !grad_signals) return TRX_ERR_ARG;
+    if (N < 1 || N > 65535 || S < 1 || bins < 1 || bins > 1024 || !(h > 0.f)) return TRX_ERR_ARG;
+    const float scale = (float)(1.0 / ((double)h * (double)S * 6.283185307179586));
+    hipLaunchKernelGGL(kde_pdf_backward_kernel, dim3((unsigned)((S + 255) / 256), N), dim3(256), 0, (hipStream_t)stream, signals, xis, grad_pdf, S, bins,
+                       1.0f / h, scale, grad_signals);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}

@@ -102,8 +102,26 @@ def K_gauss(input_):
     return (1 / (2 * torch.pi)) * torch.exp(-(input_ ** 2) / 2)
 
 
+class _KdePdfFn(torch.autograd.Function):
+    """PDF_xis on the GPU without the [N, S, bins] tensor (HIP kernels trx_kde_pdf / trx_kde_pdf_backward)."""
+
+    @staticmethod
+    def forward(ctx, signals, xis, h):
+        ctx.save_for_backward(signals, xis)
+        ctx.h = float(h)
+        return _engine.kde_pdf(signals, xis, h)
+
+    @staticmethod
+    def backward(ctx, g):
+        signals, xis = ctx.saved_tensors
+        gs = _engine.kde_pdf_backward(signals, xis, g, ctx.h) if ctx.needs_input_grad[0] else None
+        return gs, None, None
+
+
 def PDF_xis(signals, xis, h=3):
-    diff = signals.unsqueeze(-1) - xis.unsqueeze(1)          # [N, S, bins]
+    if signals.is_cuda and signals.dim() == 2 and xis.dim() == 2 and xis.shape[1] <= 1024 and signals.dtype == torch.float32:
+        return _KdePdfFn.apply(signals, xis, h)              # same numbers, 4 B per sample instead of 4 * bins
+    diff = signals.unsqueeze(-1) - xis.unsqueeze(1)          # [N, S, bins] (the reference's formulation)
     return (1 / h) * torch.mean(K_gauss(diff / h), dim=1)
 
 
