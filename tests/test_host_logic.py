@@ -88,6 +88,13 @@ def test_more_argument_validation_without_gpu():
     assert lib.trx_lncc_loss_grad(*args, 4, 1.0, 1e-5, P(16), P(16), P(16), n, None) == -1     # even window
     assert lib.trx_lncc_loss_grad(*args, 9, 1.0, 1e-5, None, None, P(16), n, None) == -1        # nothing to compute
     assert lib.trx_lncc_loss_grad(P(16), P(16), 5, 2, 8, 8, 8, 9, 1.0, 1e-5, P(16), P(16), P(16), n, None) == -2
+    # Parzen-window PDF kernels
+    assert lib.trx_kde_workspace_bytes(1, 1000, 2048) == 0                # more than 1024 bins
+    kn = lib.trx_kde_workspace_bytes(2, 10000, 256)
+    assert kn > 0
+    assert lib.trx_kde_pdf(P(16), P(16), 2, 10000, 256, 3.0, P(16), P(16), kn - 1, None) == -3
+    assert lib.trx_kde_pdf(P(16), P(16), 2, 10000, 256, 0.0, P(16), P(16), kn, None) == -1     # bandwidth must be positive
+    assert lib.trx_kde_pdf_backward(P(16), P(16), None, 2, 10000, 256, 3.0, P(16), None) == -1
     for code, word in ((-1, b"arg"), (-2, b"dim"), (-4, b"HIP"), (-5, b"loss-curve")):
         assert word.lower() in lib.trx_status_string(code).lower()
 
