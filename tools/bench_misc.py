@@ -44,3 +44,10 @@ for win in (9, 5):
 rep("local NCC w=9 loss only (1 pair)", timeit(lambda: eng.local_ncc_loss_grad(tgt, wrp, 9, need_grad=False)), 24 * N)
 tgt8, wrp8 = tgt.expand(8, 1, *shape).contiguous(), wrp.expand(8, 1, *shape).contiguous()
 rep("local NCC w=9 loss+grad (8 pairs)", timeit(lambda: eng.local_ncc_loss_grad(tgt8, wrp8, 9), 5), 52 * N * 8)
+# generic-path pieces: warp backward wrt theta from an arbitrary grad_out (row-walking gather kernel)
+go = torch.rand_like(mov)
+rep("affine_warp_backward (1 pair)", timeit(lambda: eng.affine_warp_backward(th, mov, go)), 12 * N)
+go8 = torch.rand_like(mov8)
+rep("affine_warp_backward (8 pairs)", timeit(lambda: eng.affine_warp_backward(th.expand(8, 3, 4).contiguous(), mov8, go8), 5), 12 * N * 8)
+fl1 = torch.zeros(1, 3, *shape, device=dev) + 0.3
+rep("flow_warp_backward (1 pair)", timeit(lambda: eng.flow_warp_backward(mov, fl1, go)), 36 * N)

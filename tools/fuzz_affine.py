@@ -52,7 +52,11 @@ def run(n, seed, grad_bar=2e-4, verbose=True):
         th = torch.tensor(ths, dtype=torch.float32)
         s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
         s.run(1)
-        wrp = eng.affine_warp(th.cuda(), mov.cuda()).cpu().numpy()
+        wrp_t = eng.affine_warp(th.cuda(), mov.cuda())
+        # generic warp backward (tile kernel MODE 2) with grad_out = dMSE/dwarped must reproduce the MSE gradient
+        go = 2.0 * (wrp_t - tgt.cuda()) / float(np.prod(shape))
+        dth_b = eng.affine_warp_backward(th.cuda(), mov.cuda(), go).cpu().numpy()
+        wrp = wrp_t.cpu().numpy()
         torch.cuda.synchronize()
         tabs64, tabs32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)
         for b in range(B):
@@ -68,11 +72,16 @@ def run(n, seed, grad_bar=2e-4, verbose=True):
             r64 = oracle.c_affine_warp(mov[b, 0].double().numpy(), tu, tabs64)
             r32 = oracle.c_affine_warp(mov[b, 0].numpy(), th[b].numpy(), tabs32)
             ew = np.max(np.abs(wrp[b, 0] - r32)); bw = max(2e-6, 3.0 * np.max(np.abs(r32 - r64)))   # 3x: random large theta (fixed cases: 2x)
-            worst["loss"] = max(worst["loss"], el); worst["grad"] = max(worst["grad"], eg); worst["warp"] = max(worst["warp"], ew / bw)
-            bad = el > 2e-5 or eg > grad_bar or ew > bw or not np.isfinite(loss)
+            _, _, dm64, _ = oracle.c_affine_loss_grad(mov[b, 0].double().numpy(), tgt[b, 0].double().numpy(), tu, oracle.wts(w_mse=1.0), tabs64)
+            _, _, dm32, _ = oracle.c_affine_loss_grad(mov[b, 0].numpy(), tgt[b, 0].numpy(), th[b].numpy(), oracle.wts(w_mse=1.0), tabs32)
+            mmax = max(np.max(np.abs(dm64)), 1e-12)
+            mbar = max(grad_bar, 2.0 * np.max(np.abs(dm32 - dm64)) / mmax)
+            eb = np.max(np.abs(dth_b[b] - dm64)) / mmax / mbar * grad_bar
+            worst["loss"] = max(worst["loss"], el); worst["grad"] = max(worst["grad"], eg, eb); worst["warp"] = max(worst["warp"], ew / bw)
+            bad = el > 2e-5 or eg > grad_bar or eb > grad_bar or ew > bw or not np.isfinite(loss)
             if bad:
                 fails += 1
-                if verbose: print(f"FAIL case {it} pair {b}: shape {shape} B {B} kind {kind} kw {kw} loss err {el:.2e} grad err {eg:.2e} warp err/bar {ew / bw:.2f}\n theta {tu.tolist()}")
+                if verbose: print(f"FAIL case {it} pair {b}: shape {shape} B {B} kind {kind} kw {kw} loss err {el:.2e} grad err {eg:.2e} bwd err {eb:.2e} warp err/bar {ew / bw:.2f}\n theta {tu.tolist()}")
     if verbose:
         print(f"{n} cases, {fails} failures; worst loss rel {worst['loss']:.2e} (bar 2e-5), grad rel-to-max {worst['grad']:.2e} (bar {grad_bar:.0e}), warp err/bar {worst['warp']:.2f}")
     return fails, worst

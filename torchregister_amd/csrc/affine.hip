@@ -285,6 +285,15 @@ struct F1Acc {
 template <int MODE>
 __device__ __forceinline__ void f1_accumulate_pk(const Samp3 &sm, float yv, float yn, F1Acc &a)
 {
+    if constexpr (MODE == 2) {   // generic warp backward: yv = grad_out of this voxel, only sum(go * grad) and sum(go * grad * yn)
+        const float gq[3] = {sm.dx, sm.dy, sm.dz};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const f2 gu = {gq[c], yn * gq[c]};
+            a.AB[0][c] = gu * yv + a.AB[0][c];
+        }
+        return;
+    }
     const f2 yw = {yv, sm.v};
     a.M01 += yw;
     a.M23 = yw * yw + a.M23;
@@ -363,23 +372,25 @@ template <int MODE>
 __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_kernel(trx_volumes vol, const float *__restrict__ theta,
                                                                                         TileGeom tg, int channels, float *__restrict__ partials)
 {
-    // MODE 0: F1 sums, MODE 1: moments only, MODE 3: forward warp (writes the warped volume to `partials`
-    // = out[B][channels][D][H][W]; blockIdx.y enumerates (pair, channel), channels share theta)
-    constexpr int NQ = (MODE == 0) ? 3 : 0;
-    constexpr int NP = (MODE == 0) ? np_full(3) : 5;
+    // MODE 0: F1 sums, MODE 1: moments only, MODE 2: generic warp backward (`vol.target` = grad_out [B][channels][D][H][W],
+    // 12 sums per (pair, channel)), MODE 3: forward warp (writes the warped volume to `partials` = out[B][channels][D][H][W])
+    constexpr int NQ = (MODE == 0) ? 3 : (MODE == 2 ? 1 : 0);
+    constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : 5);
+    constexpr bool kGrad = (MODE == 0) || (MODE == 2);
+    constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);   // blockIdx.y enumerates (pair, channel); channels share theta
 #ifdef TRX_LDS_PAD   // development: inflate the LDS footprint to force one block per CU
     __shared__ __attribute__((aligned(16))) float box[kBoxAlloc + TRX_LDS_PAD];
 #else
     __shared__ __attribute__((aligned(16))) float box[kBoxAlloc];
 #endif
-    const int b = (MODE == 3) ? blockIdx.y / channels : blockIdx.y;
-    const int ch = (MODE == 3) ? blockIdx.y - b * channels : 0;
+    const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
+    const int ch = kPerChannel ? blockIdx.y - b * channels : 0;
     const int D = vol.D, H = vol.H, W = vol.W;
     const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
     const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride + (size_t)ch * D * H * W;
     // MODE 3 has no target: `tgt` is the OUTPUT volume of this (pair, channel)
     float *__restrict__ wout = partials + (size_t)blockIdx.y * D * H * W;
-    const float *__restrict__ tgt = (MODE == 3) ? wout : vol.target + (size_t)b * vol.target_stride;
+    const float *__restrict__ tgt = (MODE == 3) ? wout : vol.target + (size_t)b * vol.target_stride + (MODE == 2 ? (size_t)ch * D * H * W : 0);
     const float *__restrict__ xtab = vol.xn, *__restrict__ ytab = vol.yn, *__restrict__ ztab = vol.zn;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform (SGPR)
@@ -694,7 +705,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                   Fetch nxt;
                   if (j + 1 < kRows) nxt = fetch(j + 1);
                   if (kBufs == 2 && j < kPieces && dma_next) issue_piece(j);
-                  const Samp3 sm = lerp3_pairs<MODE == 0>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
+                  const Samp3 sm = lerp3_pairs<kGrad>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
                   if constexpr (MODE == 3) { if (act) wout[(size_t)Y0 * W + (unsigned)(toff + j * W)] = sm.v; }
                   else f1_accumulate_pk<MODE>(sm, tv[j], yn_r[j], acc);
                   if (kBufs == 2 && TRX_DBG_SKIP != 3 && MODE != 3)
@@ -875,7 +886,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         const float *p = bp + a;
         const f2 r00 = *reinterpret_cast<const f2u *>(p), r01 = *reinterpret_cast<const f2u *>(p + kBW);
         const f2 r10 = *reinterpret_cast<const f2u *>(p + kBW * kBH), r11 = *reinterpret_cast<const f2u *>(p + kBW * kBH + kBW);
-        return lerp3_pairs<MODE == 0>(r00, r01, r10, r11, __builtin_amdgcn_fractf(ix), __builtin_amdgcn_fractf(iy), __builtin_amdgcn_fractf(iz));
+        return lerp3_pairs<kGrad>(r00, r01, r10, r11, __builtin_amdgcn_fractf(ix), __builtin_amdgcn_fractf(iy), __builtin_amdgcn_fractf(iz));
     };
 
     // ================= generic loop: partial last tile, tiles whose box does not fit, W % 4 != 0 =================
@@ -962,7 +973,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                 for (int j = j0; j < jend; j++) {
                     GFetch nxt = cur;
                     if (j + 1 < jend) nxt = gfetch(j + 1);
-                    const Samp3 sm = lerp3_pairs<MODE == 0>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
+                    const Samp3 sm = lerp3_pairs<kGrad>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
                     if constexpr (MODE == 3) wout[(size_t)Y0 * W + (unsigned)(toff + (j - j0) * W)] = sm.v;
                     else f1_accumulate_pk<MODE>(sm, cur.yv, cur.yn, acc);
                     cur = nxt;
@@ -973,8 +984,11 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
 
     if constexpr (MODE == 3) return;
     float vals[NP];
-    vals[0] = acc.M01.x; vals[1] = acc.M01.y; vals[2] = acc.M23.x; vals[3] = acc.M23.y; vals[4] = acc.M4;
-    int o = 5;
+    int o = 0;
+    if constexpr (MODE != 2) {
+        vals[0] = acc.M01.x; vals[1] = acc.M01.y; vals[2] = acc.M23.x; vals[3] = acc.M23.y; vals[4] = acc.M4;
+        o = 5;
+    }
 #pragma unroll
     for (int q = 0; q < NQ; q++)
 #pragma unroll
@@ -982,7 +996,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             const float a = acc.AB[q][c].x;
             vals[o++] = xn * a; vals[o++] = acc.AB[q][c].y; vals[o++] = zn * a; vals[o++] = a;
         }
-    block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)b * tg.blocks_per_pair + blockIdx.x) * NP, box);
+    block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)blockIdx.y * tg.blocks_per_pair + blockIdx.x) * NP, box);
 }
 
 #pragma clang diagnostic pop
@@ -1449,6 +1463,17 @@ extern "C" int trx_affine_warp_backward(const trx_volumes *vol, const float *the
     trx_volumes v = *vol;
     v.target = grad_out;
     v.target_stride = (size_t)channels * nvox;
+    if (use_tile_path(vol) && vol->xn && vol->yn && vol->zn && channels == 1) {
+        // LDS-tiled kernel (same staging as the F1 pass); one partial row per block, 12 sums each.  (Several channels or
+        // caller-less tables: the row-walking gather kernel below; the workspace is sized for single-channel tiles.)
+        TileGeom t = tile_geom(*vol);
+        hipLaunchKernelGGL((affine_tile_kernel<2>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
+        TRX_CHECK_LAUNCH();
+        hipLaunchKernelGGL((affine_bwd_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, t.blocks_per_pair, vol->D, vol->H,
+                           vol->W, dtheta);
+        TRX_CHECK_LAUNCH();
+        return TRX_OK;
+    }
     rc = launch_accum<2>(&v, theta, g, channels, nvox, partials, s);
     if (rc) return rc;
     if (vol->ndim == 3)
