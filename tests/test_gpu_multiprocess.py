@@ -51,3 +51,47 @@ def test_two_process_slabs_equal_whole_volume(optimizer, lr, smooth):
     for p in parts:
         assert torch.allclose(p["losses"], whole.losses.cpu(), rtol=1e-5, atol=1e-6)     # every rank records the whole-volume loss
     assert torch.max(torch.abs(flow - whole.flow.cpu())).item() <= 1e-5 * max(1.0, whole.flow.abs().max().item())
+
+
+def _pair_worker(rank, world, port, tmp, shape, total, iters):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import torch.distributed as dist
+    import phantoms as ph
+    import torchregister_amd as tr
+    from torchregister_amd import sharding
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    lo, hi = sharding.pair_range(rank, world, total)          # 5 pairs over 2 ranks: 3 + 2 (remainder on the first rank)
+    tgt = torch.cat([ph.blobs(shape, 60 + p) for p in range(lo, hi)]).cuda()
+    mov = torch.cat([ph.blobs(shape, 80 + p) for p in range(lo, hi)]).cuda()
+    s = tr.AffineSolver(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer="adam", lr=1e-3, capacity=iters)
+    s.run(iters)
+    theta, losses = sharding.gather_results(s.current_theta, s.losses[:, :iters])
+    t = sharding.max_over_ranks(0.5 + rank, torch.device("cuda", 0))
+    if rank == 0:
+        torch.save({"theta": theta.cpu(), "losses": losses.cpu(), "tmax": t}, os.path.join(tmp, "gathered.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pair_sharding_two_processes_equal_one_batch():
+    """The data-parallel path of bench.py / config 4: independent pairs sharded over ranks with NO data-path collective; the
+    gathered theta / loss curves of 2 ranks (3 + 2 pairs) are bitwise those of one process running all 5 pairs."""
+    import torch.multiprocessing as mp
+    import phantoms as ph
+    import torchregister_amd as tr
+    shape, total, iters = (24, 32, 40), 5, 8
+    tgt = torch.cat([ph.blobs(shape, 60 + p) for p in range(total)]).cuda()
+    mov = torch.cat([ph.blobs(shape, 80 + p) for p in range(total)]).cuda()
+    s = tr.AffineSolver(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer="adam", lr=1e-3, capacity=iters)
+    s.run(iters)
+    torch.cuda.synchronize()
+    with tempfile.TemporaryDirectory() as tmp:
+        port = 29900 + (os.getpid() % 90)
+        mp.spawn(_pair_worker, args=(2, port, tmp, shape, total, iters), nprocs=2, join=True)
+        got = torch.load(os.path.join(tmp, "gathered.pt"))
+    assert torch.equal(got["theta"], s.current_theta.cpu()) and torch.equal(got["losses"], s.losses[:, :iters].cpu())
+    assert got["tmax"] == 1.5
