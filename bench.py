@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--optimizer", default="adam", choices=["adam", "sgd"],
                     help="optimiser on theta for the headline number (north_star: Adam; the reference's own loop: SGD)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)           # tests: gloo
+    ap.add_argument("--single-device", action="store_true", help=argparse.SUPPRESS)  # tests: every rank on cuda:0
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(args.cpu_worker)
@@ -147,12 +149,17 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torchrun the RCCL path is exercised even with one rank
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     import torchregister_amd as tr
     mov, tgt = make_batch(rank, device, args.size)

@@ -95,3 +95,23 @@ def test_pair_sharding_two_processes_equal_one_batch():
         got = torch.load(os.path.join(tmp, "gathered.pt"))
     assert torch.equal(got["theta"], s.current_theta.cpu()) and torch.equal(got["losses"], s.losses[:, :iters].cpu())
     assert got["tmax"] == 1.5
+
+
+def test_bench_two_ranks_control_flow():
+    """bench.py's N > 1 control flow (rendezvous from the torchrun environment, barrier + max-over-ranks timing, whole-job
+    aggregate, ONE JSON line from rank 0) with two ranks on the one GPU over gloo; the driver runs the same code over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--size", "64", "--backend", "gloo", "--single-device", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["warmup"] == 2 and j["scaling"] == "weak" and j["higher_is_better"] is True
+    assert abs(j["value"] - 2 * 8 * 6 / (j["ms_per_step"] * 6e-3)) < 1e-6 * j["value"]      # whole-job aggregate over both ranks
+    assert "roofline" not in j and "cpu_baseline" not in j                                   # N = 1 only
