@@ -23,3 +23,11 @@ def test_random_sweep_flow_and_local_ncc():
     import fuzz_flow_lncc
     fails, worst = fuzz_flow_lncc.run(40, 11, verbose=True)
     assert fails == 0, worst
+
+
+def test_degenerate_shapes():
+    """Axes of 1..5 voxels in 2-D and 3-D through the affine step, the forward warp, the flow loss/gradient and the local NCC
+    (tools/fuzz_degenerate.py).  Two corners are outside the reference's domain and excluded there: a flow along an axis of
+    one voxel (the reference divides by S - 1) and the NCC of fewer than 8 voxels."""
+    import fuzz_degenerate
+    assert fuzz_degenerate.run(verbose=True) == 0
