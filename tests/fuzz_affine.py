@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the fused F1 step (and the forward warp) against the C oracle in fp64.
-   python tools/fuzz_affine.py [cases] [seed]
+   python tests/fuzz_affine.py [cases] [seed]
 Random shapes (tiny to ~100^3, ragged, W % 4 != 0), random theta (near identity ... large rotations / zoom / flips /
 mostly-out-of-bounds), random loss weights and batch sizes.  Tolerances as in tests/test_gpu_tile_paths.py."""
 import math, os, sys
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # test infrastructure: the oracle may only be used from tests/
 import oracle
 import phantoms as ph
 import torchregister_amd._engine as eng

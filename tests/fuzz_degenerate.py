@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Degenerate shapes (axes of 1..5 voxels, 2-D and 3-D) through the affine step, the forward warp, the flow loss/gradient and the
-local NCC: vs the C oracle / the torch specification in fp64.  python tools/fuzz_degenerate.py"""
+local NCC: vs the C oracle / the torch specification in fp64.  python tests/fuzz_degenerate.py"""
 import itertools, os, sys
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # test infrastructure: the oracle may only be used from tests/
 import oracle
 from oracle import compose
 import torchregister_amd._engine as eng

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the dense-flow loss/gradient kernels (vs the C oracle in fp64) and of the local-window NCC
-extension (vs its torch-conv specification in fp64).   python tools/fuzz_flow_lncc.py [cases] [seed]"""
+extension (vs its torch-conv specification in fp64).   python tests/fuzz_flow_lncc.py [cases] [seed]"""
 import os, sys
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # test infrastructure: the oracle may only be used from tests/
 import oracle
 from oracle import compose
 import phantoms as ph

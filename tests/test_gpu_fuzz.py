@@ -1,4 +1,4 @@
-"""Randomised parity sweep of the fused affine step and the forward warp (tools/fuzz_affine.py): random ragged shapes
+"""Randomised parity sweep of the fused affine step and the forward warp (tests/fuzz_affine.py): random ragged shapes
 (3..99 per axis, W % 4 != 0 included), batches of 1-3 pairs, theta from near-identity to large rotations / zoom / flips,
 random MSE + NCC weights; checker = the C oracle in fp64 (gradient bar 3e-4 of max or twice the fp32 oracle's own gap:
 random large rotations sit a little above the 2e-4 floor of the fixed cases; 1 of 400 cases reached 2.7e-4)."""
@@ -8,7 +8,7 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_random_sweep():
@@ -19,7 +19,7 @@ def test_random_sweep():
 
 def test_random_sweep_flow_and_local_ncc():
     """Dense-flow loss + dL/dflow vs the C oracle, local-window NCC loss + gradient vs its torch-conv specification:
-    random 2-D / 3-D shapes, flow amplitudes 0.3 .. 6 voxels, windows 3..9, batches (tools/fuzz_flow_lncc.py)."""
+    random 2-D / 3-D shapes, flow amplitudes 0.3 .. 6 voxels, windows 3..9, batches (tests/fuzz_flow_lncc.py)."""
     import fuzz_flow_lncc
     fails, worst = fuzz_flow_lncc.run(40, 11, verbose=True)
     assert fails == 0, worst
@@ -27,7 +27,7 @@ def test_random_sweep_flow_and_local_ncc():
 
 def test_degenerate_shapes():
     """Axes of 1..5 voxels in 2-D and 3-D through the affine step, the forward warp, the flow loss/gradient and the local NCC
-    (tools/fuzz_degenerate.py).  Two corners are outside the reference's domain and excluded there: a flow along an axis of
+    (tests/fuzz_degenerate.py).  Two corners are outside the reference's domain and excluded there: a flow along an axis of
     one voxel (the reference divides by S - 1) and the NCC of fewer than 8 voxels."""
     import fuzz_degenerate
     assert fuzz_degenerate.run(verbose=True) == 0
