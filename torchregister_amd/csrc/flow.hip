@@ -109,12 +109,22 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
     __shared__ double acc[16][8];
     const int b = blockIdx.x, tid = threadIdx.x, k = tid & 7, grp = tid >> 3;  // 128 groups of 8
     double s = 0.0;
-    for (int blk = grp; blk < nblk; blk += 128) s += (double)partials[((size_t)b * nblk + blk) * kFlowNP + k];
+    // batches of 8 independent loads (all in flight together), fixed summation order
+    for (int blk0 = grp; blk0 < nblk; blk0 += 8 * 128) {
+        float a[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int blk = blk0 + i * 128;
+            a[i] = (blk < nblk) ? partials[((size_t)b * nblk + blk) * kFlowNP + k] : 0.f;
+        }
+        s += (((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) + (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]));
+    }
     // reduce the 128 groups: lanes k, k+8, ... hold the same component
     for (int off = 32; off >= 8; off >>= 1) s += __shfl_down(s, off);
     if ((tid & 63) < 8) acc[tid >> 6][k] = s;
     __syncthreads();
     if (tid != 0) return;
+    const int t_step = step ? step[b] : 0;   // issued early: its latency hides under the fp64 arithmetic below
     double S[8];
     for (int j = 0; j < 8; j++) {
         double t = 0.0;
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
     c.k2 = (float)((double)lc.w_ncc * (alpha * Sab * Saa / (sd * sd * sd)));
     c.my = (float)my; c.mw = (float)mw;
     c.q = (float)((double)lc.w_mse * 2.0 / n + (double)lc.w_ssd * (double)lc.ssd_alpha * 2.0);
-    int t = step ? step[b] : 0;
+    int t = t_step;
     if (oc.kind == TRX_OPT_ADAM) {
         const double bc1 = 1.0 - pow((double)oc.beta1, (double)(t + 1)), bc2 = 1.0 - pow((double)oc.beta2, (double)(t + 1));
         c.step_size = (float)((double)oc.lr / bc1);
