@@ -9,6 +9,8 @@
 //   pass B  flow_update_kernel  : re-sample + derivative, dL/dflow, SGD/Adam update in place
 // replacing SpatialTransformer.forward -> criterion -> backward -> optimizer.step of
 // ref:warpings.py:208-220 when the parameter is the flow itself.
+#include <cstdlib>
+
 #include "trx_common.h"
 
 namespace trx {
@@ -305,7 +307,8 @@ static unsigned flow_grid_x(const trx_volumes &v)
 {
     const size_t nvox = (size_t)v.D * v.H * v.W;
     size_t nb = (nvox + TRX_BLOCK - 1) / TRX_BLOCK;
-    size_t cap = (size_t)(4096 + v.B - 1) / v.B;  // ~4096 blocks in flight overall
+    static const size_t total = [] { const char *e = getenv("TRX_FLOW_BLOCKS"); return (size_t)(e ? atoi(e) : 4096); }();   // development knob
+    size_t cap = (total + v.B - 1) / v.B;  // ~4096 blocks in flight overall
     if (cap < 64) cap = 64;
     return (unsigned)(nb < cap ? nb : cap);
 }
