@@ -140,3 +140,50 @@ def test_forward_warp_rows_not_multiple_of_4(eng, shape):
             r64 = oracle.c_affine_warp(x[0, c].double().numpy(), th[0].double().numpy(), oracle.base_tables(shape, np.float64))
             r32 = oracle.c_affine_warp(x[0, c].numpy(), th[0].numpy(), oracle.base_tables(shape, np.float32))
             assert np.max(np.abs(w[0, c] - r32)) <= max(2e-6, 2.0 * np.max(np.abs(r32 - r64)))   # fp32 floor, as in test_gpu_affine.py
+
+
+POSES = {  # (rot about y, rot about z, rot about x, tx, ty, tz) - ref:utils.py:287-310; translations pass through 0.25 tanh
+    "tiny": [0.02, -0.03, 0.01, 0.1, 0.0, -0.1],
+    "z04": [0.03, 0.41, -0.02, 0.2, -0.1, 0.0],          # GeomA does not fit: GeomR
+    "y03": [0.33, 0.05, 0.04, 0.0, 0.1, 0.1],
+    "x05": [0.02, -0.04, 0.52, -0.2, 0.0, 0.1],
+    "rand": [0.77, 0.5, 0.09, 0.03, 0.07, 0.15],         # torch.rand-like init: beyond GeomR for some tiles -> global gather
+}
+
+
+@pytest.mark.parametrize("shape", [(40, 36, 44), (64, 64, 64), (23, 37, 46), (33, 70, 51)])
+@pytest.mark.parametrize("pname", list(POSES))
+def test_rigid_step_dual_geometry_vs_oracle(eng, shape, pname):
+    """Rigid steps run the dual kernel: per pair GeomA (32 x 16 x 8 tile) where the pre-image fits its box, GeomR (16 x 16 x 8,
+    28 x 26 x 16 box) for rotations up to ~0.5 rad, the global gather beyond.  Loss and pose gradient vs the C oracle in fp64
+    (theta from the oracle's Theta, chain rule through its vjp); batch of two different poses so both geometries run in one launch."""
+    tgt = torch.cat([ph.blobs(shape, 77), ph.blobs(shape, 79)])
+    mov = torch.cat([ph.blobs(shape, 78), ph.blobs(shape, 80)]) + 0.1 * torch.cat([ph.blobs(shape, 81, nblob=9), ph.blobs(shape, 82, nblob=9)])
+    # (smooth phantoms only: a term that oscillates from plane to plane, like vol(shape, 0.013), turns the one-sided derivative at
+    # integer coordinates into a 3e-4 pose-gradient difference between fp32 and fp64 coordinate rounding - DESIGN.md section 2)
+    poses = np.array([POSES[pname], POSES["tiny"]], dtype=np.float64) + 1.3e-3 * np.sin(1.7 * np.arange(12).reshape(2, 6))
+    p32 = torch.tensor(poses, dtype=torch.float32)
+    kw = dict(w_ncc=1.0, w_mse=0.5)
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="rigid", loss=eng.LossSpec(**kw), lr=0.0, init=p32, capacity=1)
+    s.run(1)
+    torch.cuda.synchronize()
+    tabs = oracle.base_tables(shape, np.float64)
+    for b in range(2):
+        p64 = p32[b].double().numpy()
+        th = oracle.c_theta_fwd(p64)
+        total, _, dth, _ = oracle.c_affine_loss_grad(mov[b, 0].double().numpy(), tgt[b, 0].double().numpy(), th, oracle.wts(**kw), tabs)
+        dp = oracle.c_theta_vjp(p64, dth)
+        # the fp32 run of the oracle sets the floor of the pose gradient (large rotations amplify the coordinate rounding)
+        p32n = p32[b].numpy()
+        _, _, dth32, _ = oracle.c_affine_loss_grad(mov[b, 0].numpy(), tgt[b, 0].numpy(), oracle.c_theta_fwd(p32n), oracle.wts(**kw),
+                                                   oracle.base_tables(shape, np.float32))
+        dp32 = oracle.c_theta_vjp(p32n, dth32)
+        assert abs(s.losses[b, 0].item() - total) <= 2e-5 * max(1.0, abs(total))
+        assert np.max(np.abs(s.grad[b, :6].cpu().numpy() - dp)) <= max(3e-4 * np.max(np.abs(dp)), 2.0 * np.max(np.abs(dp32 - dp)))
+    # forward warp and loss-only kernels take the same dual dispatch
+    th32 = s.current_theta if hasattr(s, "current_theta") else None
+    w = eng.affine_warp(th32, mov.cuda()).cpu().numpy()
+    for b in range(2):
+        r32 = oracle.c_affine_warp(mov[b, 0].numpy(), th32[b].cpu().numpy(), oracle.base_tables(shape, np.float32))
+        r64 = oracle.c_affine_warp(mov[b, 0].double().numpy(), th32[b].cpu().double().numpy(), tabs)
+        assert np.max(np.abs(w[b, 0] - r32)) <= max(2e-6, 3.0 * np.max(np.abs(r32 - r64)))

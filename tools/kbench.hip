@@ -88,7 +88,7 @@ int main(int argc, char **argv)
     hipLaunchKernelGGL(trx::fill_tables_kernel, dim3((std::max(S, Wx) + 255) / 256), dim3(256), 0, 0, tab, Wx, S, S);
     trx_volumes vol = {mov, tgt, nvox, nvox, 3, B, S, S, Wx, tab, tab + Wx, tab + Wx + S};
     trx::AffineGeom g = trx::affine_geom(vol, tb);
-    CK(hipMalloc(&partials, (size_t)B * g.nblk * 41 * 4 + 4096));
+    CK(hipMalloc(&partials, (size_t)B * (g.nblk + 4096) * 41 * 4 + 4096));
     printf("B=%d S=%d W=%d geom TX=%d TY=%d RPT=%d nblk=%d\n", B, S, Wx, g.TX, g.TY, g.RPT, g.nblk);
     dim3 grid(g.nblk, B), block(256);
     const double alg = 8.0 * nvox;  // bytes per pair-iteration
@@ -104,6 +104,11 @@ int main(int argc, char **argv)
     dim3 tgrid(tgm.blocks_per_pair, B);
     rep("tile MODE1 (moments)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<1>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
     rep("tile MODE0 (full F1)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
+    {   // the dual kernel in GeomA mode: the cost of the surplus (empty) blocks
+        const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol);
+        const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
+        rep("dual MODE0 (GeomA chosen)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 20));
+    }
 #if TRX_TIMING
     {
         std::vector<unsigned long long> tmv(4 * 8192);
@@ -126,9 +131,19 @@ int main(int argc, char **argv)
         for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = rt[i];
         CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
         rep("tile MODE0 rot 0.5 (fallback)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 10));
+        {   // the dual kernel picks GeomR for this theta
+            const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol);
+            const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
+            rep("dual MODE0 rot 0.5 (GeomR)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 10));
+        }
         rep("accum MODE0 rot 0.5 (gather kernel)", time_it([&] { hipLaunchKernelGGL((trx::affine_accum_kernel<3, 0>), grid, block, 0, 0, vol, theta, g, 1, (size_t)0, partials); }, 10));
         for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = id[i];
         CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
+    }
+    {
+        const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol);
+        const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
+        rep("dual MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 20));
     }
     rep("tile MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
     return 0;

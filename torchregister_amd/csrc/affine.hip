@@ -192,28 +192,45 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
 // LDS box (floats), kBW % 4 == 0.  One LDS-DMA piece (one global_load_lds_dwordx4 per wave) covers kPP z planes of the
 // box - at most one float4 slot per thread - so piece k of a thread is its piece-0 slot shifted by k * kPP planes: one VGPR
 // offset + one packed slot id per thread instead of one per piece.
-#if TRX_TILE_CFG == 0
-constexpr int kTX = 32, kTY = 16, kTZ = 8;
-constexpr int kBW = 44, kBH = 23, kBD = 14, kPP = 2, kBufs = 1;
+template <int TX_, int TZ_, int THREADS_, int BW_, int BH_, int BD_, int PP_, int BUFS_>
+struct TileCfg {
+    static constexpr int TX = TX_, TY = 16, TZ = TZ_, Threads = THREADS_;
+    static constexpr int BW = BW_, BH = BH_, BD = BD_, PP = PP_, Bufs = BUFS_;
+    static constexpr int NH = Threads / (TX * TZ);          // y groups of a tile (2 halves of 8 rows, or 4 quarters of 4)
+    static constexpr int Rows = TY / NH;                    // rows per thread
+    static constexpr int Waves = Threads / 64;
+    static constexpr int BW4 = BW / 4;
+    static constexpr int PlaneSlots = BH * BW4;             // float4 slots per box plane
+    static constexpr int Pieces = (BD + PP - 1) / PP;       // DMA pieces per tile
+    static constexpr int PieceFloats = PP * BH * BW;        // floats of LDS per piece
+    static constexpr int BoxFloats = BW * BH * BD;          // one box; lanes of the last piece past it are always masked
+    static constexpr int ReduceScratch = Waves * 16 * 65 + Waves * 16;   // floats block_reduce_store_nw needs (aliases the box)
+    static constexpr int BoxAlloc = (Bufs * BoxFloats > ReduceScratch) ? Bufs * BoxFloats : ReduceScratch;
+    static_assert(BW % 4 == 0 && PP * PlaneSlots <= Threads && (PP == 2 || PP == 4), "one DMA piece: at most one slot per thread");
+};
+using GeomA = TileCfg<32, 8, 512, 44, 23, 14, 2, 1>;      // near-identity transforms: 32 x 16 x 8 tile, 44 x 23 x 14 box (56.7 KB)
+using GeomDeep = TileCfg<32, 16, 1024, 44, 22, 21, 4, 2>;  // cfg 1 (measured alternative): 1024 threads, two 81 KB boxes
+// Rotated transforms: the pre-image of a 32-wide tile grows by 31 sin(angle) rows / planes and stops fitting any box beyond
+// ~0.1 rad.  A more cubic tile (16 x 16 x 8, four y-quarters of 4 rows per thread) with a 28 x 26 x 16 box (46.6 KB) fits
+// every rotation about one axis up to ~0.5 rad at 55 us per 256^3 pair, whatever the angle (the global-gather fallback: 125 us).
+using GeomR = TileCfg<16, 8, 512, 28, 26, 16, 2, 1>;
+#if TRX_TILE_CFG == 1
+using GeomP = GeomDeep;   // primary geometry
+#elif TRX_TILE_CFG == 2
+using GeomP = GeomR;
 #else
-constexpr int kTX = 32, kTY = 16, kTZ = 16;
-constexpr int kBW = 44, kBH = 22, kBD = 21, kPP = 4, kBufs = 2;
+using GeomP = GeomA;
 #endif
-constexpr int kBW4 = kBW / 4;
-constexpr int kPlaneSlots = kBH * kBW4;              // float4 slots per box plane
-constexpr int kPieces = (kBD + kPP - 1) / kPP;       // DMA pieces per tile
-constexpr int kPieceFloats = kPP * kBH * kBW;        // floats of LDS per piece
-constexpr int kBoxFloats = kBW * kBH * kBD;          // one box; lanes of the last piece past it are always masked
-static_assert(kPP * kPlaneSlots <= kTX * kTZ * 2, "one DMA piece: at most one slot per thread");
 
 struct TileGeom {
     int ntx, nty, ntz, ntiles, blocks_per_pair, ysplit, tiles_per_seg;
 };
 
+template <class G = GeomP>
 static TileGeom tile_geom(const trx_volumes &v)
 {
     TileGeom t;
-    t.ntx = (v.W + kTX - 1) / kTX; t.nty = (v.H + kTY - 1) / kTY; t.ntz = (v.D + kTZ - 1) / kTZ;
+    t.ntx = (v.W + G::TX - 1) / G::TX; t.nty = (v.H + G::TY - 1) / G::TY; t.ntz = (v.D + G::TZ - 1) / G::TZ;
     t.ntiles = t.ntx * t.nty * t.ntz;
     // One block per (x-tile, z-tile) column walking y; columns are split into y segments where that fills the chip better
     // (512 block slots: 2 blocks on each of 256 CUs).  Measured with tools/kbench.hip (TRX_TILE_TARGET_BLOCKS sweeps):
@@ -270,6 +287,9 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #ifndef TRX_BOX_POLICY
 #define TRX_BOX_POLICY ""   // cache policy suffix of the box DMA (development: " nt", " sc1")
 #endif
+#ifndef TRX_DUAL_DEFAULT
+#define TRX_DUAL_DEFAULT 1   // 1: rigid steps, loss-only, warp and warp-backward launches pick GeomA / GeomR per pair in the kernel; 0: never
+#endif
 #ifndef TRX_STAGE_PRIO
 #define TRX_STAGE_PRIO 3
 #endif
@@ -310,11 +330,7 @@ __device__ __forceinline__ void f1_accumulate_pk(const Samp3 &sm, float yv, floa
     }
 }
 
-constexpr int kTileThreads = kTX * kTZ * 2;             // (32 x) x (kTZ z) x (2 halves of 8 rows): 512 or 1024 threads
-constexpr int kTileWaves = kTileThreads / 64;
-constexpr int kRows = kTY / 2;                           // rows per thread
-constexpr int kReduceScratch = kTileWaves * 16 * 65 + kTileWaves * 16;   // floats block_reduce_store_nw needs (aliases the box)
-constexpr int kBoxAlloc = (kBufs * kBoxFloats > kReduceScratch) ? kBufs * kBoxFloats : kReduceScratch;   // 56.7 KB / 162.6 KB
+constexpr int kTileThreads = GeomP::Threads;   // block size of the primary kernel (the dual kernel: 512)
 
 template <int NV, int NW>
 __device__ __forceinline__ void block_reduce_store_nw(const float (&vals)[NV], float *__restrict__ out, float *smem)
@@ -349,6 +365,15 @@ __device__ __forceinline__ void block_reduce_store_nw(const float (&vals)[NV], f
 
 // value is identical in every lane: pin it to an SGPR so it does not occupy a VGPR
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// wave-uniform pointer pinned to an SGPR pair (a no-op when the compiler already knows it is uniform); the asm blocks of the
+// tile kernel take their base addresses as "s" operands
+template <class T>
+__device__ __forceinline__ T *uni_ptr(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ float lane_bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
 // Requires vol.xn / vol.yn / vol.zn != NULL (the launcher materialises them when the caller passes NULL).
@@ -368,33 +393,33 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) { return __int_as
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
-template <int MODE>
-__global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_kernel(trx_volumes vol, const float *__restrict__ theta,
-                                                                                        TileGeom tg, int channels, float *__restrict__ partials)
+template <int MODE, class G>
+__device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *__restrict__ theta, const TileGeom &tg, int channels,
+                                          float *__restrict__ partials, float *box, const int bx, const int by)
 {
+    // geometry of this instantiation (bx, by: the block's index in the (blocks_per_pair, pairs x channels) grid)
+    constexpr int kTX = G::TX, kTY = G::TY, kTZ = G::TZ, kBW = G::BW, kBH = G::BH, kBD = G::BD, kPP = G::PP, kBufs = G::Bufs;
+    constexpr int kNH = G::NH, kRows = G::Rows, kTileWaves = G::Waves, kBW4 = G::BW4, kPlaneSlots = G::PlaneSlots, kPieces = G::Pieces;
+    constexpr int kPieceFloats = G::PieceFloats, kBoxFloats = G::BoxFloats;
+    (void)kNH; (void)kBD; (void)kPlaneSlots;
     // MODE 0: F1 sums, MODE 1: moments only, MODE 2: generic warp backward (`vol.target` = grad_out [B][channels][D][H][W],
     // 12 sums per (pair, channel)), MODE 3: forward warp (writes the warped volume to `partials` = out[B][channels][D][H][W])
     constexpr int NQ = (MODE == 0) ? 3 : (MODE == 2 ? 1 : 0);
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : 5);
     constexpr bool kGrad = (MODE == 0) || (MODE == 2);
     constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);   // blockIdx.y enumerates (pair, channel); channels share theta
-#ifdef TRX_LDS_PAD   // development: inflate the LDS footprint to force one block per CU
-    __shared__ __attribute__((aligned(16))) float box[kBoxAlloc + TRX_LDS_PAD];
-#else
-    __shared__ __attribute__((aligned(16))) float box[kBoxAlloc];
-#endif
-    const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
-    const int ch = kPerChannel ? blockIdx.y - b * channels : 0;
+    const int b = kPerChannel ? by / channels : by;
+    const int ch = kPerChannel ? by - b * channels : 0;
     const int D = vol.D, H = vol.H, W = vol.W;
-    const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
-    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride + (size_t)ch * D * H * W;
+    const float *__restrict__ th = uni_ptr(theta + (size_t)b * TRX_PSTRIDE);
+    const float *__restrict__ mov = uni_ptr(vol.moving + (size_t)b * vol.moving_stride + (size_t)ch * D * H * W);
     // MODE 3 has no target: `tgt` is the OUTPUT volume of this (pair, channel)
-    float *__restrict__ wout = partials + (size_t)blockIdx.y * D * H * W;
-    const float *__restrict__ tgt = (MODE == 3) ? wout : vol.target + (size_t)b * vol.target_stride + (MODE == 2 ? (size_t)ch * D * H * W : 0);
-    const float *__restrict__ xtab = vol.xn, *__restrict__ ytab = vol.yn, *__restrict__ ztab = vol.zn;
+    float *__restrict__ wout = uni_ptr(partials + (size_t)by * D * H * W);
+    const float *__restrict__ tgt = (MODE == 3) ? wout : uni_ptr(vol.target + (size_t)b * vol.target_stride + (MODE == 2 ? (size_t)ch * D * H * W : 0));
+    const float *__restrict__ xtab = uni_ptr(vol.xn), *__restrict__ ytab = uni_ptr(vol.yn), *__restrict__ ztab = uni_ptr(vol.zn);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform (SGPR)
-    const int lx = tid & (kTX - 1), lz = (tid >> 5) & (kTZ - 1), lh = wave / (kTileWaves / 2);
+    const int lx = tid & (kTX - 1), lz = (tid / kTX) & (kTZ - 1), lh = wave / (kTileWaves / kNH);
     const float fW = (float)W, fH = (float)H, fD = (float)D;
     const float hW = 0.5f * fW, hH = 0.5f * fH, hD = 0.5f * fD;
     const float t00 = th[0], t01 = th[1], t02 = th[2], t03 = th[3];
@@ -405,7 +430,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     // XCD-aware column order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
     // contiguous slab of columns so that the halo re-reads of neighbouring columns hit the same L2.
     const int ncol = tg.ntx * tg.ntz;
-    const int yseg = blockIdx.x / ncol, cb = blockIdx.x - yseg * ncol;
+    const int yseg = bx / ncol, cb = bx - yseg * ncol;
     int col = cb;
     if ((ncol & 7) == 0) col = (cb & 7) * (ncol >> 3) + (cb >> 3);
     const int X0 = (col % tg.ntx) * kTX, Z0 = (col / tg.ntx) * kTZ;
@@ -599,7 +624,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
                   const unsigned lds0 = dma_lds;
                   unsigned long long sv;
                   unsigned m0s;
-                  static_assert(kPieces == 6 || kPieces == 7, "the DMA block below is written for 6 or 7 pieces");
+                  static_assert(kPieces >= 6 && kPieces <= 8, "the DMA block below is written for 6, 7 or 8 pieces");
                   // one exec mask + one SGPR-base load per piece; s[100:101] walks the volume by kPP planes per piece
 #define TRX_DMA_NEXT(K)                                  \
     "s_add_u32 s100, s100, %[vstr]\n\t"                  \
@@ -616,7 +641,14 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
     "global_load_lds_dwordx4 %[off], s[100:101]" TRX_BOX_POLICY "\n\t"     \
     TRX_DMA_NEXT(1) TRX_DMA_NEXT(2) TRX_DMA_NEXT(3) TRX_DMA_NEXT(4) TRX_DMA_NEXT(5)
 #define TRX_DMA_TAIL "s_mov_b64 exec, %[sv]\n\t" "s_mov_b32 m0, %[m0s]"
-                  if constexpr (kPieces == 7) {
+                  if constexpr (kPieces == 8) {
+                      asm volatile(TRX_DMA_HEAD TRX_DMA_NEXT(6) TRX_DMA_NEXT(7) TRX_DMA_TAIL
+                                   : [sv] "=&s"(sv), [m0s] "=&s"(m0s)
+                                   : [lds] "s"(lds0), [base] "s"(mbase), [pstr] "i"(kPieceFloats * 4), [vstr] "s"(piece_stride), [off] "v"(rb0),
+                                     [k0] "s"(m_ld[0]), [k1] "s"(m_ld[1]), [k2] "s"(m_ld[2]), [k3] "s"(m_ld[3]), [k4] "s"(m_ld[4]),
+                                     [k5] "s"(m_ld[5]), [k6] "s"(m_ld[kPieces > 6 ? 6 : 0]), [k7] "s"(m_ld[kPieces - 1])
+                                   : "memory", "scc", "s100", "s101");
+                  } else if constexpr (kPieces == 7) {
                       asm volatile(TRX_DMA_HEAD TRX_DMA_NEXT(6) TRX_DMA_TAIL
                                    : [sv] "=&s"(sv), [m0s] "=&s"(m0s)
                                    : [lds] "s"(lds0), [base] "s"(mbase), [pstr] "i"(kPieceFloats * 4), [vstr] "s"(piece_stride), [off] "v"(rb0),
@@ -737,7 +769,11 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
               __builtin_amdgcn_s_setprio(0);
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // box pieces and the target column have landed
               if (m_part) zero_tails(0);
-              asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]), "+v"(yn_l));
+              {
+#pragma unroll
+                  for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tv[j]));
+                  asm volatile("" : "+v"(yn_l));
+              }
               const float yid_l = unnorm<3>(yn_l, fH);
 #if TRX_TIMING
               const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
@@ -773,7 +809,11 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
               asm volatile("global_load_dword %0, %1, %2" : "=v"(yn_l) : "v"(lane7b), "s"(ytab + (ty + gl) * kTY + j0) : "memory");
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's box pieces (issued one tile ago) and target column
               if (m_part) zero_tails(gl & 1);
-              asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]), "+v"(yn_l));
+              {
+#pragma unroll
+                  for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tv[j]));
+                  asm volatile("" : "+v"(yn_l));
+              }
               const float yid_l = unnorm<3>(yn_l, fH);
 #if TRX_TIMING
               const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
@@ -797,7 +837,9 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             }
             // the prefetch issued during the last tile is still in flight: its destination registers must not be reused,
             // and the generic loop below must not overwrite box 0 while a slower wave still gathers from it
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]) : : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tv[j]));
             __syncthreads();
           }
           ty += nf;
@@ -805,7 +847,7 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
         }
 #if TRX_TIMING
         if (tid == 0) {
-            const size_t bi = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            const size_t bi = (size_t)by * gridDim.x + bx;
             if (bi < 8192) for (int i = 0; i < 4; i++) trx_timing[bi * 4 + i] = tm_acc[i];
         }
 #endif
@@ -996,7 +1038,57 @@ __global__ __launch_bounds__(kTileThreads, TRX_TILE_MIN_WAVES) void affine_tile_
             const float a = acc.AB[q][c].x;
             vals[o++] = xn * a; vals[o++] = acc.AB[q][c].y; vals[o++] = zn * a; vals[o++] = a;
         }
-    block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)blockIdx.y * tg.blocks_per_pair + blockIdx.x) * NP, box);
+    block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)by * gridDim.x + bx) * NP, box);
+}
+
+// The primary kernel: one geometry (GeomP) for every block.
+template <int MODE>
+__global__ __launch_bounds__(GeomP::Threads, TRX_TILE_MIN_WAVES) void affine_tile_kernel(trx_volumes vol, const float *__restrict__ theta,
+                                                                                          TileGeom tg, int channels, float *__restrict__ partials)
+{
+#ifdef TRX_LDS_PAD   // development: inflate the LDS footprint to force one block per CU
+    __shared__ __attribute__((aligned(16))) float box[GeomP::BoxAlloc + TRX_LDS_PAD];
+#else
+    __shared__ __attribute__((aligned(16))) float box[GeomP::BoxAlloc];
+#endif
+    tile_body<MODE, GeomP>(vol, theta, tg, channels, partials, box, blockIdx.x, blockIdx.y);
+}
+
+// The dual kernel: per pair, GeomA where its box holds the pre-image of a GeomA tile for this theta (decided from the
+// tile-independent maximum extent, the same bound the fast loop fetches), GeomR otherwise.  The grid is sized for the geometry
+// with more blocks; the surplus blocks of the other one write a zero partial row and leave.
+template <int MODE>
+__global__ __launch_bounds__(512, TRX_TILE_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tgA,
+                                                                                   TileGeom tgR, int channels, float *__restrict__ partials)
+{
+    static_assert(GeomA::Threads == 512 && GeomR::Threads == 512, "both geometries run 512-thread blocks");
+    constexpr int kAlloc = GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc;
+    __shared__ __attribute__((aligned(16))) float box[kAlloc];
+    constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);
+    constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : 5);
+    const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
+    const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
+    const float fW = (float)vol.W, fH = (float)vol.H, fD = (float)vol.D;
+    const float slope[3][3] = {{th[0], th[1] * fW / fH, th[2] * fW / fD}, {th[4] * fH / fW, th[5], th[6] * fH / fD}, {th[8] * fD / fW, th[9] * fD / fH, th[10]}};
+    const float ex[3] = {(float)(GeomA::TX - 1), (float)(GeomA::TY - 1), (float)(GeomA::TZ - 1)};
+    float span[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) span[c] = fabsf(slope[c][0]) * ex[0] + fabsf(slope[c][1]) * ex[1] + fabsf(slope[c][2]) * ex[2];
+    // (NaN / huge theta compare false: GeomR, whose own per-tile test then sends everything to the global-gather fallback)
+    const bool fitsA = (span[0] < 1.0e6f) && (span[1] < 1.0e6f) && (span[2] < 1.0e6f) &&
+                       ((((int)floorf(span[0] + 0.1f) + 5) >> 2) + 1 <= GeomA::BW4) && ((int)floorf(span[1] + 0.1f) + 3 <= GeomA::BH) &&
+                       ((int)floorf(span[2] + 0.1f) + 3 <= GeomA::BD);
+    const bool useA = __builtin_amdgcn_readfirstlane(fitsA ? 1 : 0) != 0;
+    const int mine = useA ? tgA.blocks_per_pair : tgR.blocks_per_pair;
+    if ((int)blockIdx.x >= mine) {
+        if (MODE != 3 && threadIdx.x < NP) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + threadIdx.x] = 0.f;
+        return;
+    }
+    if (!useA) {
+        tile_body<MODE, GeomR>(vol, theta, tgR, channels, partials, box, blockIdx.x, blockIdx.y);
+        return;
+    }
+    tile_body<MODE, GeomA>(vol, theta, tgA, channels, partials, box, blockIdx.x, blockIdx.y);
 }
 
 #pragma clang diagnostic pop
@@ -1289,14 +1381,32 @@ constexpr int kTargetBlocks = 2048;
 
 using namespace trx;
 
+// 0 = primary geometry only, 1 = dual (GeomA / GeomR chosen per pair inside the kernel).  TRX_AFFINE_DUAL overrides (development).
+static bool use_dual()
+{
+    static const int v = [] { const char *e = getenv("TRX_AFFINE_DUAL"); return e ? atoi(e) : TRX_DUAL_DEFAULT; }();
+    return v != 0 && TRX_TILE_CFG == 0;
+}
+
+// partial rows per pair that a tile-path launch may write (the dual grid is sized for the geometry with more blocks)
+static size_t tile_rows_per_pair(const trx_volumes &v)
+{
+    size_t n = (size_t)tile_geom<GeomP>(v).blocks_per_pair;
+    const size_t a = (size_t)tile_geom<GeomA>(v).blocks_per_pair, r = (size_t)tile_geom<GeomR>(v).blocks_per_pair;
+    if (a > n) n = a;
+    if (r > n) n = r;
+    return n;
+}
+
+
 extern "C" size_t trx_affine_workspace_bytes(const trx_volumes *vol)
 {
     if (check_vol(vol, false) != TRX_OK) return 0;
     AffineGeom g = affine_geom(*vol, kTargetBlocks);
     size_t nblk = (size_t)g.nblk;
     if (vol->ndim == 3) {
-        TileGeom t = tile_geom(*vol);
-        if ((size_t)t.blocks_per_pair > nblk) nblk = (size_t)t.blocks_per_pair;
+        const size_t t = tile_rows_per_pair(*vol);
+        if (t > nblk) nblk = t;
     }
     const size_t tab = ((size_t)(vol->W + vol->H + vol->D) * sizeof(float) + 255) & ~(size_t)255;
     return (size_t)vol->B * nblk * np_full(3) * sizeof(float) + 256 + tab;
@@ -1312,7 +1422,7 @@ static bool use_tile_path(const trx_volumes *vol)
 // MODE 0 / 1 dispatch: LDS-tiled kernel for 3-D, row-walking gather kernel otherwise.
 // Returns the number of partial rows per pair through *nblk.
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s);
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual);
 
 template <int MODE>
 static int launch_accum(const trx_volumes *vol, const float *theta, const AffineGeom &g, int channels, size_t chan_stride,
@@ -1328,7 +1438,7 @@ static int launch_accum(const trx_volumes *vol, const float *theta, const Affine
 }
 
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s)
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual)
 {
     if (use_tile_path(vol)) {
         TileGeom t = tile_geom(*vol);
@@ -1336,13 +1446,22 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
         if (!v.xn || !v.yn || !v.zn) {
             // tables live behind the partials (trx_affine_workspace_bytes reserves the room)
             AffineGeom g = affine_geom(*vol, kTargetBlocks);
-            size_t nb = (size_t)g.nblk > (size_t)t.blocks_per_pair ? (size_t)g.nblk : (size_t)t.blocks_per_pair;
+            const size_t tr = tile_rows_per_pair(*vol);
+            size_t nb = (size_t)g.nblk > tr ? (size_t)g.nblk : tr;
             size_t off = ((size_t)vol->B * nb * np_full(3) * sizeof(float) + 255) & ~(size_t)255;
             float *tab = (float *)((char *)partials + off);
             const int n = max(v.W, max(v.H, v.D));
             hipLaunchKernelGGL(fill_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tab, v.W, v.H, v.D);
             TRX_CHECK_LAUNCH();
             v.xn = tab; v.yn = tab + v.W; v.zn = tab + v.W + v.H;
+        }
+        if (dual && use_dual()) {
+            const TileGeom ta = tile_geom<GeomA>(*vol), tr = tile_geom<GeomR>(*vol);
+            const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
+            hipLaunchKernelGGL((affine_tile_dual_kernel<MODE>), dim3(gx, vol->B), dim3(512), 0, s, v, theta, ta, tr, 1, partials);
+            TRX_CHECK_LAUNCH();
+            *nblk = gx;
+            return TRX_OK;
         }
         hipLaunchKernelGGL((affine_tile_kernel<MODE>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
         TRX_CHECK_LAUNCH();
@@ -1368,7 +1487,10 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     hipStream_t s = (hipStream_t)stream;
     float *partials = (float *)workspace;
     int nblk = 0;
-    rc = launch_f1<0>(vol, st->theta, partials, &nblk, s);
+    // Rigid runs start from a random pose (reference: torch.rand, up to 1 rad) and live at large rotations: their F1 pass picks
+    // GeomA / GeomR per pair in the kernel.  Affine runs start at the identity and use the primary kernel, whose GeomA code is
+    // 2-5 % faster near the identity than the same body inside the dual kernel (code layout); beyond ~0.1 rad they gather from L2.
+    rc = launch_f1<0>(vol, st->theta, partials, &nblk, s, st->mode == TRX_PARAM_RIGID);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
     if (vol->ndim == 3)
@@ -1388,7 +1510,7 @@ extern "C" int trx_affine_accumulate(const trx_volumes *vol, const float *theta,
     if (!theta || !workspace) return TRX_ERR_ARG;
     if (workspace_bytes < trx_affine_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
     int nblk = 0;
-    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream);
+    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream, false);   // the kernel of an affine step (profiling aid)
 }
 
 extern "C" int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
@@ -1412,7 +1534,7 @@ extern "C" int trx_affine_loss(const trx_volumes *vol, const trx_loss_cfg *loss,
     hipStream_t s = (hipStream_t)stream;
     float *partials = (float *)workspace;
     int nblk = 0;
-    rc = launch_f1<1>(vol, theta, partials, &nblk, s);
+    rc = launch_f1<1>(vol, theta, partials, &nblk, s, true);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
     hipLaunchKernelGGL(affine_loss_finalize_kernel, dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox, *loss, terms);
@@ -1433,6 +1555,14 @@ extern "C" int trx_affine_warp(const trx_volumes *vol, const float *theta, int c
         trx_volumes v = *vol;
         v.B = vol->B * channels;                       // geometry: every (pair, channel) is one slab of blocks
         TileGeom t = tile_geom(v);
+        if (use_dual()) {
+            const TileGeom ta = tile_geom<GeomA>(v), tr = tile_geom<GeomR>(v);
+            v.B = vol->B;
+            const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
+            hipLaunchKernelGGL((affine_tile_dual_kernel<3>), dim3(gx, vol->B * channels), dim3(512), 0, s, v, theta, ta, tr, channels, out);
+            TRX_CHECK_LAUNCH();
+            return TRX_OK;
+        }
         v.B = vol->B;
         hipLaunchKernelGGL((affine_tile_kernel<3>), dim3(t.blocks_per_pair, vol->B * channels), dim3(kTileThreads), 0, s, v, theta, t, channels, out);
         TRX_CHECK_LAUNCH();
@@ -1467,9 +1597,16 @@ extern "C" int trx_affine_warp_backward(const trx_volumes *vol, const float *the
         // LDS-tiled kernel (same staging as the F1 pass); one partial row per block, 12 sums each.  (Several channels or
         // caller-less tables: the row-walking gather kernel below; the workspace is sized for single-channel tiles.)
         TileGeom t = tile_geom(*vol);
-        hipLaunchKernelGGL((affine_tile_kernel<2>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
+        int rows = t.blocks_per_pair;
+        if (use_dual()) {
+            const TileGeom ta = tile_geom<GeomA>(*vol), tr = tile_geom<GeomR>(*vol);
+            rows = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
+            hipLaunchKernelGGL((affine_tile_dual_kernel<2>), dim3(rows, vol->B), dim3(512), 0, s, v, theta, ta, tr, 1, partials);
+        } else {
+            hipLaunchKernelGGL((affine_tile_kernel<2>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
+        }
         TRX_CHECK_LAUNCH();
-        hipLaunchKernelGGL((affine_bwd_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, t.blocks_per_pair, vol->D, vol->H,
+        hipLaunchKernelGGL((affine_bwd_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, rows, vol->D, vol->H,
                            vol->W, dtheta);
         TRX_CHECK_LAUNCH();
         return TRX_OK;
