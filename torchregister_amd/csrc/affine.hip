@@ -192,9 +192,9 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
 // LDS box (floats), kBW % 4 == 0.  One LDS-DMA piece (one global_load_lds_dwordx4 per wave) covers kPP z planes of the
 // box - at most one float4 slot per thread - so piece k of a thread is its piece-0 slot shifted by k * kPP planes: one VGPR
 // offset + one packed slot id per thread instead of one per piece.
-template <int TX_, int TZ_, int THREADS_, int BW_, int BH_, int BD_, int PP_, int BUFS_>
+template <int TX_, int TZ_, int THREADS_, int BW_, int BH_, int BD_, int PP_, int BUFS_, int TY_ = 16>
 struct TileCfg {
-    static constexpr int TX = TX_, TY = 16, TZ = TZ_, Threads = THREADS_;
+    static constexpr int TX = TX_, TY = TY_, TZ = TZ_, Threads = THREADS_;
     static constexpr int BW = BW_, BH = BH_, BD = BD_, PP = PP_, Bufs = BUFS_;
     static constexpr int NH = Threads / (TX * TZ);          // y groups of a tile (2 halves of 8 rows, or 4 quarters of 4)
     static constexpr int Rows = TY / NH;                    // rows per thread
@@ -214,8 +214,13 @@ using GeomDeep = TileCfg<32, 16, 1024, 44, 22, 21, 4, 2>;  // cfg 1 (measured al
 // ~0.1 rad.  A more cubic tile (16 x 16 x 8, four y-quarters of 4 rows per thread) with a 28 x 26 x 16 box (46.6 KB) fits
 // every rotation about one axis up to ~0.5 rad at 55 us per 256^3 pair, whatever the angle (the global-gather fallback: 125 us).
 using GeomR = TileCfg<16, 8, 512, 28, 26, 16, 2, 1>;
+// Wide tile (64 x 8 x 8, one row block of 8 per thread): a box row of 64 + halo voxels touches 3.3 L2 lines for 64 voxels where the
+// 32-wide tile touches 2.3 for 32, i.e. 366 instead of 444 box lines per 4096 voxels; the 76 x 13 x 14 box fits |rotation| < ~0.04 rad.
+using GeomW = TileCfg<64, 8, 512, 76, 13, 14, 2, 1, 8>;
 #if TRX_TILE_CFG == 1
 using GeomP = GeomDeep;   // primary geometry
+#elif TRX_TILE_CFG == 3
+using GeomP = GeomW;
 #elif TRX_TILE_CFG == 2
 using GeomP = GeomR;
 #else
