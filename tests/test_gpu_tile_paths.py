@@ -147,7 +147,8 @@ POSES = {  # (rot about y, rot about z, rot about x, tx, ty, tz) - ref:utils.py:
     "z04": [0.03, 0.41, -0.02, 0.2, -0.1, 0.0],          # GeomA does not fit: GeomR
     "y03": [0.33, 0.05, 0.04, 0.0, 0.1, 0.1],
     "x05": [0.02, -0.04, 0.52, -0.2, 0.0, 0.1],
-    "rand": [0.77, 0.5, 0.09, 0.03, 0.07, 0.15],         # torch.rand-like init: beyond GeomR for some tiles -> global gather
+    "rand": [0.77, 0.5, 0.09, 0.03, 0.07, 0.15],         # torch.rand-like init (ref:utils.py:316-330 draws every angle from [0,1) rad)
+    "max": [0.98, 0.93, 0.99, 0.9, 0.5, 0.2],            # the far corner of that range: GeomR's 28 x 27 x 26 box holds any rotation
 }
 
 
@@ -155,7 +156,7 @@ POSES = {  # (rot about y, rot about z, rot about x, tx, ty, tz) - ref:utils.py:
 @pytest.mark.parametrize("pname", list(POSES))
 def test_rigid_step_dual_geometry_vs_oracle(eng, shape, pname):
     """Rigid steps run the dual kernel: per pair GeomA (32 x 16 x 8 tile) where the pre-image fits its box, GeomR (16 x 16 x 8,
-    28 x 26 x 16 box) for rotations up to ~0.5 rad, the global gather beyond.  Loss and pose gradient vs the C oracle in fp64
+    28 x 27 x 26 box) for every other rotation, the global gather for zoom-out / shear beyond that.  Loss and pose gradient vs the C oracle in fp64
     (theta from the oracle's Theta, chain rule through its vjp); batch of two different poses so both geometries run in one launch."""
     tgt = torch.cat([ph.blobs(shape, 77), ph.blobs(shape, 79)])
     mov = torch.cat([ph.blobs(shape, 78), ph.blobs(shape, 80)]) + 0.1 * torch.cat([ph.blobs(shape, 81, nblob=9), ph.blobs(shape, 82, nblob=9)])

@@ -1,6 +1,7 @@
 // Standalone kernel micro-benchmark (development tool, not shipped): times the product kernels
 // and experimental variants on B pairs of S^3 random volumes with hipEvents.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kbench.hip -o build/kbench && build/kbench 8 256
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -135,6 +136,22 @@ int main(int argc, char **argv)
             const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol);
             const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
             rep("dual MODE0 rot 0.5 (GeomR)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 10));
+        }
+        {   // a general rotation (Rz(0.6) Ry(0.8) Rx(0.7), what the reference's random rigid init looks like)
+            const double a = 0.8, bz = 0.6, c = 0.7;
+            const double Ry[9] = {cos(a), 0, sin(a), 0, 1, 0, -sin(a), 0, cos(a)}, Rz[9] = {cos(bz), -sin(bz), 0, sin(bz), cos(bz), 0, 0, 0, 1},
+                         Rx[9] = {1, 0, 0, 0, cos(c), -sin(c), 0, sin(c), cos(c)};
+            double T[9], R[9];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { T[i * 3 + j] = 0; for (int k = 0; k < 3; k++) T[i * 3 + j] += Rz[i * 3 + k] * Ry[k * 3 + j]; }
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i * 3 + j] = 0; for (int k = 0; k < 3; k++) R[i * 3 + j] += T[i * 3 + k] * Rx[k * 3 + j]; }
+            for (int b = 0; b < B; b++) for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) th[b * 12 + i * 4 + j] = (float)R[i * 3 + j]; th[b * 12 + i * 4 + 3] = 0.01f * (i + 1); }
+            CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
+            const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol);
+            const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
+            rep("dual MODE0 rot .8/.6/.7", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 10));
+            rep("tile MODE0 rot .8/.6/.7", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 10));
+            for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = rt[i];
+            CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
         }
         rep("accum MODE0 rot 0.5 (gather kernel)", time_it([&] { hipLaunchKernelGGL((trx::affine_accum_kernel<3, 0>), grid, block, 0, 0, vol, theta, g, 1, (size_t)0, partials); }, 10));
         for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = id[i];

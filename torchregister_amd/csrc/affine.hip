@@ -213,7 +213,21 @@ using GeomDeep = TileCfg<32, 16, 1024, 44, 22, 21, 4, 2>;  // cfg 1 (measured al
 // Rotated transforms: the pre-image of a 32-wide tile grows by 31 sin(angle) rows / planes and stops fitting any box beyond
 // ~0.1 rad.  A more cubic tile (16 x 16 x 8, four y-quarters of 4 rows per thread) with a 28 x 26 x 16 box (46.6 KB) fits
 // every rotation about one axis up to ~0.5 rad at 55 us per 256^3 pair, whatever the angle (the global-gather fallback: 125 us).
+#ifndef TRX_GEOMR_BIG
+#define TRX_GEOMR_BIG 1
+#endif
+#if TRX_GEOMR_BIG
+// 28 x 27 x 26 box (78.6 KB, still two blocks per CU): the pre-image of the 16 x 16 x 8 tile under ANY rotation (span <= |(15,15,7)| = 22.3
+// voxels per axis) fits, i.e. every pose the reference's rigid mode can draw (angles uniform in [0,1) rad, ref:utils.py:316-330);
+// only the needed extent is fetched, so small angles cost what they cost with the 28 x 26 x 16 box.
+#ifndef TRX_GEOMR_BH
+#define TRX_GEOMR_BH 27
+#define TRX_GEOMR_BD 26
+#endif
+using GeomR = TileCfg<16, 8, 512, 28, TRX_GEOMR_BH, TRX_GEOMR_BD, 2, 1>;
+#else
 using GeomR = TileCfg<16, 8, 512, 28, 26, 16, 2, 1>;
+#endif
 // Wide tile (64 x 8 x 8, one row block of 8 per thread): a box row of 64 + halo voxels touches 3.3 L2 lines for 64 voxels where the
 // 32-wide tile touches 2.3 for 32, i.e. 366 instead of 444 box lines per 4096 voxels; the 76 x 13 x 14 box fits |rotation| < ~0.04 rad.
 using GeomW = TileCfg<64, 8, 512, 76, 13, 14, 2, 1, 8>;
@@ -294,6 +308,9 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #endif
 #ifndef TRX_DUAL_DEFAULT
 #define TRX_DUAL_DEFAULT 1   // 1: rigid steps, loss-only, warp and warp-backward launches pick GeomA / GeomR per pair in the kernel; 0: never
+#endif
+#ifndef TRX_DMA_EXECZ_SKIP
+#define TRX_DMA_EXECZ_SKIP 1   // branch over a DMA piece none of whose lanes fetch (an LDS-DMA with exec = 0 still costs its issue)
 #endif
 #ifndef TRX_STAGE_PRIO
 #define TRX_STAGE_PRIO 3
@@ -557,9 +574,17 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
             int d0;
             slot_geom(lane, rb0, d0);
         }
-        unsigned long long m_ld[kPieces];                    // cached exec masks of the DMA pieces (wave-uniform)
+        // More than 8 pieces (GeomR's deep box): one exec mask per piece would not fit the SGPR file (the reloads cost 18 %), but the
+        // masks are structured - lane (pz, dy, dx4) of piece k fetches iff its (dy, dx4) is wanted and plane 2k + pz is: two masks
+        // (pz = 0 / 1 lanes with a wanted (dy, dx4)) and one bit per box plane rebuild each piece's mask with scalar instructions.
+        constexpr bool kZMask = kPieces > 8;
+        static_assert(!kZMask || (kPP == 2 && kBD <= 32), "plane-bit masks: pieces of two planes");
+        constexpr int kNM = kZMask ? 1 : kPieces;
+        unsigned long long m_ld[kNM];                        // cached exec masks of the DMA pieces (wave-uniform)
 #pragma unroll
-        for (int k = 0; k < kPieces; k++) m_ld[k] = 0;
+        for (int k = 0; k < kNM; k++) m_ld[k] = 0;
+        unsigned long long m_a0 = 0, m_a1 = 0;               // kZMask: lanes of plane 0 / 1 of a piece whose (dy, dx4) is fetched
+        unsigned m_zb = 0;                                   // kZMask: bit z = box plane z is fetched
         unsigned m_oob = 0;                                  // bit k: slot k of this thread is needed but outside the volume
         unsigned m_part = 0;                                 // bit k: slot k straddles x = W (W % 4 != 0): zero its tail after landing
         // Fetched extent = the LARGEST pre-image extent any tile of this theta can have (capped at the box): the exact
@@ -617,9 +642,16 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
                       const int d = d0 + (k << kDShift);
                       const bool need = (((lim - d) & 0x80808080) == 0);
                       const bool ld = need && (((hi - d) & 0x80808080) == 0) && (((d - lo) & 0x80808080) == 0);
-                      m_ld[k] = __builtin_amdgcn_ballot_w64(ld);
+                      if constexpr (!kZMask) m_ld[k] = __builtin_amdgcn_ballot_w64(ld);
                       if (need && !ld) m_oob |= 1u << k;
                       if (ld && (d & 0xff) == part_x) m_part |= 1u << k;   // fetched whole; its tail past x = W is zeroed after landing
+                  }
+                  if constexpr (kZMask) {
+                      const int dyx = d0 & 0xffff;
+                      const bool xy = (((((lim & 0xffff) - dyx) | ((hi & 0xffff) - dyx) | (dyx - (lo & 0xffff))) & 0x8080) == 0);
+                      m_a0 = __builtin_amdgcn_ballot_w64(xy && (d0 >> 16) == 0);
+                      m_a1 = __builtin_amdgcn_ballot_w64(xy && (d0 >> 16) == 1);
+                      m_zb = (unsigned)__builtin_amdgcn_readfirstlane((int)(none ? 0u : (((2u << hiz) - 1u) & ~((1u << loz) - 1u))));   // hiz <= the needed depth by construction
                   }
               }
               dma_base = reinterpret_cast<const char *>(mov + (ptrdiff_t)((oz * H + oy) * W + ox));   // uniform; may point below `mov` (those lanes are masked)
@@ -629,24 +661,62 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
                   const unsigned lds0 = dma_lds;
                   unsigned long long sv;
                   unsigned m0s;
-                  static_assert(kPieces >= 6 && kPieces <= 8, "the DMA block below is written for 6, 7 or 8 pieces");
+                  static_assert((kPieces >= 6 && kPieces <= 8) || kPieces == 13, "the DMA block below is written for 6, 7, 8 or 13 pieces");
                   // one exec mask + one SGPR-base load per piece; s[100:101] walks the volume by kPP planes per piece
+#if TRX_DMA_EXECZ_SKIP
+#define TRX_DMA_SKIP "s_cbranch_execz 1f\n\t"
+#else
+#define TRX_DMA_SKIP
+#endif
 #define TRX_DMA_NEXT(K)                                  \
     "s_add_u32 s100, s100, %[vstr]\n\t"                  \
     "s_addc_u32 s101, s101, 0\n\t"                       \
     "s_add_u32 m0, m0, %[pstr]\n\t"                      \
     "s_mov_b64 exec, %[k" #K "]\n\t"                     \
-    "global_load_lds_dwordx4 %[off], s[100:101]" TRX_BOX_POLICY "\n\t"
+    TRX_DMA_SKIP                                         \
+    "global_load_lds_dwordx4 %[off], s[100:101]" TRX_BOX_POLICY "\n\t" \
+    "1:\n\t"
 #define TRX_DMA_HEAD                                     \
     "s_mov_b64 %[sv], exec\n\t"                          \
     "s_mov_b32 %[m0s], m0\n\t"                           \
     "s_mov_b64 s[100:101], %[base]\n\t"                  \
     "s_mov_b32 m0, %[lds]\n\t"                           \
     "s_mov_b64 exec, %[k0]\n\t"                          \
+    TRX_DMA_SKIP                                         \
     "global_load_lds_dwordx4 %[off], s[100:101]" TRX_BOX_POLICY "\n\t"     \
+    "1:\n\t"                                             \
     TRX_DMA_NEXT(1) TRX_DMA_NEXT(2) TRX_DMA_NEXT(3) TRX_DMA_NEXT(4) TRX_DMA_NEXT(5)
 #define TRX_DMA_TAIL "s_mov_b64 exec, %[sv]\n\t" "s_mov_b32 m0, %[m0s]"
-                  if constexpr (kPieces == 8) {
+                  if constexpr (kZMask) {
+                      static_assert(kPieces == 13, "plane-bit DMA block: 13 pieces");
+                      unsigned long long t0, t1;
+#define TRX_DMA_ZSEL(B0, B1)                             \
+    "s_bitcmp1_b32 %[zb], " #B0 "\n\t"                   \
+    "s_cselect_b64 %[t0], %[a0], 0\n\t"                 \
+    "s_bitcmp1_b32 %[zb], " #B1 "\n\t"                   \
+    "s_cselect_b64 %[t1], %[a1], 0\n\t"                 \
+    "s_or_b64 exec, %[t0], %[t1]\n\t"                   \
+    "s_cbranch_execz 1f\n\t"                            \
+    "global_load_lds_dwordx4 %[off], s[100:101]" TRX_BOX_POLICY "\n\t" \
+    "1:\n\t"
+#define TRX_DMA_ZNEXT(B0, B1)                            \
+    "s_add_u32 s100, s100, %[vstr]\n\t"                 \
+    "s_addc_u32 s101, s101, 0\n\t"                      \
+    "s_add_u32 m0, m0, %[pstr]\n\t" TRX_DMA_ZSEL(B0, B1)
+                      asm volatile("s_mov_b64 %[sv], exec\n\t"
+                                   "s_mov_b32 %[m0s], m0\n\t"
+                                   "s_mov_b64 s[100:101], %[base]\n\t"
+                                   "s_mov_b32 m0, %[lds]\n\t" TRX_DMA_ZSEL(0, 1)
+                                   TRX_DMA_ZNEXT(2, 3) TRX_DMA_ZNEXT(4, 5) TRX_DMA_ZNEXT(6, 7) TRX_DMA_ZNEXT(8, 9) TRX_DMA_ZNEXT(10, 11)
+                                   TRX_DMA_ZNEXT(12, 13) TRX_DMA_ZNEXT(14, 15) TRX_DMA_ZNEXT(16, 17) TRX_DMA_ZNEXT(18, 19)
+                                   TRX_DMA_ZNEXT(20, 21) TRX_DMA_ZNEXT(22, 23) TRX_DMA_ZNEXT(24, 25) TRX_DMA_TAIL
+                                   : [sv] "=&s"(sv), [m0s] "=&s"(m0s), [t0] "=&s"(t0), [t1] "=&s"(t1)
+                                   : [lds] "s"(lds0), [base] "s"(mbase), [pstr] "i"(kPieceFloats * 4), [vstr] "s"(piece_stride), [off] "v"(rb0),
+                                     [a0] "s"(m_a0), [a1] "s"(m_a1), [zb] "s"(__builtin_amdgcn_readfirstlane((int)m_zb))
+                                   : "memory", "scc", "s100", "s101");
+#undef TRX_DMA_ZSEL
+#undef TRX_DMA_ZNEXT
+                  } else if constexpr (kPieces == 8) {
                       asm volatile(TRX_DMA_HEAD TRX_DMA_NEXT(6) TRX_DMA_NEXT(7) TRX_DMA_TAIL
                                    : [sv] "=&s"(sv), [m0s] "=&s"(m0s)
                                    : [lds] "s"(lds0), [base] "s"(mbase), [pstr] "i"(kPieceFloats * 4), [vstr] "s"(piece_stride), [off] "v"(rb0),
@@ -669,6 +739,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
                                    : "memory", "scc", "s100", "s101");
                   }
 #undef TRX_DMA_NEXT
+#undef TRX_DMA_SKIP
 #undef TRX_DMA_HEAD
 #undef TRX_DMA_TAIL
               }
@@ -705,7 +776,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
                            "s_mov_b32 m0, %[m0s]"
                            : [sv] "=&s"(sv), [m0s] "=&s"(m0s)
                            : [lds] "s"(dma_lds + (unsigned)k * (kPieceFloats * 4u)), [base] "s"(dma_base + (size_t)k * piece_stride), [off] "v"(rb0),
-                             [mk] "s"(m_ld[k])
+                             [mk] "s"(kZMask ? ((((m_zb >> (2 * k)) & 1u) ? m_a0 : 0ull) | (((m_zb >> (2 * k + 1)) & 1u) ? m_a1 : 0ull)) : m_ld[kZMask ? 0 : k])
                            : "memory");
           };
           // ---- the 8 rows of this thread in fast tile `g`, gathered from LDS buffer `buf`.  tnext != nullptr: after row j is
