@@ -51,3 +51,10 @@ go8 = torch.rand_like(mov8)
 rep("affine_warp_backward (8 pairs)", timeit(lambda: eng.affine_warp_backward(th.expand(8, 3, 4).contiguous(), mov8, go8), 5), 12 * N * 8)
 fl1 = torch.zeros(1, 3, *shape, device=dev) + 0.3
 rep("flow_warp_backward (1 pair)", timeit(lambda: eng.flow_warp_backward(mov, fl1, go)), 36 * N)
+# rigid steps from the reference's kind of initial pose (every angle uniform in [0,1) rad, ref:utils.py:316-330): 8 pairs, 8 different poses
+g = torch.Generator().manual_seed(7)
+tgt8r = torch.cat([blobs_gpu(shape, 1000 + b, dev) for b in range(8)])
+poses = torch.rand(8, 6, generator=g)
+for name, init in (("random poses U[0,1)^6", poses), ("small poses (0.02 rad)", 0.02 * poses)):
+    sr = tr.AffineSolver(mov8, tgt8r, mode="rigid", loss=tr.LossSpec(w_mse=1.0), lr=1e-6, init=init, capacity=64)
+    rep(f"rigid step, {name} (8 pairs)", timeit(lambda: sr.run(1), 20), 8 * N * 8)

@@ -109,6 +109,7 @@ int main(int argc, char **argv)
         const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol);
         const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
         rep("dual MODE0 (GeomA chosen)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 20));
+        rep("split MODE0 (GeomA chosen)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 1>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 2>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 20));
     }
 #if TRX_TIMING
     {
@@ -136,6 +137,7 @@ int main(int argc, char **argv)
             const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol);
             const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
             rep("dual MODE0 rot 0.5 (GeomR)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 10));
+            rep("split MODE0 rot 0.5 (GeomR)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 1>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 2>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 10));
         }
         {   // a general rotation (Rz(0.6) Ry(0.8) Rx(0.7), what the reference's random rigid init looks like)
             const double a = 0.8, bz = 0.6, c = 0.7;
@@ -149,6 +151,7 @@ int main(int argc, char **argv)
             const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol);
             const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
             rep("dual MODE0 rot .8/.6/.7", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 10));
+            rep("split MODE0 rot .8/.6/.7", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 1>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 2>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 10));
             rep("tile MODE0 rot .8/.6/.7", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 10));
             for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = rt[i];
             CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
@@ -157,10 +160,12 @@ int main(int argc, char **argv)
         for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = id[i];
         CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
     }
+    rep("tile MODE0 identity (before)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
     {
         const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol);
         const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
         rep("dual MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 20));
+        rep("split MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 1>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 2>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 20));
     }
     rep("tile MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
     return 0;

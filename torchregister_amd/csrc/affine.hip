@@ -307,7 +307,7 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #define TRX_BOX_POLICY ""   // cache policy suffix of the box DMA (development: " nt", " sc1")
 #endif
 #ifndef TRX_DUAL_DEFAULT
-#define TRX_DUAL_DEFAULT 1   // 1: rigid steps, loss-only, warp and warp-backward launches pick GeomA / GeomR per pair in the kernel; 0: never
+#define TRX_DUAL_DEFAULT 1   // rigid steps, loss-only, warp and warp-backward launches pick GeomA / GeomR per pair: 1 in one kernel, 2 as two launches; 0: never
 #endif
 #ifndef TRX_DMA_EXECZ_SKIP
 #define TRX_DMA_EXECZ_SKIP 1   // branch over a DMA piece none of whose lanes fetch (an LDS-DMA with exec = 0 still costs its issue)
@@ -1133,12 +1133,15 @@ __global__ __launch_bounds__(GeomP::Threads, TRX_TILE_MIN_WAVES) void affine_til
 // The dual kernel: per pair, GeomA where its box holds the pre-image of a GeomA tile for this theta (decided from the
 // tile-independent maximum extent, the same bound the fast loop fetches), GeomR otherwise.  The grid is sized for the geometry
 // with more blocks; the surplus blocks of the other one write a zero partial row and leave.
-template <int MODE>
+// WHICH = 0: both bodies in one kernel.  WHICH = 1 / 2: only the GeomA / GeomR body - the pair of launches (1 then 2) does the
+// same job with each body compiled on its own (measured alternative: bench.py 0.328 ms per step against 0.323 ms for the two-body
+// kernel and 0.311-0.320 ms for the single-geometry kernel): blocks of a pair that the other geometry owns leave at once.
+template <int MODE, int WHICH = 0>
 __global__ __launch_bounds__(512, TRX_TILE_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tgA,
                                                                                    TileGeom tgR, int channels, float *__restrict__ partials)
 {
     static_assert(GeomA::Threads == 512 && GeomR::Threads == 512, "both geometries run 512-thread blocks");
-    constexpr int kAlloc = GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc;
+    constexpr int kAlloc = WHICH == 1 ? GeomA::BoxAlloc : (WHICH == 2 ? GeomR::BoxAlloc : (GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc));
     __shared__ __attribute__((aligned(16))) float box[kAlloc];
     constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : 5);
@@ -1155,16 +1158,31 @@ __global__ __launch_bounds__(512, TRX_TILE_MIN_WAVES) void affine_tile_dual_kern
                        ((((int)floorf(span[0] + 0.1f) + 5) >> 2) + 1 <= GeomA::BW4) && ((int)floorf(span[1] + 0.1f) + 3 <= GeomA::BH) &&
                        ((int)floorf(span[2] + 0.1f) + 3 <= GeomA::BD);
     const bool useA = __builtin_amdgcn_readfirstlane(fitsA ? 1 : 0) != 0;
+    if ((WHICH == 1 && !useA) || (WHICH == 2 && useA)) return;   // the other launch owns this pair (and its surplus rows)
     const int mine = useA ? tgA.blocks_per_pair : tgR.blocks_per_pair;
     if ((int)blockIdx.x >= mine) {
         if (MODE != 3 && threadIdx.x < NP) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + threadIdx.x] = 0.f;
         return;
     }
-    if (!useA) {
-        tile_body<MODE, GeomR>(vol, theta, tgR, channels, partials, box, blockIdx.x, blockIdx.y);
-        return;
+    if constexpr (WHICH != 1) {
+        if (!useA) {
+            tile_body<MODE, GeomR>(vol, theta, tgR, channels, partials, box, blockIdx.x, blockIdx.y);
+            return;
+        }
     }
-    tile_body<MODE, GeomA>(vol, theta, tgA, channels, partials, box, blockIdx.x, blockIdx.y);
+    if constexpr (WHICH != 2) tile_body<MODE, GeomA>(vol, theta, tgA, channels, partials, box, blockIdx.x, blockIdx.y);
+}
+
+// GeomA / GeomR per pair: one two-body launch or the pair of single-body launches (TRX_AFFINE_DUAL = 1 / 2, default 1: the pair costs one more launch and gains nothing).
+template <int MODE>
+static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const float *theta, const TileGeom &ta, const TileGeom &tr, int channels, float *out, int how)
+{
+    if (how == 1) {
+        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out);
+    } else {
+        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 1>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out);
+        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 2>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out);
+    }
 }
 
 #pragma clang diagnostic pop
@@ -1457,11 +1475,12 @@ constexpr int kTargetBlocks = 2048;
 
 using namespace trx;
 
-// 0 = primary geometry only, 1 = dual (GeomA / GeomR chosen per pair inside the kernel).  TRX_AFFINE_DUAL overrides (development).
-static bool use_dual()
+// 0 = primary geometry only, 1 = GeomA / GeomR chosen per pair inside one two-body kernel, 2 = the same choice as a pair of
+// single-body launches.  TRX_AFFINE_DUAL overrides (development).
+static int use_dual()
 {
     static const int v = [] { const char *e = getenv("TRX_AFFINE_DUAL"); return e ? atoi(e) : TRX_DUAL_DEFAULT; }();
-    return v != 0 && TRX_TILE_CFG == 0;
+    return TRX_TILE_CFG == 0 ? v : 0;
 }
 
 // partial rows per pair that a tile-path launch may write (the dual grid is sized for the geometry with more blocks)
@@ -1534,7 +1553,7 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
         if (dual && use_dual()) {
             const TileGeom ta = tile_geom<GeomA>(*vol), tr = tile_geom<GeomR>(*vol);
             const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
-            hipLaunchKernelGGL((affine_tile_dual_kernel<MODE>), dim3(gx, vol->B), dim3(512), 0, s, v, theta, ta, tr, 1, partials);
+            launch_dual<MODE>(dim3(gx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual());
             TRX_CHECK_LAUNCH();
             *nblk = gx;
             return TRX_OK;
@@ -1566,7 +1585,8 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     // Rigid runs start from a random pose (reference: torch.rand, up to 1 rad) and live at large rotations: their F1 pass picks
     // GeomA / GeomR per pair in the kernel.  Affine runs start at the identity and use the primary kernel, whose GeomA code is
     // 2-5 % faster near the identity than the same body inside the dual kernel (code layout); beyond ~0.1 rad they gather from L2.
-    rc = launch_f1<0>(vol, st->theta, partials, &nblk, s, st->mode == TRX_PARAM_RIGID);
+    static const bool dual_affine = [] { const char *e = getenv("TRX_AFFINE_DUAL_STEPS"); return e && atoi(e) != 0; }();   // development: affine-mode steps too
+    rc = launch_f1<0>(vol, st->theta, partials, &nblk, s, st->mode == TRX_PARAM_RIGID || dual_affine);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
     if (vol->ndim == 3)
@@ -1635,7 +1655,7 @@ extern "C" int trx_affine_warp(const trx_volumes *vol, const float *theta, int c
             const TileGeom ta = tile_geom<GeomA>(v), tr = tile_geom<GeomR>(v);
             v.B = vol->B;
             const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
-            hipLaunchKernelGGL((affine_tile_dual_kernel<3>), dim3(gx, vol->B * channels), dim3(512), 0, s, v, theta, ta, tr, channels, out);
+            launch_dual<3>(dim3(gx, vol->B * channels), s, v, theta, ta, tr, channels, out, use_dual());
             TRX_CHECK_LAUNCH();
             return TRX_OK;
         }
@@ -1677,7 +1697,7 @@ extern "C" int trx_affine_warp_backward(const trx_volumes *vol, const float *the
         if (use_dual()) {
             const TileGeom ta = tile_geom<GeomA>(*vol), tr = tile_geom<GeomR>(*vol);
             rows = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
-            hipLaunchKernelGGL((affine_tile_dual_kernel<2>), dim3(rows, vol->B), dim3(512), 0, s, v, theta, ta, tr, 1, partials);
+            launch_dual<2>(dim3(rows, vol->B), s, v, theta, ta, tr, 1, partials, use_dual());
         } else {
             hipLaunchKernelGGL((affine_tile_kernel<2>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
         }
