@@ -312,6 +312,9 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #ifndef TRX_DMA_EXECZ_SKIP
 #define TRX_DMA_EXECZ_SKIP 1   // branch over a DMA piece none of whose lanes fetch (an LDS-DMA with exec = 0 still costs its issue)
 #endif
+#ifndef TRX_FIN_ABLATE
+#define TRX_FIN_ABLATE 0
+#endif
 #ifndef TRX_STAGE_PRIO
 #define TRX_STAGE_PRIO 3
 #endif
@@ -1278,15 +1281,18 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
     constexpr int NG = TRX_FIN_THREADS / 64;
     double s = 0.0;
     if (k < NP) {
-        // batches of 8 independent loads per thread (all in flight together), fixed summation order
-        for (int blk0 = grp; blk0 < nblk; blk0 += 8 * NG) {
-            float a[8];
+        // batches of 16 independent loads per thread (all in flight together: one memory round trip for up to 256 rows),
+        // fixed summation order
+        for (int blk0 = grp; blk0 < nblk; blk0 += 16 * NG) {
+            float a[16];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
+            for (int i = 0; i < 16; i++) {
                 const int blk = blk0 + i * NG;
-                a[i] = (blk < nblk) ? part[(size_t)blk * NP + k] : 0.f;
+                const float v = part[(size_t)min(blk, nblk - 1) * NP + k];   // clamped, unconditional: a predicated load compiles to
+                a[i] = (blk < nblk) ? v : 0.f;                              // branch + s_waitcnt per load (16 serial round trips)
             }
-            s += (((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) + (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]));
+            s += ((((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) + (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]))) +
+                 ((((double)a[8] + (double)a[9]) + ((double)a[10] + (double)a[11])) + (((double)a[12] + (double)a[13]) + ((double)a[14] + (double)a[15])));
         }
     }
     acc[grp][k] = s;
@@ -1311,29 +1317,47 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
     constexpr int NPOSE = (ND == 3) ? 6 : 3;
     __shared__ double S[64];
     const int b = blockIdx.x;
-    reduce_partials<NP>(partials + (size_t)b * nblk * NP, nblk, S);
     // Lane-parallel epilogue: lane i owns parameter i.  Every load of the per-pair state is issued up front
     // by all lanes at once (ONE memory round trip; a single thread looping over the 12 parameters paid a
-    // dependent load->store chain per parameter, ~20 us); the scalar fp64 math is computed redundantly.
+    // dependent load->store chain per parameter, ~20 us) and BEFORE the partial rows, so that the state and the rows share
+    // one wait; the scalar fp64 math is computed redundantly.
     __shared__ double sh_dth[NT];
     __shared__ float sh_pose[NPOSE];
     const int i = threadIdx.x;
-    if (i >= 64) return;
     const bool rigid = st.mode == TRX_PARAM_RIGID;
     const int np = rigid ? NPOSE : NT;
     float *param = st.param + (size_t)b * TRX_PSTRIDE;
     float *theta = st.theta + (size_t)b * TRX_PSTRIDE;
     const int ic = min(i, NT - 1);
-    const int t = st.step[b];
-    const float best_prev = st.best_loss[b];
-    const float theta_old = theta[ic], p_old = param[ic];
-    float m_old = 0.f, v_old = 0.f;
-    if (oc.kind == TRX_OPT_ADAM) { m_old = st.adam_m[(size_t)b * TRX_PSTRIDE + ic]; v_old = st.adam_v[(size_t)b * TRX_PSTRIDE + ic]; }
+    int t = 0;
+    float best_prev = 0.f, theta_old = 0.f, p_old = 0.f, m_old = 0.f, v_old = 0.f;
     float pose_old[NPOSE];
-    if (rigid) {
+    double bc1 = 1.0, rsbc2 = 1.0;
+    if (i < 64) {
+        t = st.step[b];
+        best_prev = st.best_loss[b];
+        theta_old = theta[ic]; p_old = param[ic];
+        if (oc.kind == TRX_OPT_ADAM) { m_old = st.adam_m[(size_t)b * TRX_PSTRIDE + ic]; v_old = st.adam_v[(size_t)b * TRX_PSTRIDE + ic]; }
+        if (rigid) {
 #pragma unroll
-        for (int k = 0; k < NPOSE; k++) pose_old[k] = param[k];
+            for (int k = 0; k < NPOSE; k++) pose_old[k] = param[k];
+        }
     }
+#if TRX_FIN_ABLATE == 2   // development: no reduction
+    if (i < 64) S[i] = 1.0 + 0.01 * i;
+    __syncthreads();
+    if (false)
+#endif
+    reduce_partials<NP>(partials + (size_t)b * nblk * NP, nblk, S);
+    if (i < 64 && oc.kind == TRX_OPT_ADAM) {   // beta^(t+1) by repeated squaring: a dozen fp64 multiplies instead of two pow() calls
+        bc1 = 1.0 - ipow((double)oc.beta1, t + 1);
+        rsbc2 = 1.0 / sqrt(1.0 - ipow((double)oc.beta2, t + 1));
+    }
+    if (i >= 64) return;
+#if TRX_FIN_ABLATE == 1   // development: reduction only
+    if (i == 0) st.step[b] = t + 1 + (int)(S[0] > 1e300) + (int)(bc1 + rsbc2 + theta_old + p_old + m_old + v_old + best_prev > 1e300);
+    return;
+#endif
 
     const LossCoef L = loss_from_moments(S, nvox, lc);
     const double scale[3] = {0.5 * W, 0.5 * H, 0.5 * D};
@@ -1370,9 +1394,7 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
             const float vi = oc.beta2 * v_old + (1.0f - oc.beta2) * gf * gf;
             st.adam_m[(size_t)b * TRX_PSTRIDE + i] = mi;
             st.adam_v[(size_t)b * TRX_PSTRIDE + i] = vi;
-            const double bc1 = 1.0 - pow((double)oc.beta1, (double)(t + 1));
-            const double bc2 = 1.0 - pow((double)oc.beta2, (double)(t + 1));
-            const float denom = (float)(sqrt((double)vi) / sqrt(bc2)) + oc.eps;
+            const float denom = (float)(sqrt((double)vi) * rsbc2) + oc.eps;
             p_new = p_old - (float)((double)oc.lr / bc1) * (mi / denom);
         } else {
             p_new = p_old - oc.lr * gf;

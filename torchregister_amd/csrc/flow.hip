@@ -117,7 +117,8 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int blk = blk0 + i * 128;
-            a[i] = (blk < nblk) ? partials[((size_t)b * nblk + blk) * kFlowNP + k] : 0.f;
+            const float v = partials[((size_t)b * nblk + min(blk, nblk - 1)) * kFlowNP + k];   // clamped + select: a predicated load
+            a[i] = (blk < nblk) ? v : 0.f;                                                     // compiles to a branch and a wait per load
         }
         s += (((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) + (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]));
     }
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
     c.q = (float)((double)lc.w_mse * 2.0 / n + (double)lc.w_ssd * (double)lc.ssd_alpha * 2.0);
     int t = t_step;
     if (oc.kind == TRX_OPT_ADAM) {
-        const double bc1 = 1.0 - pow((double)oc.beta1, (double)(t + 1)), bc2 = 1.0 - pow((double)oc.beta2, (double)(t + 1));
+        const double bc1 = 1.0 - ipow((double)oc.beta1, t + 1), bc2 = 1.0 - ipow((double)oc.beta2, t + 1);
         c.step_size = (float)((double)oc.lr / bc1);
         c.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     } else {

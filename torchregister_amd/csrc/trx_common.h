@@ -30,6 +30,15 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));   // 4-byte aligned pair -> ds_read2_b32
 
 // floor(x) as int32 in ONE instruction (v_cvt_flr_i32_f32) instead of v_floor_f32 + v_cvt_i32_f32
+// b^n by repeated squaring: the Adam bias terms 1 - beta^t in the finalise / coefficient kernels (two fp64 pow() calls cost ~1 us on one lane)
+__device__ __forceinline__ double ipow(double b, int n)
+{
+    double r = 1.0;
+    for (; n > 0; n >>= 1, b *= b)
+        if (n & 1) r *= b;
+    return r;
+}
+
 __device__ __forceinline__ int floor_to_int(float x)
 {
     int i;
