@@ -9,6 +9,10 @@
 
 namespace trx {
 
+// v_exp_f32 itself: exp2f() wraps it in a denormal-range guard (compare, two selects, add, multiply - as many issue slots as the
+// exponential).  Arguments here are <= 0 and the terms are summed with O(1) neighbours, so a result flushed below 2^-126 is exact enough.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 constexpr int kKdeChunk = 4096;   // samples per block (16 KB of LDS)
 
 // partial[n][chunk][k] = sum over the chunk of exp(-((s - x_k)/h)^2 / 2)
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(256) void kde_pdf_partial_kernel(const float *__res
                 // exp(-((s - x)/h)^2 / 2) = exp2(c (s - x)^2), c = -log2(e) / (2 h^2): 3 packed ops + 2 exp2 per two samples
                 f2 d01 = {v.x - x, v.y - x}, d23 = {v.z - x, v.w - x};
                 d01 = d01 * d01 * c2; d23 = d23 * d23 * c2;
-                a01 += f2{exp2f(d01.x), exp2f(d01.y)}; a23 += f2{exp2f(d23.x), exp2f(d23.y)};
+                a01 += f2{fast_exp2(d01.x), fast_exp2(d01.y)}; a23 += f2{fast_exp2(d23.x), fast_exp2(d23.y)};
             }
             const float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
             acc += (double)((a0 + a1) + (a2 + a3));
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void kde_pdf_partial_kernel(const float *__res
             float a0 = 0.f;
             for (int i = c16; i < cnt; i++) {
                 const float d = s[i] - x;
-                a0 += exp2f(d * d * c2);
+                a0 += fast_exp2(d * d * c2);
             }
             acc += (double)a0;
         }
@@ -55,20 +59,39 @@ __global__ __launch_bounds__(256) void kde_pdf_partial_kernel(const float *__res
 }
 
 // pdf[n][k] = scale * sum over chunks (fixed order, fp64)
-__global__ __launch_bounds__(256) void kde_pdf_finalize_kernel(const double *__restrict__ partial, int nchunk, int bins, double scale, float *__restrict__ pdf)
+// 64 bins x 16 chunk groups per block: thread (g, k) adds chunks g, g + 16, ... (8 loads in flight), the groups are then added in
+// fixed order.  (One thread per bin walking all ~250-500 chunks on 8 CUs took 78 us for 8 rows - latency, not bytes.)
+__global__ __launch_bounds__(1024) void kde_pdf_finalize_kernel(const double *__restrict__ partial, int nchunk, int bins, double scale, float *__restrict__ pdf)
 {
-    const int n = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= bins) return;
+    __shared__ double acc[16][64];
+    const int n = blockIdx.y, kl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl, kc = min(k, bins - 1);
+    const double *__restrict__ row = partial + (long)n * nchunk * bins + kc;
     double a = 0.0;
-    for (int c = 0; c < nchunk; c++) a += partial[((long)n * nchunk + c) * bins + k];
-    pdf[(long)n * bins + k] = (float)(a * scale);
+    for (int c0 = g; c0 < nchunk; c0 += 8 * 16) {
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int c = c0 + i * 16;
+            const double x = row[(long)min(c, nchunk - 1) * bins];   // clamped + select keeps the eight loads in flight together
+            v[i] = (c < nchunk) ? x : 0.0;
+        }
+        a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    acc[g][kl] = a;
+    __syncthreads();
+    if (g != 0 || k >= bins) return;
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) t += acc[i][kl];
+    pdf[(long)n * bins + k] = (float)(t * scale);
 }
 
 // grad_s[n][i] = sum_k g[n][k] * d pdf[n][k] / d s[n][i] = scale * sum_k g_k * exp(-u^2/2) * (-u) / h,  u = (s_i - x_k) / h
 __global__ __launch_bounds__(256) void kde_pdf_backward_kernel(const float *__restrict__ sig, const float *__restrict__ xis, const float *__restrict__ gpdf, long S,
                                                                int bins, float inv_h, float scale, float *__restrict__ gsig)
 {
-    __shared__ float xs[1024], gs[1024];
+    __shared__ __attribute__((aligned(16))) float xs[1024], gs[1024];
     const int n = blockIdx.y, tid = threadIdx.x;
     for (int k = tid; k < bins; k += 256) { xs[k] = xis[(long)n * bins + k]; gs[k] = gpdf[(long)n * bins + k]; }
     __syncthreads();
@@ -77,16 +100,22 @@ __global__ __launch_bounds__(256) void kde_pdf_backward_kernel(const float *__re
     const float v = sig[(long)n * S + i];
     const float c2 = -0.5f * 1.4426950408889634f * inv_h * inv_h;
     // sum_k g_k (s - x_k) exp2(c (s - x_k)^2); the common factor -scale / h^2 is applied once at the end
-    float a0 = 0.f, a1 = 0.f;
+    // four bins per step: two 16-byte LDS broadcasts, 5 packed ops + 2 exp2 per two (sample, bin) pairs
+    f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+    const f2 vv = {v, v};
     int k = 0;
-    for (; k + 1 < bins; k += 2) {
-        const float d0 = v - xs[k], d1 = v - xs[k + 1];
-        a0 = fmaf(gs[k] * d0, exp2f(d0 * d0 * c2), a0);
-        a1 = fmaf(gs[k + 1] * d1, exp2f(d1 * d1 * c2), a1);
+    for (; k + 3 < bins; k += 4) {
+        const float4 x = *reinterpret_cast<const float4 *>(&xs[k]), g = *reinterpret_cast<const float4 *>(&gs[k]);
+        const f2 d01 = vv - f2{x.x, x.y}, d23 = vv - f2{x.z, x.w};
+        const f2 t01 = d01 * d01 * c2, t23 = d23 * d23 * c2;
+        const f2 e01 = {fast_exp2(t01.x), fast_exp2(t01.y)}, e23 = {fast_exp2(t23.x), fast_exp2(t23.y)};
+        a01 += (f2{g.x, g.y} * d01) * e01;
+        a23 += (f2{g.z, g.w} * d23) * e23;
     }
-    if (k < bins) {
+    float a0 = (a01.x + a01.y), a1 = (a23.x + a23.y);
+    for (; k < bins; k++) {
         const float d0 = v - xs[k];
-        a0 = fmaf(gs[k] * d0, exp2f(d0 * d0 * c2), a0);
+        a0 = fmaf(gs[k] * d0, fast_exp2(d0 * d0 * c2), a0);
     }
     gsig[(long)n * S + i] = -scale * inv_h * inv_h * (a0 + a1);
 }
@@ -114,7 +143,7 @@ extern "C" int trx_kde_pdf(const float *signals, const float *xis, int N, long S
     hipLaunchKernelGGL(kde_pdf_partial_kernel, dim3(nchunk, N), dim3(256), 0, s, signals, xis, S, bins, 1.0f / h, (double *)workspace);
     TRX_CHECK_LAUNCH();
     const double scale = 1.0 / ((double)h * (double)S * 6.283185307179586);   // (1/h) * (1/S) * 1/(2 pi)
-    hipLaunchKernelGGL(kde_pdf_finalize_kernel, dim3((bins + 255) / 256, N), dim3(256), 0, s, (const double *)workspace, nchunk, bins, scale, pdf);
+    hipLaunchKernelGGL(kde_pdf_finalize_kernel, dim3((bins + 63) / 64, N), dim3(1024), 0, s, (const double *)workspace, nchunk, bins, scale, pdf);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
