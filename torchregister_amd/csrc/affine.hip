@@ -1460,11 +1460,9 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_warp_kernel(trx_volumes vol,
     const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
     float *__restrict__ o = out + (size_t)b * channels * nvox;
     const float fW = (float)W, fH = (float)H, fD = (float)D;
-    for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
-        const int x = (int)(i % W);
-        const size_t r = i / W;
-        const int y = (int)(r % H);
-        const int z = (int)(r / H);
+    for (VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W); vw.i < nvox; vw.next(H, W)) {
+        const size_t i = vw.i;
+        const int x = vw.x, y = vw.y, z = vw.z;
         const float xn = base_coord(vol.xn, x, W), yn = base_coord(vol.yn, y, H);
         if constexpr (ND == 3) {
             const float zn = base_coord(vol.zn, z, D);

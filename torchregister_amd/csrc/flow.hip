@@ -30,14 +30,6 @@ struct Slab {
     const float *halo_lo, *halo_hi;
 };
 
-__device__ __forceinline__ void decode(size_t i, int H, int W, int &z, int &y, int &x)
-{
-    x = (int)(i % W);
-    const size_t r = i / W;
-    y = (int)(r % H);
-    z = (int)(r / H);
-}
-
 // sample at p + flow; returns value and derivative in flow-channel order (dim0, dim1[, dim2])
 template <int ND>
 __device__ __forceinline__ float flow_sample(const float *__restrict__ mov, const float *__restrict__ fl, size_t nvox,
@@ -71,9 +63,9 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_moments_kernel(trx_volumes vol
     const float *__restrict__ fl = flow + (size_t)b * ND * nvox;
     float vals[kFlowNP] = {0, 0, 0, 0, 0, 0, 0, 0};
     const size_t dstride[3] = {ND == 3 ? (size_t)H * W : (size_t)W, ND == 3 ? (size_t)W : 1, 1};
-    for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
-        int z, y, x;
-        decode(i, H, W, z, y, x);
+    for (VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W); vw.i < nvox; vw.next(H, W)) {
+        const size_t i = vw.i;
+        const int z = vw.z, y = vw.y, x = vw.x;
         float d[3];
         const float w = flow_sample<ND>(mov, fl, nvox, i, slab.Dm, H, W, z + slab.zoff, y, x, d);
         const float yv = tgt[i];
@@ -202,9 +194,9 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
     float *fo = flow_out + (size_t)b * ND * nvox;
     const FlowCoef c = coef[b];
     const size_t dstride[3] = {ND == 3 ? (size_t)H * W : (size_t)W, ND == 3 ? (size_t)W : 1, 1};
-    for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
-        int z, y, x;
-        decode(i, H, W, z, y, x);
+    for (VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W); vw.i < nvox; vw.next(H, W)) {
+        const size_t i = vw.i;
+        const int z = vw.z, y = vw.y, x = vw.x;
         float d[3];
         const float w = flow_sample<ND>(mov, fl, nvox, i, slab.Dm, H, W, z + slab.zoff, y, x, d);
         const float yv = tgt[i];
@@ -259,9 +251,9 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_warp_kernel(trx_volumes vol, c
     const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
     const float *__restrict__ fl = flow + (size_t)b * ND * nvox;
     float *__restrict__ o = out + (size_t)b * channels * nvox;
-    for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
-        int z, y, x;
-        decode(i, H, W, z, y, x);
+    for (VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W); vw.i < nvox; vw.next(H, W)) {
+        const size_t i = vw.i;
+        const int z = vw.z, y = vw.y, x = vw.x;
         float d[3];
         for (int ch = 0; ch < channels; ch++) o[ch * nvox + i] = flow_sample<ND>(mov + ch * nvox, fl, nvox, i, D, H, W, z, y, x, d);
     }
@@ -278,9 +270,9 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_warp_bwd_kernel(trx_volumes vo
     const float *__restrict__ fl = flow + (size_t)b * ND * nvox;
     const float *__restrict__ go = grad_out + (size_t)b * channels * nvox;
     float *__restrict__ df = dflow + (size_t)b * ND * nvox;
-    for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
-        int z, y, x;
-        decode(i, H, W, z, y, x);
+    for (VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W); vw.i < nvox; vw.next(H, W)) {
+        const size_t i = vw.i;
+        const int z = vw.z, y = vw.y, x = vw.x;
         float acc[3] = {0.f, 0.f, 0.f};
         for (int ch = 0; ch < channels; ch++) {
             float d[3];
