@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep of the fused F1 step (and the forward warp) against the C oracle in fp64.
+"""Randomised parity sweep of the fused F1 step (affine and rigid mode, forward warp, warp backward) against the C oracle in fp64.
    python tests/fuzz_affine.py [cases] [seed]
 Random shapes (tiny to ~100^3, ragged, W % 4 != 0), random theta (near identity ... large rotations / zoom / flips /
 mostly-out-of-bounds), random loss weights and batch sizes.  Tolerances as in tests/test_gpu_tile_paths.py."""
@@ -33,10 +33,26 @@ def smooth(shape, f):
     return v.float().view(1, 1, *shape)
 
 
-def run(n, seed, grad_bar=2e-4, verbose=True):
+KINK_SHIFT = 2.5e-7   # normalised units = S/2 * 2.5e-7 voxels: ~1 fp32 ulp of a coordinate of magnitude S, whatever S
+
+
+def kink_variants(theta):
+    """theta with all three translations nudged by +/- KINK_SHIFT.  At integer sample coordinates (including -1 and S, where
+    the zero padding starts) the trilinear value is continuous but its derivative jumps by up to a full voxel value: when a
+    sample lies within fp32 rounding of such a coordinate, an fp32 evaluation may legitimately land on the other side.  How
+    much that can matter for THIS theta is measured on the oracle itself: its fp64 gradient at the nudged thetas."""
+    th = np.asarray(theta, dtype=np.float64).reshape(3, 4)
+    out = []
+    for sgn in (+1.0, -1.0):
+        t = th.copy(); t[:, 3] += sgn * KINK_SHIFT
+        out.append(t.reshape(np.asarray(theta).shape))
+    return out
+
+
+def run(n, seed, grad_bar=2e-4, verbose=True, only=None):
     rng = np.random.default_rng(seed)
     worst = {"loss": 0.0, "grad": 0.0, "warp": 0.0}
-    fails = 0
+    fails = kinks = 0
     for it in range(n):
         big = rng.random() < 0.3
         shape = tuple(int(v) for v in (rng.integers(3, 100, 3) if big else rng.integers(3, 48, 3)))
@@ -50,6 +66,11 @@ def run(n, seed, grad_bar=2e-4, verbose=True):
         mov = torch.cat([ph.blobs(shape, 900 + 5 * it + b) + 0.1 * smooth(shape, 0.23) for b in range(B)])
         ths = np.stack([rand_theta(rng, kind) for _ in range(B)])
         th = torch.tensor(ths, dtype=torch.float32)
+        # rigid step (dual kernel: GeomA / GeomR per pair) from a pose drawn like the reference's init (ref:utils.py:316-330) or near zero
+        poses = rng.uniform(0.0, 1.0, (B, 6)) * (1.0 if rng.random() < 0.6 else 0.08)
+        p32 = torch.tensor(poses, dtype=torch.float32)
+        if only is not None and it != only:
+            continue
         s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
         s.run(1)
         wrp_t = eng.affine_warp(th.cuda(), mov.cuda())
@@ -57,6 +78,8 @@ def run(n, seed, grad_bar=2e-4, verbose=True):
         go = 2.0 * (wrp_t - tgt.cuda()) / float(np.prod(shape))
         dth_b = eng.affine_warp_backward(th.cuda(), mov.cuda(), go).cpu().numpy()
         wrp = wrp_t.cpu().numpy()
+        sr = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="rigid", loss=eng.LossSpec(**kw), lr=0.0, init=p32, capacity=1)
+        sr.run(1)
         torch.cuda.synchronize()
         tabs64, tabs32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)
         for b in range(B):
@@ -67,7 +90,11 @@ def run(n, seed, grad_bar=2e-4, verbose=True):
             el = abs(loss - total) / max(1.0, abs(total))
             gmax = max(np.max(np.abs(dth)), 1e-12)
             # fp32 floor of the gradient: the reference's own fp32-vs-fp64 gap (cancellation in the NCC terms), as in the tests
-            gbar = max(grad_bar, 2.0 * np.max(np.abs(dth32 - dth)) / gmax)
+            m64, t64 = mov[b, 0].double().numpy(), tgt[b, 0].double().numpy()
+            kv = kink_variants(tu)
+            ksens = max(np.max(np.abs(oracle.c_affine_loss_grad(m64, t64, t, oracle.wts(**kw), tabs64)[2] - dth)) for t in kv) / gmax
+            kinks += ksens > grad_bar
+            gbar = max(grad_bar, 2.0 * np.max(np.abs(dth32 - dth)) / gmax, 1.5 * ksens)
             eg = np.max(np.abs(grad - dth)) / gmax / gbar * grad_bar     # normalised so that the bar reads grad_bar
             r64 = oracle.c_affine_warp(mov[b, 0].double().numpy(), tu, tabs64)
             r32 = oracle.c_affine_warp(mov[b, 0].numpy(), th[b].numpy(), tabs32)
@@ -75,18 +102,41 @@ def run(n, seed, grad_bar=2e-4, verbose=True):
             _, _, dm64, _ = oracle.c_affine_loss_grad(mov[b, 0].double().numpy(), tgt[b, 0].double().numpy(), tu, oracle.wts(w_mse=1.0), tabs64)
             _, _, dm32, _ = oracle.c_affine_loss_grad(mov[b, 0].numpy(), tgt[b, 0].numpy(), th[b].numpy(), oracle.wts(w_mse=1.0), tabs32)
             mmax = max(np.max(np.abs(dm64)), 1e-12)
-            mbar = max(grad_bar, 2.0 * np.max(np.abs(dm32 - dm64)) / mmax)
+            msens = max(np.max(np.abs(oracle.c_affine_loss_grad(m64, t64, t, oracle.wts(w_mse=1.0), tabs64)[2] - dm64)) for t in kv) / mmax
+            mbar = max(grad_bar, 2.0 * np.max(np.abs(dm32 - dm64)) / mmax, 1.5 * msens)
             eb = np.max(np.abs(dth_b[b] - dm64)) / mmax / mbar * grad_bar
-            worst["loss"] = max(worst["loss"], el); worst["grad"] = max(worst["grad"], eg, eb); worst["warp"] = max(worst["warp"], ew / bw)
-            bad = el > 2e-5 or eg > grad_bar or eb > grad_bar or ew > bw or not np.isfinite(loss)
+            pu = p32[b].double().numpy()
+            thr = oracle.c_theta_fwd(pu)
+            tot_r, _, dth_r, _ = oracle.c_affine_loss_grad(mov[b, 0].double().numpy(), tgt[b, 0].double().numpy(), thr, oracle.wts(**kw), tabs64)
+            dp = oracle.c_theta_vjp(pu, dth_r)
+            _, _, dth_r32, _ = oracle.c_affine_loss_grad(mov[b, 0].numpy(), tgt[b, 0].numpy(), oracle.c_theta_fwd(p32[b].numpy()), oracle.wts(**kw), tabs32)
+            dp32 = oracle.c_theta_vjp(p32[b].numpy(), dth_r32)
+            pmax = max(np.max(np.abs(dp)), 1e-12)
+            psens = max(np.max(np.abs(oracle.c_theta_vjp(pu, oracle.c_affine_loss_grad(m64, t64, t, oracle.wts(**kw), tabs64)[2]) - dp))
+                        for t in kink_variants(thr)) / pmax
+            kinks += psens > grad_bar
+            pbar = max(grad_bar, 2.0 * np.max(np.abs(dp32 - dp)) / pmax, 1.5 * psens)
+            er = np.max(np.abs(sr.grad[b, :6].cpu().numpy() - dp)) / pmax / pbar * grad_bar
+            elr = abs(sr.losses[b, 0].item() - tot_r) / max(1.0, abs(tot_r))
+            el = max(el, elr)
+            worst["loss"] = max(worst["loss"], el); worst["warp"] = max(worst["warp"], ew / bw)
+            worst["grad"] = max(worst["grad"], eg, eb, er)
+            bad = el > 2e-5 or eg > grad_bar or eb > grad_bar or er > grad_bar or ew > bw or not np.isfinite(loss)
             if bad:
                 fails += 1
-                if verbose: print(f"FAIL case {it} pair {b}: shape {shape} B {B} kind {kind} kw {kw} loss err {el:.2e} grad err {eg:.2e} bwd err {eb:.2e} warp err/bar {ew / bw:.2f}\n theta {tu.tolist()}")
+                if verbose and only is not None:
+                    e = np.abs(wrp[b, 0] - r32)
+                    idx = np.argwhere(e > bw)
+                    print(" warp: voxels over the bar:", len(idx), "first", idx[:6].tolist(), "last", idx[-3:].tolist(),
+                          "\n gpu", [float(wrp[b, 0][tuple(i)]) for i in idx[:6]], "\n ref", [float(r32[tuple(i)]) for i in idx[:6]])
+                    print(" pose", pu.tolist(), "\n gpu pose grad", sr.grad[b, :6].cpu().numpy(), "\n oracle", dp, "\n oracle fp32", dp32)
+                if verbose: print(f"FAIL case {it} pair {b}: shape {shape} B {B} kind {kind} kw {kw} loss err {el:.2e} grad err {eg:.2e} bwd err {eb:.2e} rigid err {er:.2e} warp err/bar {ew / bw:.2f}\n theta {tu.tolist()}")
     if verbose:
-        print(f"{n} cases, {fails} failures; worst loss rel {worst['loss']:.2e} (bar 2e-5), grad rel-to-max {worst['grad']:.2e} (bar {grad_bar:.0e}), warp err/bar {worst['warp']:.2f}")
+        print(f"{n} cases, {fails} failures ({kinks} gradient bars widened: a sample within fp32 rounding of an integer coordinate, see kink_variants); worst loss rel {worst['loss']:.2e} (bar 2e-5), grad rel-to-max {worst['grad']:.2e} (bar {grad_bar:.0e}), warp err/bar {worst['warp']:.2f}")
     return fails, worst
 
 
 if __name__ == "__main__":
-    f, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    f, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+               only=int(sys.argv[3]) if len(sys.argv) > 3 else None)   # third argument: re-run one case of the sweep verbosely
     sys.exit(1 if f else 0)

@@ -188,3 +188,33 @@ def test_rigid_step_dual_geometry_vs_oracle(eng, shape, pname):
         r32 = oracle.c_affine_warp(mov[b, 0].numpy(), th32[b].cpu().numpy(), oracle.base_tables(shape, np.float32))
         r64 = oracle.c_affine_warp(mov[b, 0].double().numpy(), th32[b].cpu().double().numpy(), tabs)
         assert np.max(np.abs(w[b, 0] - r32)) <= max(2e-6, 3.0 * np.max(np.abs(r32 - r64)))
+
+
+def test_straddling_float4_moves_between_tiles(eng):
+    """Regression (found by tests/fuzz_affine.py, seed 5 case 79): W % 4 != 0 and a column of tiles whose box origin shifts by
+    4 voxels in x from one tile to the next.  The slot that straddles x = W (fetched whole, tail zeroed after landing) then sits in
+    a different float4 of the box while the cached fetch masks - keyed on the slot range only - stayed valid, and the tail of
+    the wrong slot was zeroed: 8 voxels of this warp were off by up to 70 %.  The straddler's position is part of the key now."""
+    shape = (54, 83, 90)
+    th64 = np.array([[0.9194692373275757, -0.213600292801857, -0.11958087980747223, 0.1763327270746231],
+                     [0.220373272895813, 1.001311182975769, 0.19802626967430115, 0.39654022455215454],
+                     [0.08663784712553024, -0.28822240233421326, 0.7801948189735413, -0.27287742495536804]])
+    # three pairs, as in the sweep: the batch size sets how many tiles of a column one block walks (tile_geom's y split)
+    x = torch.cat([ph.blobs(shape, 1295 + b) + 0.25 for b in range(3)])
+    th = torch.tensor(th64, dtype=torch.float32)[None].expand(3, 3, 4).contiguous()
+    w = eng.affine_warp(th.cuda(), x.cuda()).cpu().numpy()
+    for b in range(3):
+        r64 = oracle.c_affine_warp(x[b, 0].double().numpy(), th[b].double().numpy(), oracle.base_tables(shape, np.float64))
+        r32 = oracle.c_affine_warp(x[b, 0].numpy(), th[b].numpy(), oracle.base_tables(shape, np.float32))
+        assert np.max(np.abs(w[b, 0] - r32)) <= max(2e-6, 3.0 * np.max(np.abs(r32 - r64)))
+    x, th = x[:1], th[:1]
+    # the fused step at the same theta (single-geometry kernel: global gather for this rotation) and through the dual kernel
+    tgt = ph.blobs(shape, 77)
+    for mode_kw in (dict(mode="affine", init=th.reshape(1, 12)),):
+        s = eng.AffineSolver(x.cuda(), tgt.cuda(), loss=eng.LossSpec(w_mse=1.0), lr=0.0, capacity=1, **mode_kw)
+        s.run(1)
+        torch.cuda.synchronize()
+        total, _, dth, _ = oracle.c_affine_loss_grad(x[0, 0].double().numpy(), tgt[0, 0].double().numpy(), th[0].double().numpy(), oracle.wts(w_mse=1.0),
+                                                     oracle.base_tables(shape, np.float64))
+        assert abs(s.losses[0, 0].item() - total) <= 2e-5 * max(1.0, abs(total))
+        assert np.max(np.abs(s.grad[0, :12].cpu().numpy().reshape(3, 4) - dth)) <= 2e-4 * np.max(np.abs(dth))

@@ -600,7 +600,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
             const int eym = (int)floorf(ext_hi[1] - ext_lo[1] + slack2) + 3, ezm = (int)floorf(ext_hi[2] - ext_lo[2] + slack2) + 3;
             lim_blk = __builtin_amdgcn_readfirstlane(((min(ezm, kBD) - 1) << 16) | ((min(eym, kBH) - 1) << 8) | (min(ex4m, kBW4) - 1));
         }
-        int m_lim = -1, m_lo = -1, m_hi = -1;
+        int m_lim = -1, m_lo = -1, m_hi = -1, m_px = -2;
 #if TRX_TIMING
         unsigned long long tm_acc[4] = {0, 0, 0, 0};   // wave 0: stage-wait, barrier-1 wait, gather, barrier-2 wait
 #endif
@@ -630,11 +630,13 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
               const bool none = (hiz < loz) || (hiy < loy) || (hix < lox);   // the whole pre-image lies outside the volume
               const int lo = none ? 0x7f7f7f : ((loz << 16) | (loy << 8) | lox);
               const int hi = none ? 0 : ((hiz << 16) | (hiy << 8) | hix);
-              if (lim != m_lim || lo != m_lo || hi != m_hi) {
-                  m_lim = lim; m_lo = lo; m_hi = hi;
+              // float4 index of the slot straddling x = W (W % 4 != 0) if this tile fetches it.  It moves with ox, so it is part of
+              // the cache key: two tiles of a column can share (lim, lo, hi) while the straddler sits in different slots.
+              const int part_x = ((W & 3) && !none && ((W - ox) >> 2) <= hix) ? ((W - ox) >> 2) : -1;
+              if (lim != m_lim || lo != m_lo || hi != m_hi || part_x != m_px) {
+                  m_lim = lim; m_lo = lo; m_hi = hi; m_px = part_x;
                   m_oob = 0;
                   m_part = 0;
-                  const int part_x = (W & 3) ? ((W - ox) >> 2) : -1;   // float4 index of the slot straddling x = W
                   int ln = lane;   // opaque copy: keeps the slot decode inside this (rarely taken) branch
                   asm volatile("" : "+v"(ln));
                   unsigned rbx;
