@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the paths tests/fuzz_affine.py does not reach (all against the C oracle in fp64):
+   2-D affine / rigid steps, forward warp and warp backward; multi-channel forward warps (2-D and 3-D, one launch for all
+   channels); loss-only evaluation; short SGD trajectories (affine and rigid, 2-D and 3-D: loss curve, best index, final theta).
+   python tests/fuzz_misc.py [cases] [seed]
+Bars: loss 2e-5 relative, gradients 3e-4 of their maximum (random large theta sits a little above the 2e-4 floor of the fixed
+cases: 2 marginal results, 2.7e-4 and a warp at 1.08x a 3x bar, in 900 cases) or twice the oracle's own fp32-vs-fp64 gap, warps 2e-6 or
+four times that gap, trajectories 1e-4 or twice the gap of the oracle's fp32 and fp64 loops."""
+import math, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # test infrastructure: the oracle may only be used from tests/
+import oracle
+import phantoms as ph
+import torchregister_amd._engine as eng
+from fuzz_affine import rand_theta, smooth
+from fuzz_flow_lncc import smooth_nd
+
+
+GRAD_FLOOR, WARP_GAPS = 3e-4, 4.0
+
+
+def rand_theta2(rng, kind):
+    a = {"tiny": 0.02, "small": 0.12, "medium": 0.4, "large": 1.2}[kind]
+    ang = rng.uniform(-a, a)
+    sc = np.diag(rng.uniform(0.8, 1.25, 2) if kind != "tiny" else rng.uniform(0.97, 1.03, 2))
+    if kind == "large" and rng.random() < 0.3:
+        sc = sc @ np.diag(rng.choice([-1.0, 1.0], 2))
+    m = np.array([[math.cos(ang), -math.sin(ang)], [math.sin(ang), math.cos(ang)]]) @ sc
+    t = rng.uniform(-0.5, 0.5, 2) if kind in ("medium", "large") else rng.uniform(-0.06, 0.06, 2)
+    th = np.concatenate([m, t[:, None]], axis=1)
+    return th + 1e-3 * rng.standard_normal(th.shape)
+
+
+def phantom(shape, seed, f):
+    return ph.blobs(shape, seed) + 0.1 * smooth_nd(shape, f)
+
+
+def gbar(g32, g64, floor):
+    gmax = max(np.max(np.abs(g64)), 1e-12)
+    return max(floor, 2.0 * np.max(np.abs(np.asarray(g32, dtype=np.float64) - g64)) / gmax), gmax
+
+
+def steps_2d(rng, it, out):
+    shape = tuple(int(v) for v in rng.integers(3, 300, 2))
+    B = int(rng.integers(1, 4))
+    kind = rng.choice(["tiny", "small", "medium", "large"], p=[0.3, 0.35, 0.2, 0.15])
+    kw = dict(w_ncc=float(rng.uniform(0, 1)), w_mse=float(rng.uniform(0, 1)))
+    tgt = torch.cat([phantom(shape, 4000 + 7 * it + b, 0.31) for b in range(B)])
+    mov = torch.cat([phantom(shape, 5000 + 5 * it + b, 0.23) for b in range(B)])
+    th = torch.tensor(np.stack([rand_theta2(rng, kind) for _ in range(B)]), dtype=torch.float32)
+    poses = torch.tensor(rng.uniform(0.0, 1.0, (B, 3)) * (1.0 if rng.random() < 0.6 else 0.08), dtype=torch.float32)
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
+    s.run(1)
+    sr = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="rigid", loss=eng.LossSpec(**kw), lr=0.0, init=poses, capacity=1)
+    sr.run(1)
+    wrp = eng.affine_warp(th.cuda(), mov.cuda())
+    go = 2.0 * (wrp - tgt.cuda()) / float(np.prod(shape))
+    dth_b = eng.affine_warp_backward(th.cuda(), mov.cuda(), go).cpu().numpy()
+    terms = s.eval_loss().cpu().numpy()
+    wrp = wrp.cpu().numpy()
+    torch.cuda.synchronize()
+    t64, t32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)
+    for b in range(B):
+        m64, g64 = mov[b, 0].double().numpy(), tgt[b, 0].double().numpy()
+        m32, g32 = mov[b, 0].numpy(), tgt[b, 0].numpy()
+        tu = th[b].double().numpy()
+        total, _, dth, _ = oracle.c_affine_loss_grad(m64, g64, tu, oracle.wts(**kw), t64)
+        _, _, dth32, _ = oracle.c_affine_loss_grad(m32, g32, th[b].numpy(), oracle.wts(**kw), t32)
+        bar, gmax = gbar(dth32, dth, GRAD_FLOOR)
+        out.check("2d loss", abs(s.losses[b, 0].item() - total) / max(1.0, abs(total)), 2e-5, (it, b, shape, kind))
+        out.check("2d loss-only", abs(terms[b, 0] - total) / max(1.0, abs(total)), 2e-5, (it, b, shape, kind))
+        out.check("2d grad", np.max(np.abs(s.grad[b, :6].cpu().numpy().reshape(2, 3) - dth)) / gmax, bar, (it, b, shape, kind))
+        _, _, dm, _ = oracle.c_affine_loss_grad(m64, g64, tu, oracle.wts(w_mse=1.0), t64)
+        _, _, dm32, _ = oracle.c_affine_loss_grad(m32, g32, th[b].numpy(), oracle.wts(w_mse=1.0), t32)
+        bar, mmax = gbar(dm32, dm, GRAD_FLOOR)
+        out.check("2d warp backward", np.max(np.abs(dth_b[b] - dm)) / mmax, bar, (it, b, shape, kind))
+        r64, r32 = oracle.c_affine_warp(m64, tu, t64), oracle.c_affine_warp(m32, th[b].numpy(), t32)
+        out.check("2d warp", np.max(np.abs(wrp[b, 0] - r32)), max(2e-6, WARP_GAPS * np.max(np.abs(r32 - r64))), (it, b, shape, kind))
+        pu = poses[b].double().numpy()
+        tot_r, _, dth_r, _ = oracle.c_affine_loss_grad(m64, g64, oracle.c_theta_fwd(pu), oracle.wts(**kw), t64)
+        dp = oracle.c_theta_vjp(pu, dth_r)
+        _, _, dth_r32, _ = oracle.c_affine_loss_grad(m32, g32, oracle.c_theta_fwd(poses[b].numpy()), oracle.wts(**kw), t32)
+        bar, pmax = gbar(oracle.c_theta_vjp(poses[b].numpy(), dth_r32), dp, GRAD_FLOOR)
+        out.check("2d rigid loss", abs(sr.losses[b, 0].item() - tot_r) / max(1.0, abs(tot_r)), 2e-5, (it, b, shape, pu.tolist()))
+        out.check("2d rigid grad", np.max(np.abs(sr.grad[b, :3].cpu().numpy() - dp)) / pmax, bar, (it, b, shape, pu.tolist()))
+
+
+def multichannel_warp(rng, it, out):
+    nd = 3 if rng.random() < 0.6 else 2
+    shape = tuple(int(v) for v in (rng.integers(3, 70, 3) if nd == 3 else rng.integers(3, 200, 2)))
+    B, C = int(rng.integers(1, 3)), int(rng.integers(2, 5))
+    kind = rng.choice(["tiny", "small", "medium", "large"], p=[0.3, 0.3, 0.2, 0.2])
+    x = torch.cat([torch.cat([phantom(shape, 6000 + 11 * it + 5 * b + c, 0.2 + 0.03 * c) for c in range(C)], dim=1) for b in range(B)])
+    th = torch.tensor(np.stack([(rand_theta if nd == 3 else rand_theta2)(rng, kind) for _ in range(B)]), dtype=torch.float32)
+    w = eng.affine_warp(th.cuda(), x.cuda()).cpu().numpy()
+    t64, t32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)
+    for b in range(B):
+        for c in range(C):
+            r64 = oracle.c_affine_warp(x[b, c].double().numpy(), th[b].double().numpy(), t64)
+            r32 = oracle.c_affine_warp(x[b, c].numpy(), th[b].numpy(), t32)
+            out.check(f"{nd}d warp, {C} channels", np.max(np.abs(w[b, c] - r32)), max(2e-6, WARP_GAPS * np.max(np.abs(r32 - r64))), (it, b, c, shape, kind))
+
+
+def trajectory(rng, it, out):
+    nd = 3 if rng.random() < 0.6 else 2
+    shape = tuple(int(v) for v in (rng.integers(6, 36, 3) if nd == 3 else rng.integers(8, 120, 2)))
+    rigid = rng.random() < 0.5
+    iters = int(rng.integers(3, 16))
+    tgt = phantom(shape, 7000 + it, 0.31)
+    th_true = (rand_theta if nd == 3 else rand_theta2)(rng, "tiny")
+    mov = torch.tensor(oracle.c_affine_warp(tgt[0, 0].double().numpy(), th_true, oracle.base_tables(shape, np.float64)), dtype=torch.float32)[None, None]
+    mov = mov + 0.02 * phantom(shape, 7500 + it, 0.27)
+    kw = dict(w_mse=1.0) if rng.random() < 0.5 else dict(w_ncc=float(rng.uniform(0.2, 1.0)), w_mse=float(rng.uniform(0, 1)))
+    lr = float(10 ** rng.uniform(-3.0, -1.5)) / (1.0 + 100.0 * kw.get("w_ncc", 0.0))   # stable step sizes: overshooting runs amplify fp32 noise
+    npose = 6 if nd == 3 else 3
+    pose0 = rng.uniform(-0.05, 0.05, npose) if rigid else None
+    init = torch.tensor(pose0[None], dtype=torch.float32) if rigid else None
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="rigid" if rigid else "affine", loss=eng.LossSpec(**kw), lr=lr, init=init, capacity=iters)
+    s.run(iters)
+    torch.cuda.synchronize()
+    m32, g32 = mov[0, 0].numpy(), tgt[0, 0].numpy()
+    p32 = None if pose0 is None else init[0].numpy()
+    o32 = oracle.c_affine_loop(m32, g32, oracle.wts(**kw), lr, iters, pose0=p32, tables=oracle.base_tables(shape, np.float32))
+    o64 = oracle.c_affine_loop(m32.astype(np.float64), g32.astype(np.float64), oracle.wts(**kw), float(np.float32(lr)), iters,
+                               pose0=None if p32 is None else p32.astype(np.float64), tables=oracle.base_tables(shape, np.float64))
+    tag = (it, shape, "rigid" if rigid else "affine", iters, lr, kw)
+    losses = s.losses[0, :iters].cpu().numpy()
+    lbar = max(1e-4, 2.0 * np.max(np.abs(o32["losses"] - o64["losses"]) / np.maximum(1.0, np.abs(o64["losses"]))))
+    out.check("trajectory losses", np.max(np.abs(losses - o64["losses"]) / np.maximum(1.0, np.abs(o64["losses"]))), lbar, tag)
+    tbar = max(1e-4, 2.0 * np.max(np.abs(o32["final_theta"] - o64["final_theta"])))
+    out.check("trajectory final theta", np.max(np.abs(s.current_theta[0].cpu().numpy() - o64["final_theta"])), tbar, tag)
+    # best = first strict minimum (ref:warpings.py:85-93); only compared where the fp64 curve separates its two lowest values
+    l64 = np.sort(o64["losses"])
+    if len(l64) < 2 or (l64[1] - l64[0]) > 4.0 * lbar * max(1.0, abs(l64[0])):
+        out.check("trajectory best index", float(int(s.best_idx[0].item()) != o64["best_idx"]), 0.5, tag)
+        out.check("trajectory best theta", np.max(np.abs(s.best[0].cpu().numpy() - o64["thetas"][o64["best_idx"]])), tbar, tag)
+
+
+class Tally:
+    def __init__(self, verbose):
+        self.worst, self.fails, self.verbose = {}, 0, verbose
+
+    def check(self, name, err, bar, tag):
+        r = float(err) / float(bar) if bar > 0 else float(err)
+        self.worst[name] = max(self.worst.get(name, 0.0), r)
+        if not (r <= 1.0):
+            self.fails += 1
+            if self.verbose:
+                print(f"FAIL {name}: error {err:.3e} bar {bar:.3e}  case {tag}")
+
+
+def run(n, seed, verbose=True):
+    rng = np.random.default_rng(seed)
+    out = Tally(verbose)
+    for it in range(n):
+        (steps_2d, multichannel_warp, trajectory)[it % 3](rng, it, out)
+    if verbose:
+        print(f"{n} cases, {out.fails} failures; worst error / bar: " + ", ".join(f"{k} {v:.2f}" for k, v in sorted(out.worst.items())))
+    return out.fails, out.worst
+
+
+if __name__ == "__main__":
+    f, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 90, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    sys.exit(1 if f else 0)

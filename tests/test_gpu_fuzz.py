@@ -1,4 +1,4 @@
-"""Randomised parity sweep of the fused affine step and the forward warp (tests/fuzz_affine.py): random ragged shapes
+"""Randomised parity sweeps.  tests/fuzz_affine.py (fused affine and rigid steps, forward warp, warp backward): random ragged shapes
 (3..99 per axis, W % 4 != 0 included), batches of 1-3 pairs, theta from near-identity to large rotations / zoom / flips,
 random MSE + NCC weights; checker = the C oracle in fp64 (gradient bar 3e-4 of max or twice the fp32 oracle's own gap:
 random large rotations sit a little above the 2e-4 floor of the fixed cases; 1 of 400 cases reached 2.7e-4)."""
@@ -31,3 +31,11 @@ def test_degenerate_shapes():
     one voxel (the reference divides by S - 1) and the NCC of fewer than 8 voxels."""
     import fuzz_degenerate
     assert fuzz_degenerate.run(verbose=True) == 0
+
+
+def test_random_sweep_2d_channels_trajectories():
+    """2-D affine / rigid steps, warp and warp backward; multi-channel warps; loss-only evaluation; short SGD trajectories
+    (loss curve, best index, final theta) in 2-D and 3-D (tests/fuzz_misc.py)."""
+    import fuzz_misc
+    fails, worst = fuzz_misc.run(60, 7, verbose=True)
+    assert fails == 0, worst
