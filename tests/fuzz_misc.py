@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the paths tests/fuzz_affine.py does not reach (all against the C oracle in fp64):
    2-D affine / rigid steps, forward warp and warp backward; multi-channel forward warps (2-D and 3-D, one launch for all
-   channels); loss-only evaluation; short SGD trajectories (affine and rigid, 2-D and 3-D: loss curve, best index, final theta).
+   channels); loss-only evaluation; short SGD and Adam trajectories (affine and rigid, 2-D and 3-D: loss curve, best index, final theta).
    python tests/fuzz_misc.py [cases] [seed]
 Bars: loss 2e-5 relative, gradients 3e-4 of their maximum (random large theta sits a little above the 2e-4 floor of the fixed
 cases: 2 marginal results, 2.7e-4 and a warp at 1.08x a 3x bar, in 900 cases) or twice the oracle's own fp32-vs-fp64 gap, warps 2e-6 or
@@ -12,6 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # test infrastructure: the oracle may only be used from tests/
 import oracle
+from oracle import compose
 import phantoms as ph
 import torchregister_amd._engine as eng
 from fuzz_affine import rand_theta, smooth
@@ -117,15 +118,26 @@ def trajectory(rng, it, out):
     npose = 6 if nd == 3 else 3
     pose0 = rng.uniform(-0.05, 0.05, npose) if rigid else None
     init = torch.tensor(pose0[None], dtype=torch.float32) if rigid else None
-    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="rigid" if rigid else "affine", loss=eng.LossSpec(**kw), lr=lr, init=init, capacity=iters)
+    adam = rng.random() < 0.4          # Adam (extension, torch.optim.Adam defaults) against the torch composition of the same ops
+    if adam:
+        lr = float(10 ** rng.uniform(-3.5, -2.3))
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="rigid" if rigid else "affine", loss=eng.LossSpec(**kw), lr=lr, init=init, capacity=iters,
+                         optimizer="adam" if adam else "sgd")
     s.run(iters)
     torch.cuda.synchronize()
     m32, g32 = mov[0, 0].numpy(), tgt[0, 0].numpy()
     p32 = None if pose0 is None else init[0].numpy()
-    o32 = oracle.c_affine_loop(m32, g32, oracle.wts(**kw), lr, iters, pose0=p32, tables=oracle.base_tables(shape, np.float32))
-    o64 = oracle.c_affine_loop(m32.astype(np.float64), g32.astype(np.float64), oracle.wts(**kw), float(np.float32(lr)), iters,
-                               pose0=None if p32 is None else p32.astype(np.float64), tables=oracle.base_tables(shape, np.float64))
-    tag = (it, shape, "rigid" if rigid else "affine", iters, lr, kw)
+    if adam:
+        def loop(dt):
+            r = compose.affine_loop(mov.to(dt), tgt.to(dt), float(np.float32(lr)), iters, pose0=None if init is None else init[0].to(dt), optimizer="adam", **kw)
+            th = r["thetas"].double().numpy()
+            return dict(losses=r["losses"].numpy(), thetas=th, final_theta=th[-1], best_idx=r["best_idx"])
+        o32, o64 = loop(torch.float32), loop(torch.float64)
+    else:
+        o32 = oracle.c_affine_loop(m32, g32, oracle.wts(**kw), lr, iters, pose0=p32, tables=oracle.base_tables(shape, np.float32))
+        o64 = oracle.c_affine_loop(m32.astype(np.float64), g32.astype(np.float64), oracle.wts(**kw), float(np.float32(lr)), iters,
+                                   pose0=None if p32 is None else p32.astype(np.float64), tables=oracle.base_tables(shape, np.float64))
+    tag = (it, shape, "rigid" if rigid else "affine", "adam" if adam else "sgd", iters, lr, kw)
     losses = s.losses[0, :iters].cpu().numpy()
     lbar = max(1e-4, 2.0 * np.max(np.abs(o32["losses"] - o64["losses"]) / np.maximum(1.0, np.abs(o64["losses"]))))
     out.check("trajectory losses", np.max(np.abs(losses - o64["losses"]) / np.maximum(1.0, np.abs(o64["losses"]))), lbar, tag)
