@@ -2,7 +2,7 @@
 """Randomised parity sweep of the paths tests/fuzz_affine.py does not reach (all against the C oracle in fp64):
    2-D affine / rigid steps, forward warp and warp backward; multi-channel forward warps (2-D and 3-D, one launch for all
    channels); loss-only evaluation; short SGD and Adam trajectories (affine and rigid, 2-D and 3-D: loss curve, best index, final theta); dense-flow trajectories
-   (SGD / Adam, with and without the smoothness term, vs the torch composition) and their Z-slab partition (random cuts) vs the whole volume.
+   (SGD / Adam, with and without the smoothness term, vs the torch composition) and their Z-slab partition (random cuts) vs the whole volume; the Parzen-window PDFs of the NMI loss, forward and backward.
    python tests/fuzz_misc.py [cases] [seed]
 Bars: loss 2e-5 relative, gradients 3e-4 of their maximum (random large theta sits a little above the 2e-4 floor of the fixed
 cases: 2 marginal results, 2.7e-4 and a warp at 1.08x a 3x bar, in 900 cases) or twice the oracle's own fp32-vs-fp64 gap, warps 2e-6 or
@@ -262,6 +262,33 @@ def flow_trajectory(rng, it, out):
         out.check("slab field", torch.max(torch.abs(flow - s.flow)).item(), max(1e-4 * max(1.0, s.flow.abs().max().item()), fb if adam else 0.0), tag + (bounds,))
 
 
+def kde_pdf(rng, it, out):
+    """Parzen-window PDFs of the NMI loss (trx_kde_pdf / trx_kde_pdf_backward) vs the reference's [N, S, bins] formulation
+    (ref:utils.py:24-30) in fp64: ragged sample counts (the kernel works in chunks of 4096 and groups of 16), 1..1024 bins."""
+    import torchregister_amd.utils as U
+    N = int(rng.integers(1, 5))
+    S = int(rng.choice([rng.integers(1, 40), rng.integers(40, 5000), rng.integers(4000, 14000)]))
+    bins = int(rng.choice([rng.integers(1, 9), rng.integers(9, 300), rng.integers(300, 1025)], p=[0.25, 0.6, 0.15]))
+    h = float(rng.choice([0.05, 0.1, 0.5, 1.0, 3.0]))
+    sig = torch.tensor(rng.uniform(-0.2, 1.3, (N, S)), dtype=torch.float32)
+    xis = torch.linspace(sig.max().item(), sig.min().item(), bins).repeat(N, 1)
+    wts = torch.tensor(rng.uniform(-0.3, 0.7, (N, bins)), dtype=torch.float32)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        sg = sig.clone().to(dt).requires_grad_()
+        diff = sg.unsqueeze(-1) - xis.to(dt).unsqueeze(1)
+        p = (1 / h) * torch.mean((1 / (2 * torch.pi)) * torch.exp(-((diff / h) ** 2) / 2), dim=1)
+        (p * wts.to(dt)).sum().backward()
+        ref[dt] = (p.detach().double().numpy(), sg.grad.double().numpy())
+    sc = sig.clone().cuda().requires_grad_()
+    pc = U.PDF_xis(sc, xis.cuda(), h)
+    (pc * wts.cuda()).sum().backward()
+    (p32, g32), (p64, g64) = ref[torch.float32], ref[torch.float64]
+    tag = (it, N, S, bins, h)
+    out.check("kde pdf", np.max(np.abs(pc.detach().cpu().double().numpy() - p64)), max(2e-6 * np.max(np.abs(p64)), 2 * np.max(np.abs(p32 - p64))), tag)
+    out.check("kde pdf backward", np.max(np.abs(sc.grad.cpu().double().numpy() - g64)), max(1e-5 * np.max(np.abs(g64)), 2 * np.max(np.abs(g32 - g64)), 1e-12), tag)
+
+
 class Tally:
     def __init__(self, verbose):
         self.worst, self.fails, self.verbose = {}, 0, verbose
@@ -284,7 +311,7 @@ def run(n, seed, verbose=True, only=None):
         if only is not None and it == only:
             os.environ["FUZZ_DEBUG"] = "1"
         # (every case draws from the shared generator, so earlier cases are re-run to reach case `only`)
-        (steps_2d, multichannel_warp, trajectory, flow_trajectory)[it % 4](rng, it, out)
+        (steps_2d, multichannel_warp, trajectory, flow_trajectory, kde_pdf)[it % 5](rng, it, out)
     if verbose:
         print(f"{n} cases, {out.fails} failures; worst error / bar: " + ", ".join(f"{k} {v:.2f}" for k, v in sorted(out.worst.items())))
     return out.fails, out.worst
