@@ -56,6 +56,8 @@ def run(n, seed, grad_bar=2e-4, verbose=True, only=None):
     for it in range(n):
         big = rng.random() < 0.3
         shape = tuple(int(v) for v in (rng.integers(3, 100, 3) if big else rng.integers(3, 48, 3)))
+        if os.environ.get("FUZZ_BIG"):   # a few large ragged volumes (many tiles per column, several block rounds): minutes per case on the oracle
+            shape = tuple(int(v) for v in rng.integers(100, 270, 3))
         B = int(rng.integers(1, 4))
         kind = rng.choice(["tiny", "small", "medium", "large"], p=[0.3, 0.35, 0.2, 0.15])
         kw = dict(w_ncc=float(rng.uniform(0, 1)), w_mse=float(rng.uniform(0, 1)))
