@@ -220,6 +220,30 @@ def test_full_size_properties(eng):
     assert abs(s2.losses[0, 0].item() - ncc.item()) <= 2e-4 * max(1.0, abs(ncc.item()))
 
 
+def test_headline_size_step_vs_oracle(eng):
+    """The bench workload itself - 256^3, affine + NCC, theta near the bench's theta* - against the C oracle in fp64 (and its fp32
+    run for the bar): loss 2e-5 relative, dL/dtheta 2e-4 of its maximum or twice the oracle's own fp32-vs-fp64 gap.  Two pairs with
+    different theta in one launch (the oracle needs ~10 s per evaluation at this size, so not the full batch of 8)."""
+    shape = (256, 256, 256)
+    tgt = torch.cat([ph.blobs(shape, 1000), ph.blobs(shape, 1001)])
+    ths = np.stack([np.asarray(ph.THETA_STAR3, dtype=np.float64).reshape(3, 4),
+                    np.eye(3, 4) + 0.02 * np.sin(1.3 * np.arange(12)).reshape(3, 4)])
+    th = torch.tensor(ths, dtype=torch.float32)
+    mov = eng.affine_warp(torch.tensor(np.stack([np.eye(3, 4) + 0.03 * np.cos(0.9 * np.arange(12)).reshape(3, 4)] * 2), dtype=torch.float32).cuda(),
+                          tgt.cuda()).cpu() + 0.05 * torch.cat([ph.blobs(shape, 1002), ph.blobs(shape, 1003)])
+    kw = dict(w_ncc=1.0)
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
+    s.run(1)
+    torch.cuda.synchronize()
+    t64, t32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)
+    for b in range(2):
+        total, _, dth, _ = oracle.c_affine_loss_grad(mov[b, 0].double().numpy(), tgt[b, 0].double().numpy(), th[b].double().numpy(), oracle.wts(**kw), t64)
+        _, _, dth32, _ = oracle.c_affine_loss_grad(mov[b, 0].numpy(), tgt[b, 0].numpy(), th[b].numpy(), oracle.wts(**kw), t32)
+        assert abs(s.losses[b, 0].item() - total) <= 2e-5 * max(1.0, abs(total))
+        gmax = np.max(np.abs(dth))
+        assert np.max(np.abs(s.grad[b, :12].cpu().numpy().reshape(3, 4) - dth)) <= max(2e-4 * gmax, 2.0 * np.max(np.abs(dth32 - dth)))
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 4), (2, 3, 4), (1, 16, 32), (3, 1, 8), (4, 4), (1, 7), (2, 2, 2)])
 def test_tiny_and_degenerate_shapes(eng, shape):
     """Smallest volumes (single voxel rows/planes, sizes below every tile dimension) against the C oracle."""
