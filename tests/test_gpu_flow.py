@@ -129,6 +129,24 @@ def test_flow_extensions_vs_torch(eng, optimizer, smooth):
     assert np.max(np.abs(s.flow.cpu().numpy() - f32)) <= bar(f32, f64, 2e-4)
 
 
+def test_flow_headline_size_vs_oracle(eng):
+    """BASELINE config 3 at full size - one 256^3 pair, dense flow + NCC: loss and dL/dflow of one evaluation against the C oracle in
+    fp64 (bar: 1e-4 of the gradient's maximum or twice the oracle's own fp32-vs-fp64 gap, as in the small cases)."""
+    shape = (256, 256, 256)
+    tgt, mov = ph.blobs(shape, 1000), ph.blobs(shape, 1001)
+    ax = [torch.arange(n, dtype=torch.float64) for n in shape]
+    comp = lambda a, b, c: (torch.sin(a * ax[0])[:, None, None] + torch.cos(b * ax[1])[None, :, None] + torch.sin(c * ax[2] + 0.4)[None, None, :])
+    fl = torch.stack([1.3 * comp(0.021, 0.017, 0.013), 0.9 * comp(0.011, 0.023, 0.019), 1.1 * comp(0.015, 0.012, 0.027)]).float()[None] + 0.37
+    kw = dict(w_ncc=1.0)
+    terms, dfl = eng.flow_loss_grad(mov.cuda(), tgt.cuda(), fl.cuda(), eng.LossSpec(**kw))
+    torch.cuda.synchronize()
+    args = lambda dt: (mov[0, 0].numpy().astype(dt), tgt[0, 0].numpy().astype(dt), fl[0].numpy().astype(dt), oracle.wts(**kw))
+    t64, _, d64, _ = oracle.c_flow_loss_grad(*args(np.float64))
+    t32, _, d32, _ = oracle.c_flow_loss_grad(*args(np.float32))
+    assert abs(terms[0, 0].item() - t64) <= 2e-5 * max(1.0, abs(t64))
+    assert np.max(np.abs(dfl[0].cpu().numpy() - d64)) <= max(1e-4 * np.max(np.abs(d64)), 2.0 * np.max(np.abs(d32.astype(np.float64) - d64)))
+
+
 def test_flow_full_size_properties(eng):
     """256^3: zero flow reproduces moving exactly; integer shift flow == slicing; run is deterministic."""
     shape = (256, 256, 256)
