@@ -12,6 +12,8 @@ Compatibility notes:
   Q6  grad_edges=True crashes in the reference (reflect-pad by 5000 voxels); here it raises.
   Q8  returns [final, best]; "best" = first strict minimum, theta of that forward.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -217,6 +219,14 @@ class flow_register(nn.Module):
             raise NotImplementedError("grad_edges=True is not supported (SURVEY Q6)")
         spec = loss_spec_from(self.criterions, self.weights[: len(self.criterions)])
         if self.flow_model == "unet":
+            # The U-Net's convolutions run in MIOpen through torch.  With torch's default (benchmark off) MIOpen's immediate mode picks
+            # im2col + SGEMM / a CK weight-gradient kernel that need 1.7 s per iteration at 156^3, n = 32; with the solver search on it
+            # is 42 ms per iteration (measured, tools/prof_unet.py).  The one-off search costs the same ~100 s either way (kernel
+            # compilation) and lands in MIOpen's user find-db.  Scoped to this call; TRX_MIOPEN_BENCHMARK=0 keeps torch's setting.
+            # 2-D images gain nothing (6 ms per iteration at 160^2 either way) and would pay a search per layer shape: 3-D only.
+            if moving.dim() == 5 and os.environ.get("TRX_MIOPEN_BENCHMARK", "1") != "0":
+                with torch.backends.cudnn.flags(enabled=True, benchmark=True):
+                    return self._optimize_unet(moving, target, spec, debug)
             return self._optimize_unet(moving, target, spec, debug)
         if spec is None:
             return self._optimize_generic(moving, target, debug)
