@@ -49,6 +49,21 @@ __device__ __forceinline__ float flow_sample(const float *__restrict__ mov, cons
     }
 }
 
+// same, with the flow of this voxel already in registers (f[0..ND-1] in channel order)
+template <int ND>
+__device__ __forceinline__ float flow_sample_v(const float *__restrict__ mov, const float *f, int D, int H, int W, int z, int y, int x, float *d)
+{
+    if constexpr (ND == 3) {
+        Samp3 s = sample3(mov, D, H, W, (float)x + f[2], (float)y + f[1], (float)z + f[0]);
+        d[0] = s.dz; d[1] = s.dy; d[2] = s.dx;
+        return s.v;
+    } else {
+        Samp2 s = sample2(mov, H, W, (float)x + f[1], (float)y + f[0]);
+        d[0] = s.dy; d[1] = s.dx;
+        return s.v;
+    }
+}
+
 constexpr int kFlowNP = 8;  // 5 moments + up to 3 smoothness sums
 
 template <int ND, bool SMOOTH>
@@ -63,12 +78,30 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_moments_kernel(trx_volumes vol
     const float *__restrict__ fl = flow + (size_t)b * ND * nvox;
     float vals[kFlowNP] = {0, 0, 0, 0, 0, 0, 0, 0};
     const size_t dstride[3] = {ND == 3 ? (size_t)H * W : (size_t)W, ND == 3 ? (size_t)W : 1, 1};
-    for (VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W); vw.i < nvox; vw.next(H, W)) {
+    // The flow and target of voxel k+1 are loaded before the gather of voxel k is consumed: the gather addresses depend on the
+    // flow, so without this each iteration is two dependent memory round trips with only four loads in flight in the first.
+    VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W);
+    float fc[3] = {0.f, 0.f, 0.f}, tc = 0.f;
+    if (vw.i < nvox) {
+#pragma unroll
+        for (int c = 0; c < ND; c++) fc[c] = fl[c * nvox + vw.i];
+        tc = tgt[vw.i];
+    }
+    while (vw.i < nvox) {
         const size_t i = vw.i;
         const int z = vw.z, y = vw.y, x = vw.x;
+        vw.next(H, W);
+        const size_t in = vw.i < nvox ? (size_t)vw.i : i;   // clamped: the loads stay unconditional
+        float fn[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < ND; c++) fn[c] = fl[c * nvox + in];
+        const float tn = tgt[in];
         float d[3];
-        const float w = flow_sample<ND>(mov, fl, nvox, i, slab.Dm, H, W, z + slab.zoff, y, x, d);
-        const float yv = tgt[i];
+        const float w = flow_sample_v<ND>(mov, fc, slab.Dm, H, W, z + slab.zoff, y, x, d);
+        const float yv = tc;
+#pragma unroll
+        for (int c = 0; c < ND; c++) fc[c] = fn[c];
+        tc = tn;
         vals[0] += yv; vals[1] += w;
         vals[2] = fmaf(yv, yv, vals[2]); vals[3] = fmaf(w, w, vals[3]); vals[4] = fmaf(yv, w, vals[4]);
         if constexpr (SMOOTH) {
@@ -83,9 +116,9 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_moments_kernel(trx_volumes vol
 #pragma unroll
                 for (int c = 0; c < ND; c++) {
                     const float f0 = fl[c * nvox + i];
-                    float fn = fl[c * nvox + nb];
-                    if (halo) fn = slab.halo_hi[c * ((size_t)H * W) + (size_t)y * W + x];
-                    const float df = fn - f0;
+                    float fnb = fl[c * nvox + nb];
+                    if (halo) fnb = slab.halo_hi[c * ((size_t)H * W) + (size_t)y * W + x];
+                    const float df = fnb - f0;
                     vals[5 + dd] = fmaf(df, df, vals[5 + dd]);
                 }
             }
