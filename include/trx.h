@@ -196,6 +196,15 @@ int trx_kde_pdf(const float *signals, const float *xis, int N, long S, int bins,
                 size_t workspace_bytes, void *stream);
 int trx_kde_pdf_backward(const float *signals, const float *xis, const float *grad_pdf, int N, long S, int bins, float h,
                          float *grad_signals, void *stream);
+/* The same two functions as a series in (s - x)^2 / (2 h^2) (thirteen terms, 2e-14): the S x bins exponentials become 25 fp64 power
+ * sums of the samples and a polynomial per bin.  VALID ONLY when |signals[n][i] - xis[n][k]| <= h for every pair of the call (the NMI
+ * loss's bandwidth 3 on intensities normalised to [0, 1]); the caller checks that and passes `center`, the middle of the value range
+ * of signals and xis.  One workspace size serves both. */
+size_t trx_kde_series_workspace_bytes(int N, long S, int bins);
+int trx_kde_pdf_series(const float *signals, const float *xis, int N, long S, int bins, float h, double center, float *pdf,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int trx_kde_pdf_series_backward(const float *signals, const float *xis, const float *grad_pdf, int N, long S, int bins, float h,
+                                double center, float *grad_signals, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

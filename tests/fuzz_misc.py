@@ -269,7 +269,7 @@ def kde_pdf(rng, it, out):
     N = int(rng.integers(1, 5))
     S = int(rng.choice([rng.integers(1, 40), rng.integers(40, 5000), rng.integers(4000, 14000)]))
     bins = int(rng.choice([rng.integers(1, 9), rng.integers(9, 300), rng.integers(300, 1025)], p=[0.25, 0.6, 0.15]))
-    h = float(rng.choice([0.05, 0.1, 0.5, 1.0, 3.0]))
+    h = float(rng.choice([0.05, 0.1, 0.5, 1.0, 1.5, 1.7, 3.0]))   # >= 1.5: the series form (window >= value range)
     sig = torch.tensor(rng.uniform(-0.2, 1.3, (N, S)), dtype=torch.float32)
     xis = torch.linspace(sig.max().item(), sig.min().item(), bins).repeat(N, 1)
     wts = torch.tensor(rng.uniform(-0.3, 0.7, (N, bins)), dtype=torch.float32)

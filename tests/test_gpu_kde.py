@@ -16,9 +16,14 @@ def _ref_pdf(signals, xis, h):
     return (1 / h) * torch.mean((1 / (2 * torch.pi)) * torch.exp(-((diff / h) ** 2) / 2), dim=1)
 
 
-@pytest.mark.parametrize("N,S,bins,h", [(1, 1000, 256, 3.0), (3, 4096 + 17, 256, 0.1), (2, 30000, 64, 0.5), (8, 5000, 256, 3.0), (1, 7, 5, 1.0)])
-def test_kde_pdf_forward_backward(N, S, bins, h):
+@pytest.mark.parametrize("series", ["1", "0"])
+@pytest.mark.parametrize("N,S,bins,h", [(1, 1000, 256, 3.0), (3, 4096 + 17, 256, 0.1), (2, 30000, 64, 0.5), (8, 5000, 256, 3.0), (1, 7, 5, 1.0),
+                                        (2, 9000, 256, 1.5), (1, 4097, 1024, 1.6), (3, 33, 3, 2.0)])
+def test_kde_pdf_forward_backward(N, S, bins, h, series, monkeypatch):
+    """Both forms of the kernels: one exponential per (sample, bin) pair, and - where the window is at least as wide as the value range
+    (h >= 1.5 here) - the series form (25 power sums + a polynomial per bin); TRX_KDE_SERIES=0 forces the first."""
     import torchregister_amd.utils as U
+    monkeypatch.setenv("TRX_KDE_SERIES", series)
     g = torch.Generator().manual_seed(S + bins)
     sig = torch.rand(N, S, generator=g) * 1.5 - 0.2
     hi, lo = sig.max().item(), sig.min().item()

@@ -479,8 +479,17 @@ def local_ncc_loss_grad(target, warped, window=9, alpha=1.0, eps=1e-5, need_grad
     return loss, grad
 
 
-def kde_pdf(signals, xis, h):
-    """Parzen-window PDF (include/trx.h: trx_kde_pdf): signals [N,S], xis [N,bins] fp32 on the GPU -> pdf [N,bins]."""
+def kde_series_center(signals, xis, h):
+    """Centre of the value range if the series form of the PDF applies (|s - x| <= h for every pair: include/trx.h), else None.
+    One host sync (the reference's get_pdf syncs twice per PDF for its .item() calls anyway, ref:utils.py:40-48)."""
+    ends = torch.stack([signals.detach().amin(), signals.detach().amax(), xis.detach().amin(), xis.detach().amax()]).tolist()
+    lo, hi = min(ends[0], ends[2]), max(ends[1], ends[3])
+    return 0.5 * (lo + hi) if (hi - lo) <= float(h) else None
+
+
+def kde_pdf(signals, xis, h, center=None):
+    """Parzen-window PDF (include/trx.h: trx_kde_pdf / trx_kde_pdf_series): signals [N,S], xis [N,bins] fp32 on the GPU -> pdf [N,bins].
+    center: None = one exponential per (sample, bin) pair; a float = the series form about that value (see kde_series_center)."""
     lib = _lib.load()
     if not (signals.is_cuda and xis.is_cuda):
         raise _lib.TrxError("kde_pdf needs CUDA (HIP) tensors: there is no CPU fallback")
@@ -488,21 +497,31 @@ def kde_pdf(signals, xis, h):
     N, S = sig.shape
     bins = x.shape[1]
     pdf = torch.empty(N, bins, device=sig.device)
-    ws_bytes = lib.trx_kde_workspace_bytes(N, S, bins)
+    ws_bytes = (lib.trx_kde_workspace_bytes if center is None else lib.trx_kde_series_workspace_bytes)(N, S, bins)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=sig.device)
     with torch.cuda.device(sig.device):
-        rc = lib.trx_kde_pdf(_lib.ptr(sig), _lib.ptr(x), N, S, bins, float(h), _lib.ptr(pdf), _lib.ptr(ws), ws_bytes, _lib.current_stream(sig.device))
+        if center is None:
+            rc = lib.trx_kde_pdf(_lib.ptr(sig), _lib.ptr(x), N, S, bins, float(h), _lib.ptr(pdf), _lib.ptr(ws), ws_bytes, _lib.current_stream(sig.device))
+        else:
+            rc = lib.trx_kde_pdf_series(_lib.ptr(sig), _lib.ptr(x), N, S, bins, float(h), float(center), _lib.ptr(pdf), _lib.ptr(ws), ws_bytes,
+                                        _lib.current_stream(sig.device))
     _lib.check(rc, "trx_kde_pdf")
     return pdf
 
 
-def kde_pdf_backward(signals, xis, grad_pdf, h):
+def kde_pdf_backward(signals, xis, grad_pdf, h, center=None):
     lib = _lib.load()
     sig, x, g = signals.detach().contiguous().float(), xis.detach().contiguous().float(), grad_pdf.contiguous().float()
     N, S = sig.shape
     out = torch.empty_like(sig)
     with torch.cuda.device(sig.device):
-        rc = lib.trx_kde_pdf_backward(_lib.ptr(sig), _lib.ptr(x), _lib.ptr(g), N, S, x.shape[1], float(h), _lib.ptr(out), _lib.current_stream(sig.device))
+        if center is None:
+            rc = lib.trx_kde_pdf_backward(_lib.ptr(sig), _lib.ptr(x), _lib.ptr(g), N, S, x.shape[1], float(h), _lib.ptr(out), _lib.current_stream(sig.device))
+        else:
+            ws_bytes = lib.trx_kde_series_workspace_bytes(N, S, x.shape[1])
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=sig.device)
+            rc = lib.trx_kde_pdf_series_backward(_lib.ptr(sig), _lib.ptr(x), _lib.ptr(g), N, S, x.shape[1], float(h), float(center), _lib.ptr(out),
+                                                 _lib.ptr(ws), ws_bytes, _lib.current_stream(sig.device))
     _lib.check(rc, "trx_kde_pdf_backward")
     return out
 

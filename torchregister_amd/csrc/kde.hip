@@ -122,6 +122,146 @@ __global__ __launch_bounds__(256) void kde_pdf_backward_kernel(const float *__re
 
 static int kde_nchunk(long S) { return (int)((S + kKdeChunk - 1) / kKdeChunk); }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Series form.  When the window is wide against the data - |s - x| <= h for every (sample, bin) pair, which is the NMI loss's own
+// setting (bandwidth 3) on intensities normalised to [0, 1] - the Gaussian is its Taylor series in u = d^2 / (2 h^2) <= 1/2, thirteen
+// terms to 2e-14:  sum_i exp(-(s_i - x)^2 / 2h^2) = sum_j a_j sum_i (t_i - y)^{2j},  a_j = (-1 / 2h^2)^j / j!,  t = s - c, y = x - c,
+// and sum_i (t_i - y)^{2j} = sum_m C(2j, m) (-y)^{2j-m} p_m with the power sums p_m = sum_i t_i^m.  The S x bins exponentials become
+// 25 power sums of the samples (fp64) and a 13 x 25 polynomial per bin: O(25 S + 170 bins) instead of O(S bins).  All terms of the
+// binomial sum are bounded by R^{2j} against a result of order (R/2)^{2j}, so fp64 keeps >= 8 digits in the worst (j = 12) term,
+// which itself weighs < 1e-12 of the sum.  The backward is the same algebra: a degree-25 polynomial in t_i whose coefficients
+// come from the moments sum_k g_k (-y_k)^r of the incoming gradient.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int kSerN = 12;               // highest series term
+constexpr int kSerP = 2 * kSerN + 1;    // power sums p_0 .. p_24
+constexpr int kSerQ = 2 * kSerN + 2;    // backward polynomial coefficients q_0 .. q_25
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;   // lane 0
+}
+
+// partial[n][chunk][m] = sum over the chunk of (s - c)^m
+__global__ __launch_bounds__(256) void kde_powsum_kernel(const float *__restrict__ sig, long S, double center, double *__restrict__ partial)
+{
+    __shared__ double red[4][kSerP];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const long i0 = (long)chunk * kKdeChunk;
+    const float *__restrict__ src = sig + (long)n * S + i0;
+    const int cnt = (int)min((long)kKdeChunk, S - i0);
+    double acc[kSerP];
+#pragma unroll
+    for (int m = 0; m < kSerP; m++) acc[m] = 0.0;
+    for (int i = tid; i < cnt; i += 256) {
+        const double t = (double)src[i] - center;
+        double pw = 1.0;
+        acc[0] += 1.0;
+#pragma unroll
+        for (int m = 1; m < kSerP; m++) { pw *= t; acc[m] += pw; }
+    }
+#pragma unroll
+    for (int m = 0; m < kSerP; m++) {
+        const double w = wave_sum(acc[m]);
+        if ((tid & 63) == 0) red[tid >> 6][m] = w;
+    }
+    __syncthreads();
+    if (tid < kSerP) partial[((long)n * gridDim.x + chunk) * kSerP + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// pdf[n][k] = scale * sum_j a_j sum_m C(2j, m) (-y_k)^{2j-m} p_m
+__global__ __launch_bounds__(1024) void kde_series_pdf_kernel(const double *__restrict__ partial, int nchunk, const float *__restrict__ xis, int bins,
+                                                              double center, double inv_2h2, double scale, float *__restrict__ pdf)
+{
+    __shared__ double acc[32][kSerP], p[kSerP];
+    const int n = blockIdx.x, tid = threadIdx.x, m = tid & 31, g = tid >> 5;
+    if (m < kSerP) {   // fixed-order reduction of the chunk partials: 32 groups, then the groups in order
+        double a = 0.0;
+        for (int c = g; c < nchunk; c += 32) a += partial[((long)n * nchunk + c) * kSerP + m];
+        acc[g][m] = a;
+    }
+    __syncthreads();
+    if (tid < kSerP) {
+        double a = 0.0;
+        for (int i = 0; i < 32; i++) a += acc[i][tid];
+        p[tid] = a;
+    }
+    __syncthreads();
+    for (int k = tid; k < bins; k += 1024) {
+        const double ny = center - (double)xis[(long)n * bins + k];   // -y
+        double npw[kSerP];
+        npw[0] = 1.0;
+#pragma unroll
+        for (int r = 1; r < kSerP; r++) npw[r] = npw[r - 1] * ny;
+        double res = 0.0, aj = 1.0;
+        for (int j = 0; j <= kSerN; j++) {
+            double sj = 0.0, coef = 1.0;   // C(2j, m), exact in fp64
+            for (int mm = 0; mm <= 2 * j; mm++) {
+                sj += coef * npw[2 * j - mm] * p[mm];
+                coef = coef * (double)(2 * j - mm) / (double)(mm + 1);
+            }
+            res += aj * sj;
+            aj *= -inv_2h2 / (double)(j + 1);
+        }
+        pdf[(long)n * bins + k] = (float)(scale * res);
+    }
+}
+
+// q[n][m], m = 0 .. 25: d/ds of sum_k g_k pdf_k = -(scale / h^2) * sum_m q_m t^m,
+//   q_m = sum_{j : 2j+1 >= m} a_j C(2j+1, m) G_{2j+1-m},  G_r = sum_k g_k (-y_k)^r
+__global__ __launch_bounds__(256) void kde_series_coef_kernel(const float *__restrict__ xis, const float *__restrict__ gpdf, int bins, double center,
+                                                              double inv_2h2, double *__restrict__ q)
+{
+    __shared__ double red[4][kSerQ], G[kSerQ];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    double acc[kSerQ];
+#pragma unroll
+    for (int r = 0; r < kSerQ; r++) acc[r] = 0.0;
+    for (int k = tid; k < bins; k += 256) {
+        const double ny = center - (double)xis[(long)n * bins + k], gk = (double)gpdf[(long)n * bins + k];
+        double pw = gk;
+#pragma unroll
+        for (int r = 0; r < kSerQ; r++) { acc[r] += pw; pw *= ny; }
+    }
+#pragma unroll
+    for (int r = 0; r < kSerQ; r++) {
+        const double w = wave_sum(acc[r]);
+        if ((tid & 63) == 0) red[tid >> 6][r] = w;
+    }
+    __syncthreads();
+    if (tid < kSerQ) G[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __syncthreads();
+    if (tid < kSerQ) {
+        const int m = tid;
+        double qm = 0.0, aj = 1.0;
+        for (int j = 0; j <= kSerN; j++) {
+            const int nn = 2 * j + 1;
+            if (nn >= m) {
+                double coef = 1.0;   // C(nn, m)
+                for (int i = 0; i < m; i++) coef = coef * (double)(nn - i) / (double)(i + 1);
+                qm += aj * coef * G[nn - m];
+            }
+            aj *= -inv_2h2 / (double)(j + 1);
+        }
+        q[(long)n * kSerQ + m] = qm;
+    }
+}
+
+__global__ __launch_bounds__(256) void kde_series_backward_kernel(const float *__restrict__ sig, long S, double center, const double *__restrict__ q,
+                                                                  double factor, float *__restrict__ gsig)
+{
+    const int n = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    const double *__restrict__ qn = q + (long)n * kSerQ;   // uniform: scalar loads
+    const double t = (double)sig[(long)n * S + i] - center;
+    double a = qn[kSerQ - 1];
+#pragma unroll
+    for (int m = kSerQ - 2; m >= 0; m--) a = fma(a, t, qn[m]);
+    gsig[(long)n * S + i] = (float)(factor * a);
+}
+
 }  // namespace trx
 
 using namespace trx;
@@ -156,6 +296,48 @@ extern "C" int trx_kde_pdf_backward(const float *signals, const float *xis, cons
     const float scale = (float)(1.0 / ((double)h * (double)S * 6.283185307179586));
     hipLaunchKernelGGL(kde_pdf_backward_kernel, dim3((unsigned)((S + 255) / 256), N), dim3(256), 0, (hipStream_t)stream, signals, xis, grad_pdf, S, bins,
                        1.0f / h, scale, grad_signals);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+// Series form of the same PDFs (see the block comment above kde_powsum_kernel): valid when |s - x| <= h for every (sample, bin)
+// pair of the call - the caller checks that (torchregister_amd.utils.PDF_xis does) and passes the centre of the data range.
+extern "C" size_t trx_kde_series_workspace_bytes(int N, long S, int bins)
+{
+    if (N < 1 || S < 1 || bins < 1 || bins > 1024) return 0;
+    const size_t fwd = (size_t)N * kde_nchunk(S) * kSerP * sizeof(double), bwd = (size_t)N * kSerQ * sizeof(double);
+    return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int trx_kde_pdf_series(const float *signals, const float *xis, int N, long S, int bins, float h, double center, float *pdf, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    if (!signals || !xis || !pdf || !workspace) return TRX_ERR_ARG;
+    if (N < 1 || N > 65535 || S < 1 || bins < 1 || bins > 1024 || !(h > 0.f)) return TRX_ERR_ARG;
+    if (workspace_bytes < trx_kde_series_workspace_bytes(N, S, bins)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = kde_nchunk(S);
+    hipLaunchKernelGGL(kde_powsum_kernel, dim3(nchunk, N), dim3(256), 0, s, signals, S, center, (double *)workspace);
+    TRX_CHECK_LAUNCH();
+    const double scale = 1.0 / ((double)h * (double)S * 6.283185307179586);
+    hipLaunchKernelGGL(kde_series_pdf_kernel, dim3(N), dim3(1024), 0, s, (const double *)workspace, nchunk, xis, bins, center, 0.5 / ((double)h * (double)h),
+                       scale, pdf);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+extern "C" int trx_kde_pdf_series_backward(const float *signals, const float *xis, const float *grad_pdf, int N, long S, int bins, float h, double center,
+                                           float *grad_signals, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!signals || !xis || !grad_pdf || !grad_signals || !workspace) return TRX_ERR_ARG;
+    if (N < 1 || N > 65535 || S < 1 || bins < 1 || bins > 1024 || !(h > 0.f)) return TRX_ERR_ARG;
+    if (workspace_bytes < trx_kde_series_workspace_bytes(N, S, bins)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(kde_series_coef_kernel, dim3(N), dim3(256), 0, s, xis, grad_pdf, bins, center, 0.5 / ((double)h * (double)h), (double *)workspace);
+    TRX_CHECK_LAUNCH();
+    const double scale = 1.0 / ((double)h * (double)S * 6.283185307179586);
+    hipLaunchKernelGGL(kde_series_backward_kernel, dim3((unsigned)((S + 255) / 256), N), dim3(256), 0, s, signals, S, center, (const double *)workspace,
+                       -scale / ((double)h * (double)h), grad_signals);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }

@@ -5,6 +5,8 @@ on the GPU through PyTorch-ROCm) so they can be used stand-alone exactly like th
 inside Register.optim the MSE / NCC / SSD family is recognised and replaced by the fused HIP
 kernels (see warpings.loss_spec_from).  SpatialTransformer is backed by the HIP flow kernels.
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn import functional as F
@@ -106,27 +108,35 @@ class _KdePdfFn(torch.autograd.Function):
     """PDF_xis on the GPU without the [N, S, bins] tensor (HIP kernels trx_kde_pdf / trx_kde_pdf_backward)."""
 
     @staticmethod
-    def forward(ctx, signals, xis, h):
+    def forward(ctx, signals, xis, h, value_range=None):
         ctx.save_for_backward(signals, xis)
         ctx.h = float(h)
-        return _engine.kde_pdf(signals, xis, h)
+        # window wide against the data (the NMI loss's bandwidth 3 on normalised intensities): series form, O(S + bins) instead of O(S * bins)
+        ctx.center = None
+        if os.environ.get("TRX_KDE_SERIES", "1") != "0":
+            if value_range is not None:      # (lo, hi) of signals and xis already known on the host (get_pdf): no extra sync
+                lo, hi = value_range
+                ctx.center = 0.5 * (lo + hi) if (hi - lo) <= float(h) else None
+            else:
+                ctx.center = _engine.kde_series_center(signals, xis, h)
+        return _engine.kde_pdf(signals, xis, h, ctx.center)
 
     @staticmethod
     def backward(ctx, g):
         signals, xis = ctx.saved_tensors
-        gs = _engine.kde_pdf_backward(signals, xis, g, ctx.h) if ctx.needs_input_grad[0] else None
-        return gs, None, None
+        gs = _engine.kde_pdf_backward(signals, xis, g, ctx.h, ctx.center) if ctx.needs_input_grad[0] else None
+        return gs, None, None, None
 
 
-def PDF_xis(signals, xis, h=3):
+def PDF_xis(signals, xis, h=3, value_range=None):
     if signals.is_cuda and signals.dim() == 2 and xis.dim() == 2 and xis.shape[1] <= 1024 and signals.dtype == torch.float32:
-        return _KdePdfFn.apply(signals, xis, h)              # same numbers, 4 B per sample instead of 4 * bins
+        return _KdePdfFn.apply(signals, xis, h, value_range)  # same numbers, 4 B per sample instead of 4 * bins
     diff = signals.unsqueeze(-1) - xis.unsqueeze(1)          # [N, S, bins] (the reference's formulation)
     return (1 / h) * torch.mean(K_gauss(diff / h), dim=1)
 
 
-def PDF(signals, Xs, h=3):
-    return PDF_xis(signals, Xs, h)
+def PDF(signals, Xs, h=3, value_range=None):
+    return PDF_xis(signals, Xs, h, value_range)
 
 
 def get_pdf(data, steps=256, bandwidth=2):
@@ -135,7 +145,7 @@ def get_pdf(data, steps=256, bandwidth=2):
     hi, lo = torch.max(signals).item(), torch.min(signals).item()
     line = torch.linspace(hi, lo, steps, dtype=torch.float, device=signals.device) * torch.ones(
         (len(data), steps), dtype=torch.float, device=signals.device)
-    return PDF(signals, line, h=bandwidth)
+    return PDF(signals, line, h=bandwidth, value_range=(lo, hi))   # the sample line spans exactly the signals' range
 
 
 def NMI(img1, img2, bins=256, bandwidth=0.1):
