@@ -312,11 +312,24 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_warp_kernel(trx_volumes vol, c
     const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
     const float *__restrict__ fl = flow + (size_t)b * ND * nvox;
     float *__restrict__ o = out + (size_t)b * channels * nvox;
-    for (VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W); vw.i < nvox; vw.next(H, W)) {
+    VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W);
+    float fc[3] = {0.f, 0.f, 0.f};
+    if (vw.i < nvox) {
+#pragma unroll
+        for (int c = 0; c < ND; c++) fc[c] = fl[c * nvox + vw.i];
+    }
+    while (vw.i < nvox) {   // the next voxel's flow is requested before this voxel's gather is consumed (see flow_moments_kernel)
         const size_t i = vw.i;
         const int z = vw.z, y = vw.y, x = vw.x;
+        vw.next(H, W);
+        const size_t in = vw.i < nvox ? (size_t)vw.i : i;
+        float fnx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < ND; c++) fnx[c] = fl[c * nvox + in];
         float d[3];
-        for (int ch = 0; ch < channels; ch++) o[ch * nvox + i] = flow_sample<ND>(mov + ch * nvox, fl, nvox, i, D, H, W, z, y, x, d);
+        for (int ch = 0; ch < channels; ch++) o[ch * nvox + i] = flow_sample_v<ND>(mov + ch * nvox, fc, D, H, W, z, y, x, d);
+#pragma unroll
+        for (int c = 0; c < ND; c++) fc[c] = fnx[c];
     }
 }
 
@@ -331,13 +344,27 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_warp_bwd_kernel(trx_volumes vo
     const float *__restrict__ fl = flow + (size_t)b * ND * nvox;
     const float *__restrict__ go = grad_out + (size_t)b * channels * nvox;
     float *__restrict__ df = dflow + (size_t)b * ND * nvox;
-    for (VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W); vw.i < nvox; vw.next(H, W)) {
+    VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W);
+    float fc[3] = {0.f, 0.f, 0.f};
+    if (vw.i < nvox) {
+#pragma unroll
+        for (int c = 0; c < ND; c++) fc[c] = fl[c * nvox + vw.i];
+    }
+    while (vw.i < nvox) {
         const size_t i = vw.i;
         const int z = vw.z, y = vw.y, x = vw.x;
+        vw.next(H, W);
+        const size_t in = vw.i < nvox ? (size_t)vw.i : i;
+        float fnx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < ND; c++) fnx[c] = fl[c * nvox + in];
+        const float fcur[3] = {fc[0], fc[1], fc[2]};
+#pragma unroll
+        for (int c = 0; c < ND; c++) fc[c] = fnx[c];
         float acc[3] = {0.f, 0.f, 0.f};
         for (int ch = 0; ch < channels; ch++) {
             float d[3];
-            flow_sample<ND>(mov + ch * nvox, fl, nvox, i, D, H, W, z, y, x, d);
+            flow_sample_v<ND>(mov + ch * nvox, fcur, D, H, W, z, y, x, d);
             const float g = go[ch * nvox + i];
 #pragma unroll
             for (int c = 0; c < ND; c++) acc[c] = fmaf(g, d[c], acc[c]);
