@@ -71,6 +71,41 @@ def loss_spec_from(criterions, weights):
     return spec
 
 
+def split_fusable(criterions, weights):
+    """(LossSpec of the criterions that have a fused form or None, the remaining (criterion, weight) pairs)."""
+    fused_c, fused_w, rest = [], [], []
+    for c, w in zip(criterions, weights):
+        if (type(c) is nn.MSELoss and c.reduction == "mean") or type(c) in (NCCLoss, SSDLoss):
+            fused_c.append(c)
+            fused_w.append(float(w))
+        else:
+            rest.append((c, float(w)))
+    spec = loss_spec_from(fused_c, fused_w) if fused_c else None
+    if spec is None and fused_c:      # e.g. two NCC terms with different alpha: leave them to torch
+        rest = list(zip(criterions, [float(w) for w in weights]))
+    return spec, rest
+
+
+class _FusedLossFn(torch.autograd.Function):
+    """Value and d/dtheta of the fused terms (MSE / NCC / SSD mix) from ONE launch of the F1 kernel: a persistent AffineSolver with lr = 0
+    is pointed at the current theta and stepped once (its loss and gradient slots are read back as tensors, no host sync)."""
+
+    @staticmethod
+    def forward(ctx, theta, solver):
+        nd = solver.nd
+        solver.theta.copy_(_engine.pad_theta(theta.detach().reshape(theta.shape[0], -1), nd))
+        solver.param.copy_(solver.theta)
+        t = int(solver._fused_calls)
+        solver._fused_calls += 1
+        solver.run(1)
+        ctx.grad = solver.grad[:, : nd * (nd + 1)].reshape(theta.shape).clone()
+        return solver.losses[:, t].sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.grad, None
+
+
 def _resolve_criterions(criterions, weights, honor_criterion, device):
     if criterions is None:
         criterions = [nn.MSELoss(), NCCLoss(device=device), NMILoss()]
@@ -92,12 +127,22 @@ def _generic_loop(moving, target, mode, criterions, weights, lr, epochs, init, o
         p = (torch.eye(nd, nd + 1, device=dev)[None] if init is None else init.to(dev).reshape(1, nd, nd + 1)).clone().requires_grad_()
         make = lambda: p  # noqa: E731
     opt = torch.optim.SGD([p], lr) if optimizer == "sgd" else torch.optim.Adam([p], lr)
+    # terms with a fused form (MSE / NCC / SSD) come from one F1 launch; only the others (NMI, user modules) see the warped volume
+    spec, rest = split_fusable(criterions, weights)
+    fused = None
+    if spec is not None and rest and moving.shape[0] == 1:
+        fused = AffineSolver(moving, target, mode="affine", loss=spec, lr=0.0, capacity=max(1, epochs))
+        fused._fused_calls = 0
+    else:
+        rest = list(zip(criterions, weights))
     losses, best = [], None
     for _ in range(epochs):
         opt.zero_grad()
         theta = make()
         warped = get_affine_warp(theta, moving)
-        err = sum(w * c(target, warped) for c, w in zip(criterions, weights))
+        err = sum(w * c(target, warped) for c, w in rest)
+        if fused is not None:
+            err = err + _FusedLossFn.apply(theta, fused)
         err.backward()
         opt.step()
         v = err.item()
