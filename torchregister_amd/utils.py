@@ -139,19 +139,25 @@ def PDF(signals, Xs, h=3, value_range=None):
     return PDF_xis(signals, Xs, h, value_range)
 
 
-def get_pdf(data, steps=256, bandwidth=2):
+def get_pdf(data, steps=256, bandwidth=2, value_range=None):
     signals = torch.flatten(data, start_dim=1)
     # the reference names these (min, max) but takes (max, min): the sample line runs max -> min
-    hi, lo = torch.max(signals).item(), torch.min(signals).item()
+    if value_range is None:
+        hi, lo = torch.max(signals).item(), torch.min(signals).item()
+    else:                     # (hi, lo) already on the host (NMI fetches the extrema of both images in one sync)
+        hi, lo = value_range
     line = torch.linspace(hi, lo, steps, dtype=torch.float, device=signals.device) * torch.ones(
         (len(data), steps), dtype=torch.float, device=signals.device)
     return PDF(signals, line, h=bandwidth, value_range=(lo, hi))   # the sample line spans exactly the signals' range
 
 
 def NMI(img1, img2, bins=256, bandwidth=0.1):
-    h1 = get_pdf(img1, steps=bins, bandwidth=bandwidth)
-    h2 = get_pdf(img2, steps=bins, bandwidth=bandwidth)
-    hj = get_pdf(torch.stack((img1, img2), dim=1), steps=bins, bandwidth=bandwidth)
+    # the six .item() calls of the reference's three get_pdf (ref:utils.py:40-48) as one host sync: the joint sample's extrema are
+    # those of the two images
+    hi1, lo1, hi2, lo2 = torch.stack([img1.detach().amax(), img1.detach().amin(), img2.detach().amax(), img2.detach().amin()]).tolist()
+    h1 = get_pdf(img1, steps=bins, bandwidth=bandwidth, value_range=(hi1, lo1))
+    h2 = get_pdf(img2, steps=bins, bandwidth=bandwidth, value_range=(hi2, lo2))
+    hj = get_pdf(torch.stack((img1, img2), dim=1), steps=bins, bandwidth=bandwidth, value_range=(max(hi1, hi2), min(lo1, lo2)))
     p1 = h1 / h1.sum(dim=1, keepdim=True)
     p2 = h2 / h2.sum(dim=1, keepdim=True)
     pj = hj / hj.sum(dim=1, keepdim=True)
