@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void kde_pdf_backward_kernel(const float *__re
 }
 
 static int kde_nchunk(long S) { return (int)((S + kKdeChunk - 1) / kKdeChunk); }
+static int kde_ser_nchunk(long S);
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Series form.  When the window is wide against the data - |s - x| <= h for every (sample, bin) pair, which is the NMI loss's own
@@ -132,6 +133,7 @@ static int kde_nchunk(long S) { return (int)((S + kKdeChunk - 1) / kKdeChunk); }
 // which itself weighs < 1e-12 of the sum.  The backward is the same algebra: a degree-25 polynomial in t_i whose coefficients
 // come from the moments sum_k g_k (-y_k)^r of the incoming gradient.
 // ------------------------------------------------------------------------------------------------------------------------------
+constexpr int kSerChunk = 16384;        // samples per block of the power-sum pass (64 per thread: the 25 wave reductions are amortised)
 constexpr int kSerN = 12;               // highest series term
 constexpr int kSerP = 2 * kSerN + 1;    // power sums p_0 .. p_24
 constexpr int kSerQ = 2 * kSerN + 2;    // backward polynomial coefficients q_0 .. q_25
@@ -148,9 +150,9 @@ __global__ __launch_bounds__(256) void kde_powsum_kernel(const float *__restrict
 {
     __shared__ double red[4][kSerP];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    const long i0 = (long)chunk * kKdeChunk;
+    const long i0 = (long)chunk * kSerChunk;
     const float *__restrict__ src = sig + (long)n * S + i0;
-    const int cnt = (int)min((long)kKdeChunk, S - i0);
+    const int cnt = (int)min((long)kSerChunk, S - i0);
     double acc[kSerP];
 #pragma unroll
     for (int m = 0; m < kSerP; m++) acc[m] = 0.0;
@@ -262,6 +264,8 @@ __global__ __launch_bounds__(256) void kde_series_backward_kernel(const float *_
     gsig[(long)n * S + i] = (float)(factor * a);
 }
 
+static int kde_ser_nchunk(long S) { return (int)((S + kSerChunk - 1) / kSerChunk); }
+
 }  // namespace trx
 
 using namespace trx;
@@ -305,7 +309,7 @@ extern "C" int trx_kde_pdf_backward(const float *signals, const float *xis, cons
 extern "C" size_t trx_kde_series_workspace_bytes(int N, long S, int bins)
 {
     if (N < 1 || S < 1 || bins < 1 || bins > 1024) return 0;
-    const size_t fwd = (size_t)N * kde_nchunk(S) * kSerP * sizeof(double), bwd = (size_t)N * kSerQ * sizeof(double);
+    const size_t fwd = (size_t)N * kde_ser_nchunk(S) * kSerP * sizeof(double), bwd = (size_t)N * kSerQ * sizeof(double);
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -316,7 +320,7 @@ extern "C" int trx_kde_pdf_series(const float *signals, const float *xis, int N,
     if (N < 1 || N > 65535 || S < 1 || bins < 1 || bins > 1024 || !(h > 0.f)) return TRX_ERR_ARG;
     if (workspace_bytes < trx_kde_series_workspace_bytes(N, S, bins)) return TRX_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const int nchunk = kde_nchunk(S);
+    const int nchunk = kde_ser_nchunk(S);
     hipLaunchKernelGGL(kde_powsum_kernel, dim3(nchunk, N), dim3(256), 0, s, signals, S, center, (double *)workspace);
     TRX_CHECK_LAUNCH();
     const double scale = 1.0 / ((double)h * (double)S * 6.283185307179586);
