@@ -208,7 +208,10 @@ struct TileCfg {
     static constexpr int BoxAlloc = (Bufs * BoxFloats > ReduceScratch) ? Bufs * BoxFloats : ReduceScratch;
     static_assert(BW % 4 == 0 && PP * PlaneSlots <= Threads && (PP == 2 || PP == 4), "one DMA piece: at most one slot per thread");
 };
-using GeomA = TileCfg<32, 8, 512, 44, 23, 14, 2, 1>;      // near-identity transforms: 32 x 16 x 8 tile, 44 x 23 x 14 box (56.7 KB)
+#ifndef TRX_GEOMA_BD
+#define TRX_GEOMA_BD 14   // (13 = 52.6 KB: three blocks per CU fit the LDS; measured with TRX_TILE_MIN_WAVES=6)
+#endif
+using GeomA = TileCfg<32, 8, 512, 44, 23, TRX_GEOMA_BD, 2, 1>;      // near-identity transforms: 32 x 16 x 8 tile, 44 x 23 x 14 box (56.7 KB)
 using GeomDeep = TileCfg<32, 16, 1024, 44, 22, 21, 4, 2>;  // cfg 1 (measured alternative): 1024 threads, two 81 KB boxes
 // Rotated transforms: the pre-image of a 32-wide tile grows by 31 sin(angle) rows / planes and stops fitting any box beyond
 // ~0.1 rad.  A more cubic tile (16 x 16 x 8, four y-quarters of 4 rows per thread) with a 28 x 26 x 16 box (46.6 KB) fits
@@ -315,11 +318,17 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #ifndef TRX_FIN_ABLATE
 #define TRX_FIN_ABLATE 0
 #endif
+#ifndef TRX_SWP
+#define TRX_SWP 1   // software pipeline of the gather: LDS reads of row j+1 issued before the arithmetic of row j (0: at use)
+#endif
 #ifndef TRX_STAGE_PRIO
 #define TRX_STAGE_PRIO 3
 #endif
 #ifndef TRX_TILE_MIN_WAVES
 #define TRX_TILE_MIN_WAVES 4   // waves per SIMD the register allocator must allow (16 waves per CU)
+#endif
+#ifndef TRX_DUAL_MIN_WAVES
+#define TRX_DUAL_MIN_WAVES 4   // the dual kernel's LDS (GeomR's 78.6 KB box) allows two blocks per CU whatever the registers
 #endif
 // packed running sums of the tile kernel: AB[q][c] = (sum q*g_c, sum q*g_c*yn), M01 = (Sy, Sw), M23 = (Syy, Sww)
 struct F1Acc {
@@ -816,14 +825,14 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
 #pragma unroll
               for (int j = 0; j < kRows; j++) {
                   Fetch nxt;
-                  if (j + 1 < kRows) nxt = fetch(j + 1);
+                  if (TRX_SWP && j + 1 < kRows) nxt = fetch(j + 1);
                   if (kBufs == 2 && j < kPieces && dma_next) issue_piece(j);
                   const Samp3 sm = lerp3_pairs<kGrad>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
                   if constexpr (MODE == 3) { if (act) wout[(size_t)Y0 * W + (unsigned)(toff + j * W)] = sm.v; }
                   else f1_accumulate_pk<MODE>(sm, tv[j], yn_r[j], acc);
                   if (kBufs == 2 && TRX_DBG_SKIP != 3 && MODE != 3)
                       asm volatile("global_load_dword %0, %1, %2" : "=v"(tv[j]) : "v"(toffb), "s"(tnext + (size_t)j * W));
-                  if (j + 1 < kRows) cur = nxt;
+                  if (j + 1 < kRows) cur = TRX_SWP ? nxt : fetch(j + 1);
               }
           };
           auto load_targets = [&](int g, float (&tv)[kRows]) {
@@ -1142,7 +1151,7 @@ __global__ __launch_bounds__(GeomP::Threads, TRX_TILE_MIN_WAVES) void affine_til
 // same job with each body compiled on its own (measured alternative: bench.py 0.328 ms per step against 0.323 ms for the two-body
 // kernel and 0.311-0.320 ms for the single-geometry kernel): blocks of a pair that the other geometry owns leave at once.
 template <int MODE, int WHICH = 0>
-__global__ __launch_bounds__(512, TRX_TILE_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tgA,
+__global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tgA,
                                                                                    TileGeom tgR, int channels, float *__restrict__ partials)
 {
     static_assert(GeomA::Threads == 512 && GeomR::Threads == 512, "both geometries run 512-thread blocks");
