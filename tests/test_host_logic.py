@@ -127,6 +127,17 @@ def test_criterion_mapping_follows_reference_branches():
     assert (s.w_mse, s.w_ssd, s.ssd_alpha, s.w_ncc, s.ncc_alpha) == (0.5, 0.1, 2.0, 0.2, 10.0)
     assert w.loss_spec_from([nn.L1Loss()], [1.0]) is None
     assert w.loss_spec_from([nn.MSELoss(reduction="sum")], [1.0]) is None
+    # mixed lists: the terms with a fused form go to one F1 launch, the others stay with torch (warpings._generic_loop)
+    spec, rest = w.split_fusable(c, [0.3, 0.5, 0.2])                  # the default criterion: MSE + NCC fused, NMI generic
+    assert (spec.w_mse, spec.w_ncc, spec.ncc_alpha) == (0.3, 0.5, 100.0) and len(rest) == 1 and type(rest[0][0]) is tr.NMILoss and rest[0][1] == 0.2
+    l1 = nn.L1Loss()
+    spec, rest = w.split_fusable([l1, tr.SSDLoss(alpha=2)], [1.0, 0.25])
+    assert (spec.w_ssd, spec.ssd_alpha, spec.w_mse, spec.w_ncc) == (0.25, 2.0, 0.0, 0.0) and rest == [(l1, 1.0)]
+    spec, rest = w.split_fusable([l1], [1.0])
+    assert spec is None and rest == [(l1, 1.0)]
+    two = [tr.NCCLoss(alpha=10), tr.NCCLoss(alpha=100), l1]          # two NCC terms with different alpha have no single fused form
+    spec, rest = w.split_fusable(two, [1.0, 1.0, 1.0])
+    assert spec is None and [c for c, _ in rest] == two
 
 
 def test_torch_side_helpers_match_golden(single_step):
