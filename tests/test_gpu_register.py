@@ -98,6 +98,37 @@ def test_register_generic_criterion_path(tr):
     assert np.allclose(reg.final_theta.cpu().numpy(), th.detach().numpy(), atol=2e-3)
 
 
+@pytest.mark.parametrize("mode", ["affine", "rigid"])
+def test_register_mixed_criterion_list(tr, mode):
+    """A list that mixes fused terms (NCC, MSE) with one that has no fused form (L1): the fused terms come from one F1 launch
+    (warpings._FusedLossFn), L1 from the generic autograd path, and the sum must follow the same loop on torch's CPU ops in fp64."""
+    from oracle import compose
+    shape = (18, 16, 20)
+    tgt = ph.blobs(shape, 1005)
+    mov = compose.affine_warp(torch.tensor(ph.THETA_STAR3)[None], tgt) + 0.02 * ph.blobs(shape, 1006)
+    w = [0.4, 1.0, 0.7]
+    pose0 = torch.tensor([0.02, -0.03, 0.01, 0.05, 0.0, -0.04])
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        p = (pose0.to(dt).clone() if mode == "rigid" else torch.eye(3, 4, dtype=dt)[None].clone()).requires_grad_()
+        opt = torch.optim.SGD([p], 2e-3)
+        ls = []
+        for _ in range(8):
+            opt.zero_grad()
+            th = compose.pose_to_theta(p) if mode == "rigid" else p
+            y = compose.affine_warp(th, mov.to(dt))
+            e = w[0] * compose.ncc_loss(tgt.to(dt), y) + w[1] * nn.functional.l1_loss(y, tgt.to(dt)) + w[2] * compose.mse_loss(tgt.to(dt), y)
+            e.backward(); opt.step(); ls.append(e.item())
+        ref[dt] = (np.asarray(ls), (compose.pose_to_theta(p) if mode == "rigid" else p).detach().double().numpy().reshape(3, 4))
+    reg = tr.Register(mode, device="cuda", criterion=[tr.NCCLoss(), nn.L1Loss(), nn.MSELoss()], weight=w, honor_criterion=True,
+                      init=pose0 if mode == "rigid" else None)
+    reg.optim(mov.cuda(), tgt.cuda(), lr=2e-3, max_epochs=8)
+    (l32, t32), (l64, t64) = ref[torch.float32], ref[torch.float64]
+    got = reg.losses.cpu().numpy().ravel()
+    assert np.max(np.abs(got - l64) / np.maximum(1.0, np.abs(l64))) <= max(1e-4, 2.0 * np.max(np.abs(l32 - l64) / np.maximum(1.0, np.abs(l64))))
+    assert np.max(np.abs(reg.final_theta.cpu().numpy().reshape(3, 4) - t64)) <= max(1e-4, 2.0 * np.max(np.abs(t32 - t64)))
+
+
 def test_get_affine_warp_autograd(tr, single_step):
     g = single_step
     mov, tgt = ph.vol((5, 6, 7), 0.37, "sin").cuda(), ph.vol((5, 6, 7), 0.23, "cos").cuda()
