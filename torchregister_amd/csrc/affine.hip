@@ -1244,14 +1244,18 @@ template <int ND>
 __device__ void theta_from_pose(const float *p, double *th)
 {
     if constexpr (ND == 3) {
-        const double cps = cos((double)p[0]), sps = sin((double)p[0]);
-        const double cth = cos((double)p[1]), sth = sin((double)p[1]);
-        const double cph = cos((double)p[2]), sph = sin((double)p[2]);
+        double cps, sps;
+        sincos((double)p[0], &sps, &cps);
+        double cth, sth;
+        sincos((double)p[1], &sth, &cth);
+        double cph, sph;
+        sincos((double)p[2], &sph, &cph);
         th[0] = cps * cth; th[1] = sph * sps * cth - cph * sth; th[2] = cph * sps * cth + sph * sth; th[3] = 0.25 * tanh((double)p[3]);
         th[4] = cps * sth; th[5] = sph * sps * sth + cph * cth; th[6] = cph * sps * sth - sph * cth; th[7] = 0.25 * tanh((double)p[4]);
         th[8] = -sps;      th[9] = sph * cps;                   th[10] = cph * cps;                  th[11] = 0.25 * tanh((double)p[5]);
     } else {
-        const double c = cos((double)p[0]), s = sin((double)p[0]);
+        double c, s;
+        sincos((double)p[0], &s, &c);
         th[0] = c; th[1] = -s; th[2] = p[1];
         th[3] = s; th[4] = c;  th[5] = p[2];
     }
@@ -1261,9 +1265,12 @@ template <int ND>
 __device__ void pose_vjp(const float *p, const double *g, double *dx)
 {
     if constexpr (ND == 3) {
-        const double cps = cos((double)p[0]), sps = sin((double)p[0]);
-        const double cth = cos((double)p[1]), sth = sin((double)p[1]);
-        const double cph = cos((double)p[2]), sph = sin((double)p[2]);
+        double cps, sps;
+        sincos((double)p[0], &sps, &cps);
+        double cth, sth;
+        sincos((double)p[1], &sth, &cth);
+        double cph, sph;
+        sincos((double)p[2], &sph, &cph);
         dx[0] = g[0] * (-sps * cth) + g[1] * (sph * cps * cth) + g[2] * (cph * cps * cth) + g[4] * (-sps * sth) +
                 g[5] * (sph * cps * sth) + g[6] * (cph * cps * sth) + g[8] * (-cps) + g[9] * (-sph * sps) + g[10] * (-cph * sps);
         dx[1] = g[0] * (-cps * sth) + g[1] * (-sph * sps * sth - cph * cth) + g[2] * (-cph * sps * sth + sph * cth) +
@@ -1275,7 +1282,8 @@ __device__ void pose_vjp(const float *p, const double *g, double *dx)
             dx[3 + i] = g[3 + 4 * i] * 0.25 * (1.0 - t * t);
         }
     } else {
-        const double c = cos((double)p[0]), s = sin((double)p[0]);
+        double c, s;
+        sincos((double)p[0], &s, &c);
         dx[0] = g[0] * (-s) + g[1] * (-c) + g[3] * c + g[4] * (-s);
         dx[1] = g[2];
         dx[2] = g[5];
