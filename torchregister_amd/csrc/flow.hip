@@ -214,12 +214,17 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
 // MODE 0: optimiser update (SGD/Adam) written to flow_out;  MODE 1: write the gradient to flow_out
 // PIPE: read voxel k+1's flow / target ahead of voxel k's gather (plain SGD without the regulariser: -9 %; the Adam and smoothness
 // variants hold more state per voxel and lose 3-4 % to it, so they load at the point of use).
-template <int ND, int MODE, bool SMOOTH, bool PIPE = false>
+// NEXT: pass A of the FOLLOWING iteration rides along - the voxel is sampled once more at its updated flow and the five moments go
+// to `next_partials` in exactly the layout, voxel order and arithmetic of flow_moments_kernel, so the next iteration starts at its
+// coefficient kernel (no smoothness term: that one needs the neighbours' updated flows).  One gather more, one 20 B/voxel pass less.
+template <int ND, int MODE, bool SMOOTH, bool PIPE = false, bool NEXT = false>
 __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol, const float *flow,
                                                                 float *flow_out, float *__restrict__ adam_m,
                                                                 float *__restrict__ adam_v, const FlowCoef *__restrict__ coef,
-                                                                trx_opt_cfg oc, Slab slab)
+                                                                trx_opt_cfg oc, Slab slab, float *__restrict__ next_partials = nullptr)
 {
+    static_assert(!NEXT || (!SMOOTH && MODE == 0), "the fused next-iteration moments need the plain update");
+    float nv[kFlowNP] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int b = blockIdx.y;
     const int D = vol.D, H = vol.H, W = vol.W;
     const size_t nvox = (size_t)D * H * W;
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
         for (int ch = 0; ch < ND; ch++) fc[ch] = fnx[ch];
         tc = tn;
         const float go = fmaf(c.k1, yv - c.my, fmaf(c.k2, w - c.mw, c.q * (w - yv)));
+        float pnew[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int ch = 0; ch < ND; ch++) {
             float g = go * d[ch];
@@ -297,9 +303,17 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
                     p = p - c.step_size * g;
                 }
                 fo[ch * nvox + i] = p;
+                if constexpr (NEXT) pnew[ch] = p;
             }
         }
+        if constexpr (NEXT) {
+            float d2[3];
+            const float w2 = flow_sample_v<ND>(mov, pnew, slab.Dm, H, W, z + slab.zoff, y, x, d2);
+            nv[0] += yv; nv[1] += w2;
+            nv[2] = fmaf(yv, yv, nv[2]); nv[3] = fmaf(w2, w2, nv[3]); nv[4] = fmaf(yv, w2, nv[4]);
+        }
     }
+    if constexpr (NEXT) block_reduce_store<kFlowNP, 8>(nv, next_partials + ((size_t)b * gridDim.x + blockIdx.x) * kFlowNP);
 }
 
 template <int ND>
@@ -428,10 +442,20 @@ static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth
 
 template <int MODE>
 static int launch_update(const trx_volumes *vol, const float *flow, float *flow_out, float *m, float *v, const FlowCoef *coef,
-                         const trx_opt_cfg &oc, bool smooth, hipStream_t s, Slab slab = Slab{0, -1, nullptr, nullptr})
+                         const trx_opt_cfg &oc, bool smooth, hipStream_t s, Slab slab = Slab{0, -1, nullptr, nullptr}, float *next_partials = nullptr)
 {
     if (slab.Dm < 0) slab.Dm = vol->D;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
+    if constexpr (MODE == 0) {
+        if (next_partials && vol->ndim == 3 && !smooth) {   // the update + the next iteration's pass A in one kernel
+            if (oc.kind != TRX_OPT_ADAM)
+                hipLaunchKernelGGL((flow_update_kernel<3, 0, false, true, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
+            else
+                hipLaunchKernelGGL((flow_update_kernel<3, 0, false, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
+            TRX_CHECK_LAUNCH();
+            return TRX_OK;
+        }
+    }
     if (vol->ndim == 3) {
         const bool pipe = (MODE == 0) && !smooth && oc.kind != TRX_OPT_ADAM;
         if (smooth) hipLaunchKernelGGL((flow_update_kernel<3, MODE, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab);
@@ -445,18 +469,20 @@ static int launch_update(const trx_volumes *vol, const float *flow, float *flow_
     return TRX_OK;
 }
 
+// have_moments: the partials of `cur` are already in the workspace (written by the previous iteration's fused update);
+// fuse_next: let this iteration's update write the partials of the flow it produces.
 static int flow_step_impl(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_flow_state *st,
-                          float *cur, float *nxt, void *workspace, hipStream_t s)
+                          float *cur, float *nxt, void *workspace, hipStream_t s, bool have_moments = false, bool fuse_next = false)
 {
     const bool smooth = st->smooth_weight != 0.f;
     float *partials = (float *)workspace;
     FlowCoef *coef = coef_ptr(vol, workspace);
-    int rc = launch_moments(vol, cur, smooth, partials, s);
+    int rc = have_moments ? TRX_OK : launch_moments(vol, cur, smooth, partials, s);
     if (rc) return rc;
     hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, partials, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
                        vol->W, *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr, (const double *)nullptr, vol->D);
     TRX_CHECK_LAUNCH();
-    return launch_update<0>(vol, cur, nxt, st->adam_m, st->adam_v, coef, *opt, smooth, s);
+    return launch_update<0>(vol, cur, nxt, st->adam_m, st->adam_v, coef, *opt, smooth, s, Slab{0, -1, nullptr, nullptr}, fuse_next ? partials : nullptr);
 }
 
 static int check_flow_args(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_flow_state *st,
@@ -481,9 +507,16 @@ extern "C" int trx_flow_run(const trx_volumes *vol, const trx_loss_cfg *loss, co
     hipStream_t s = (hipStream_t)stream;
     const bool smooth = st->smooth_weight != 0.f;
     float *cur = st->flow, *nxt = smooth ? st->flow_tmp : st->flow;
+    // Inside one call the update of iteration i also produces the moments of iteration i + 1 (3-D, no smoothness term): after the
+    // first iteration every step is coefficient kernel + one streaming kernel.  TRX_FLOW_FUSE_NEXT=0 keeps the two-pass steps.
+    static const bool fuse = [] { const char *e = getenv("TRX_FLOW_FUSE_NEXT"); return !(e && atoi(e) == 0); }();
+    const bool can_fuse = fuse && !smooth && vol->ndim == 3;
+    bool have = false;
     for (int i = 0; i < iters; i++) {
-        rc = flow_step_impl(vol, loss, opt, st, cur, nxt, workspace, s);
+        const bool next = can_fuse && (i + 1 < iters);
+        rc = flow_step_impl(vol, loss, opt, st, cur, nxt, workspace, s, have, next);
         if (rc) return rc;
+        have = next;
         float *t = cur; cur = nxt; nxt = t;
     }
     if (cur != st->flow) {  // odd number of double-buffered steps: result lives in flow_tmp
