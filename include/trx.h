@@ -171,6 +171,13 @@ int trx_flow_slab_moments(const trx_volumes *vol, int z_offset, int D_full, cons
 int trx_flow_slab_update(const trx_volumes *vol, int z_offset, int D_full, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
                          const trx_flow_state *st, const double *global_moments, const float *halo_lo, const float *halo_hi,
                          void *workspace, size_t workspace_bytes, void *stream);
+/* Without the smoothness term (3-D): the update that also leaves the slab's block partials of the UPDATED flow in the workspace, and the
+ * reduction of those partials to the 8 sums - together they replace trx_flow_slab_moments from the second iteration on (one pass over
+ * the slab per iteration instead of two; same numbers). */
+int trx_flow_slab_update_fused(const trx_volumes *vol, int z_offset, int D_full, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
+                               const trx_flow_state *st, const double *global_moments, void *workspace, size_t workspace_bytes, void *stream);
+int trx_flow_slab_moments_ready(const trx_volumes *vol, int z_offset, int D_full, double *moments, void *workspace, size_t workspace_bytes,
+                                void *stream);
 
 /* Generic backward of the flow warp: dflow[B][ndim][...] = sum_c grad_out[B][c][...] * d warp/d flow. */
 int trx_flow_warp_backward(const trx_volumes *vol, const float *flow, int channels, const float *grad_out,

@@ -4,6 +4,7 @@ PyTorch is used for device memory and streams only; all arithmetic of the hot pa
 libtrx.so.  Tensors must be fp32 CUDA(HIP) tensors; anything else raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -392,6 +393,8 @@ class SlabFlowSolver:
         self.ws_bytes = self.lib.trx_flow_workspace_bytes(ctypes.byref(v))
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self._adam = adam
+        self._partials_valid = False
+        self._fuse = os.environ.get("TRX_FLOW_FUSE_NEXT", "1") != "0"
 
     def _state(self):
         st = _lib.FlowState()
@@ -424,7 +427,15 @@ class SlabFlowSolver:
                 r.wait()
 
     def local_moments(self):
-        """Pass A: this slab's raw sums into self.moments (device, fp64 [1,8])."""
+        """Pass A: this slab's raw sums into self.moments (device, fp64 [1,8]).  Without the smoothness term the previous apply() has
+        already left the block partials of the current flow in the workspace and only their reduction runs (anything that changes
+        self.flow in between must set self._partials_valid = False)."""
+        if self._partials_valid:
+            with torch.cuda.device(self.device):
+                rc = self.lib.trx_flow_slab_moments_ready(ctypes.byref(self.vol), self.z_offset, self.D_full, _lib.ptr(self.moments),
+                                                          _lib.ptr(self.workspace), self.ws_bytes, _lib.current_stream(self.device))
+            _lib.check(rc, "trx_flow_slab_moments_ready")
+            return self.moments
         with torch.cuda.device(self.device):
             rc = self.lib.trx_flow_slab_moments(ctypes.byref(self.vol), self.z_offset, self.D_full, _lib.ptr(self.flow), int(bool(self.smooth)),
                                                 _lib.ptr(self.halo_hi), _lib.ptr(self.moments), _lib.ptr(self.workspace), self.ws_bytes,
@@ -436,6 +447,14 @@ class SlabFlowSolver:
         """Pass B with the whole-volume sums ([1,8] fp64 on this device)."""
         gm = global_moments.contiguous()
         st = self._state()
+        if not self.smooth and self._fuse:   # one pass: the update also produces the partials of the updated flow
+            with torch.cuda.device(self.device):
+                rc = self.lib.trx_flow_slab_update_fused(ctypes.byref(self.vol), self.z_offset, self.D_full, ctypes.byref(self.loss_c), ctypes.byref(self.opt),
+                                                         ctypes.byref(st), _lib.ptr(gm), _lib.ptr(self.workspace), self.ws_bytes,
+                                                         _lib.current_stream(self.device))
+            _lib.check(rc, "trx_flow_slab_update_fused")
+            self._partials_valid = True
+            return
         with torch.cuda.device(self.device):
             rc = self.lib.trx_flow_slab_update(ctypes.byref(self.vol), self.z_offset, self.D_full, ctypes.byref(self.loss_c), ctypes.byref(self.opt),
                                                ctypes.byref(st), _lib.ptr(gm), _lib.ptr(self.halo_lo), _lib.ptr(self.halo_hi),

@@ -78,6 +78,9 @@ SIGNATURES = {
     "trx_flow_slab_moments": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_flow_slab_update": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, ctypes.POINTER(LossCfg),
                                             ctypes.POINTER(OptCfg), ctypes.POINTER(FlowState), _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "trx_flow_slab_update_fused": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, ctypes.POINTER(LossCfg),
+                                                  ctypes.POINTER(OptCfg), ctypes.POINTER(FlowState), _P, _P, ctypes.c_size_t, _P]),
+    "trx_flow_slab_moments_ready": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, _P, _P, ctypes.c_size_t, _P]),
     "trx_flow_loss_grad": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.POINTER(LossCfg), _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_flow_warp_backward": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, ctypes.c_int, _P, _P, _P]),
     "trx_kde_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_long, ctypes.c_int]),

@@ -633,3 +633,42 @@ extern "C" int trx_flow_slab_update(const trx_volumes *vol, int z_offset, int D_
     return launch_update<0>(vol, st->flow, smooth ? st->flow_tmp : st->flow, st->adam_m, st->adam_v, coef, *opt, smooth, s,
                             Slab{z_offset, D_full, halo_lo, halo_hi});
 }
+
+// Slab counterpart of the fused step of trx_flow_run (no smoothness term, 3-D): the update also leaves the slab's block partials of
+// the UPDATED flow in the workspace; trx_flow_slab_moments_ready then reduces them to the 8 sums without another pass over the slab.
+extern "C" int trx_flow_slab_update_fused(const trx_volumes *vol, int z_offset, int D_full, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
+                                          const trx_flow_state *st, const double *global_moments, void *workspace, size_t workspace_bytes,
+                                          void *stream)
+{
+    int rc = check_slab(vol, z_offset, D_full);
+    if (rc) return rc;
+    if (!global_moments) return TRX_ERR_ARG;
+    rc = check_flow_args(vol, loss, opt, st, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (st->smooth_weight != 0.f || vol->ndim != 3) return TRX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    FlowCoef *coef = coef_ptr(vol, workspace);
+    hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, (const float *)workspace, 0, vol->ndim, vol->D, vol->H, vol->W,
+                       *loss, *opt, 0.f, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr,
+                       global_moments, D_full);
+    TRX_CHECK_LAUNCH();
+    return launch_update<0>(vol, st->flow, st->flow, st->adam_m, st->adam_v, coef, *opt, false, s, Slab{z_offset, D_full, nullptr, nullptr},
+                            (float *)workspace);
+}
+
+extern "C" int trx_flow_slab_moments_ready(const trx_volumes *vol, int z_offset, int D_full, double *moments, void *workspace,
+                                           size_t workspace_bytes, void *stream)
+{
+    int rc = check_slab(vol, z_offset, D_full);
+    if (rc) return rc;
+    if (!moments || !workspace) return TRX_ERR_ARG;
+    if (workspace_bytes < trx_flow_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    trx_loss_cfg lc = {0.f, 0.f, 0.f, 0.f, 0.f};
+    trx_opt_cfg oc = {TRX_OPT_SGD, 0.f, 0.f, 0.f, 0.f};
+    hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, (const float *)workspace, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
+                       vol->W, lc, oc, 0.f, (float *)nullptr, 0, (int *)nullptr, (float *)nullptr, (FlowCoef *)nullptr, moments,
+                       (const double *)nullptr, D_full);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
