@@ -447,8 +447,10 @@ static int launch_update(const trx_volumes *vol, const float *flow, float *flow_
     if (slab.Dm < 0) slab.Dm = vol->D;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
     if constexpr (MODE == 0) {
-        if (next_partials && vol->ndim == 3 && !smooth) {   // the update + the next iteration's pass A in one kernel
-            if (oc.kind != TRX_OPT_ADAM)
+        if (next_partials && !smooth) {   // the update + the next iteration's pass A in one kernel
+            if (vol->ndim == 2)
+                hipLaunchKernelGGL((flow_update_kernel<2, 0, false, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
+            else if (oc.kind != TRX_OPT_ADAM)
                 hipLaunchKernelGGL((flow_update_kernel<3, 0, false, true, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
             else
                 hipLaunchKernelGGL((flow_update_kernel<3, 0, false, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
@@ -507,10 +509,10 @@ extern "C" int trx_flow_run(const trx_volumes *vol, const trx_loss_cfg *loss, co
     hipStream_t s = (hipStream_t)stream;
     const bool smooth = st->smooth_weight != 0.f;
     float *cur = st->flow, *nxt = smooth ? st->flow_tmp : st->flow;
-    // Inside one call the update of iteration i also produces the moments of iteration i + 1 (3-D, no smoothness term): after the
+    // Inside one call the update of iteration i also produces the moments of iteration i + 1 (no smoothness term): after the
     // first iteration every step is coefficient kernel + one streaming kernel.  TRX_FLOW_FUSE_NEXT=0 keeps the two-pass steps.
     static const bool fuse = [] { const char *e = getenv("TRX_FLOW_FUSE_NEXT"); return !(e && atoi(e) == 0); }();
-    const bool can_fuse = fuse && !smooth && vol->ndim == 3;
+    const bool can_fuse = fuse && !smooth;
     bool have = false;
     for (int i = 0; i < iters; i++) {
         const bool next = can_fuse && (i + 1 < iters);
