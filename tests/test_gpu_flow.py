@@ -147,18 +147,22 @@ def test_flow_headline_size_vs_oracle(eng):
     assert np.max(np.abs(dfl[0].cpu().numpy() - d64)) <= max(1e-4 * np.max(np.abs(d64)), 2.0 * np.max(np.abs(d32.astype(np.float64) - d64)))
 
 
+@pytest.mark.parametrize("smooth", [0.0, 2.5])
 @pytest.mark.parametrize("shape", [(40, 36, 44), (70, 90)])
 @pytest.mark.parametrize("optimizer,lr", [("sgd", 1.0), ("adam", 0.02)])
-def test_fused_next_moments_are_bitwise_the_two_pass_steps(eng, optimizer, lr, shape):
+def test_fused_next_moments_are_bitwise_the_two_pass_steps(eng, optimizer, lr, shape, smooth):
     """Inside one trx_flow_run call the update kernel of iteration i also produces the moments of iteration i + 1 (no
     smoothness term; 2-D and 3-D).  Same voxel order, same arithmetic as the stand-alone moments pass: run(12) and 12 x run(1) (which cannot
     fuse) must agree bit for bit - loss curve, flow and, for Adam, the optimiser state."""
     tgt, mov = ph.blobs(shape, 1).cuda(), ph.blobs(shape, 2).cuda()
-    kw = dict(loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr, capacity=12)
+    kw = dict(loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr, capacity=13, smooth_weight=smooth)
     a = eng.FlowSolver(mov, tgt, **kw)
-    a.run(12)
+    a.run(7)        # (with the smoothness term the regulariser part of each recorded loss arrives one coefficient kernel later and
+    a.run(2)        #  the last one of a call by a flush: several calls of different lengths, odd and even for the double buffer)
+    a.run(1)
+    a.run(3)
     b = eng.FlowSolver(mov, tgt, **kw)
-    for _ in range(12):
+    for _ in range(13):
         b.run(1)
     torch.cuda.synchronize()
     assert torch.equal(a.losses, b.losses) and torch.equal(a.flow, b.flow)

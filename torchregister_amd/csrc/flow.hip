@@ -65,6 +65,7 @@ __device__ __forceinline__ float flow_sample_v(const float *__restrict__ mov, co
 }
 
 constexpr int kFlowNP = 8;  // 5 moments + up to 3 smoothness sums
+constexpr int kLagRecord = 1, kLagPatch = 2, kLagFlush = 4;
 
 template <int ND, bool SMOOTH>
 __global__ __launch_bounds__(TRX_BLOCK) void flow_moments_kernel(trx_volumes vol, const float *__restrict__ flow,
@@ -131,8 +132,15 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
                                                          int W, trx_loss_cfg lc, trx_opt_cfg oc, float smooth_weight,
                                                          float *__restrict__ losses, int losses_capacity, int *__restrict__ step,
                                                          float *__restrict__ terms, FlowCoef *__restrict__ coef,
-                                                         double *__restrict__ mom_out, const double *__restrict__ mom_in, int D_full)
+                                                         double *__restrict__ mom_out, const double *__restrict__ mom_in, int D_full,
+                                                         int lag = 0, double *__restrict__ stash = nullptr)
 {
+    // lag (fused steps with the smoothness term, trx_flow_run): the data moments S[0..4] describe THIS iteration's flow, the
+    // smoothness sums S[5..7] the PREVIOUS one (they are collected by the update kernel, which is where the neighbours of a flow are
+    // read).  The gradient step needs only the former; the recorded loss of iteration t - 1 gets its regulariser term one
+    // coefficient kernel later, from the data part stashed in fp64 - the same additions as the two-pass step, in the same order.
+    //   kLagRecord: record the data part of this iteration (provisional) and stash it;  kLagPatch: complete losses[t - 1];
+    //   kLagFlush: only that (after the last iteration of a run).
     __shared__ double acc[16][8];
     const int b = blockIdx.x, tid = threadIdx.x, k = tid & 7, grp = tid >> 3;  // 128 groups of 8
     double s = 0.0;
@@ -187,7 +195,15 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
                 c.sm[dd] = (float)((double)smooth_weight / ndim * 2.0 / cnt);
             }
         }
-        total += (double)smooth_weight / ndim * reg;
+        if (lag == 0) {
+            total += (double)smooth_weight / ndim * reg;
+        } else {
+            const int tp = t_step - 1;
+            if ((lag & kLagPatch) && losses && tp >= 0 && tp < losses_capacity)
+                losses[(size_t)b * losses_capacity + tp] = (float)(stash[b] + (double)smooth_weight / ndim * reg);
+            if (lag & kLagFlush) return;
+            stash[b] = total;
+        }
     }
     c.k1 = (float)((double)lc.w_ncc * (-alpha / sd));
     c.k2 = (float)((double)lc.w_ncc * (alpha * Sab * Saa / (sd * sd * sd)));
@@ -216,14 +232,15 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
 // variants hold more state per voxel and lose 3-4 % to it, so they load at the point of use).
 // NEXT: pass A of the FOLLOWING iteration rides along - the voxel is sampled once more at its updated flow and the five moments go
 // to `next_partials` in exactly the layout, voxel order and arithmetic of flow_moments_kernel, so the next iteration starts at its
-// coefficient kernel (no smoothness term: that one needs the neighbours' updated flows).  One gather more, one 20 B/voxel pass less.
+// coefficient kernel.  One gather more, one 20 B/voxel pass less.  With the smoothness term the three regulariser sums in
+// `next_partials` are those of the flow this step STARTS from (its neighbours are read here anyway); see flow_coef_kernel's lag mode.
 template <int ND, int MODE, bool SMOOTH, bool PIPE = false, bool NEXT = false>
 __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol, const float *flow,
                                                                 float *flow_out, float *__restrict__ adam_m,
                                                                 float *__restrict__ adam_v, const FlowCoef *__restrict__ coef,
                                                                 trx_opt_cfg oc, Slab slab, float *__restrict__ next_partials = nullptr)
 {
-    static_assert(!NEXT || (!SMOOTH && MODE == 0), "the fused next-iteration moments need the plain update");
+    static_assert(!NEXT || MODE == 0, "the fused next-iteration moments ride on the update");
     float nv[kFlowNP] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int b = blockIdx.y;
     const int D = vol.D, H = vol.H, W = vol.W;
@@ -286,6 +303,10 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
                         if (!has_hi && slab.halo_hi) fhi = slab.halo_hi[ch * (size_t)H * W + (size_t)y * W + x];
                     }
                     g = fmaf(c.sm[dd], (f0 - flo) - (fhi - f0), g);
+                    if constexpr (NEXT) {   // smoothness sums of the flow this step STARTS from (flow_moments_kernel's arithmetic and order)
+                        const float df = fhi - f0;
+                        nv[5 + dd] = fmaf(df, df, nv[5 + dd]);
+                    }
                 }
             }
             if constexpr (MODE == 1) {
@@ -415,7 +436,8 @@ using namespace trx;
 extern "C" size_t trx_flow_workspace_bytes(const trx_volumes *vol)
 {
     if (check_vol_flow(vol, false) != TRX_OK) return 0;
-    return (size_t)vol->B * flow_grid_x(*vol) * kFlowNP * sizeof(float) + (size_t)vol->B * sizeof(FlowCoef) + 256;
+    return (size_t)vol->B * flow_grid_x(*vol) * kFlowNP * sizeof(float) + (size_t)vol->B * sizeof(FlowCoef) + 256 +
+           (size_t)vol->B * sizeof(double) + 256;   // + the fp64 data part of the last recorded loss (lagged regulariser term)
 }
 
 static FlowCoef *coef_ptr(const trx_volumes *vol, void *workspace)
@@ -423,6 +445,13 @@ static FlowCoef *coef_ptr(const trx_volumes *vol, void *workspace)
     size_t off = (size_t)vol->B * flow_grid_x(*vol) * kFlowNP * sizeof(float);
     off = (off + 255) & ~(size_t)255;
     return (FlowCoef *)((char *)workspace + off);
+}
+
+static double *stash_ptr(const trx_volumes *vol, void *workspace)
+{
+    size_t off = (size_t)((char *)(coef_ptr(vol, workspace) + vol->B) - (char *)workspace);
+    off = (off + 255) & ~(size_t)255;
+    return (double *)((char *)workspace + off);
 }
 
 static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth, float *partials, hipStream_t s, Slab slab = Slab{0, -1, nullptr, nullptr})
@@ -447,6 +476,14 @@ static int launch_update(const trx_volumes *vol, const float *flow, float *flow_
     if (slab.Dm < 0) slab.Dm = vol->D;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
     if constexpr (MODE == 0) {
+        if (next_partials && smooth) {
+            if (vol->ndim == 2)
+                hipLaunchKernelGGL((flow_update_kernel<2, 0, true, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
+            else
+                hipLaunchKernelGGL((flow_update_kernel<3, 0, true, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
+            TRX_CHECK_LAUNCH();
+            return TRX_OK;
+        }
         if (next_partials && !smooth) {   // the update + the next iteration's pass A in one kernel
             if (vol->ndim == 2)
                 hipLaunchKernelGGL((flow_update_kernel<2, 0, false, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
@@ -474,7 +511,7 @@ static int launch_update(const trx_volumes *vol, const float *flow, float *flow_
 // have_moments: the partials of `cur` are already in the workspace (written by the previous iteration's fused update);
 // fuse_next: let this iteration's update write the partials of the flow it produces.
 static int flow_step_impl(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_flow_state *st,
-                          float *cur, float *nxt, void *workspace, hipStream_t s, bool have_moments = false, bool fuse_next = false)
+                          float *cur, float *nxt, void *workspace, hipStream_t s, bool have_moments = false, bool fuse_next = false, int lag = 0)
 {
     const bool smooth = st->smooth_weight != 0.f;
     float *partials = (float *)workspace;
@@ -482,7 +519,8 @@ static int flow_step_impl(const trx_volumes *vol, const trx_loss_cfg *loss, cons
     int rc = have_moments ? TRX_OK : launch_moments(vol, cur, smooth, partials, s);
     if (rc) return rc;
     hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, partials, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
-                       vol->W, *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr, (const double *)nullptr, vol->D);
+                       vol->W, *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr, (const double *)nullptr, vol->D,
+                       lag, stash_ptr(vol, workspace));
     TRX_CHECK_LAUNCH();
     return launch_update<0>(vol, cur, nxt, st->adam_m, st->adam_v, coef, *opt, smooth, s, Slab{0, -1, nullptr, nullptr}, fuse_next ? partials : nullptr);
 }
@@ -512,14 +550,23 @@ extern "C" int trx_flow_run(const trx_volumes *vol, const trx_loss_cfg *loss, co
     // Inside one call the update of iteration i also produces the moments of iteration i + 1 (no smoothness term): after the
     // first iteration every step is coefficient kernel + one streaming kernel.  TRX_FLOW_FUSE_NEXT=0 keeps the two-pass steps.
     static const bool fuse = [] { const char *e = getenv("TRX_FLOW_FUSE_NEXT"); return !(e && atoi(e) == 0); }();
-    const bool can_fuse = fuse && !smooth;
+    // With the smoothness term every update of a run of >= 2 iterations is the fused one (its regulariser sums lag by one iteration,
+    // see flow_coef_kernel) and one coefficient-kernel launch after the loop completes the last recorded loss.
+    const bool lagged = fuse && smooth && iters >= 2;
     bool have = false;
     for (int i = 0; i < iters; i++) {
-        const bool next = can_fuse && (i + 1 < iters);
-        rc = flow_step_impl(vol, loss, opt, st, cur, nxt, workspace, s, have, next);
+        const bool next = lagged || (fuse && !smooth && (i + 1 < iters));
+        const int lag = (lagged && i >= 1) ? (kLagRecord | (i >= 2 ? kLagPatch : 0)) : 0;
+        rc = flow_step_impl(vol, loss, opt, st, cur, nxt, workspace, s, have, next, lag);
         if (rc) return rc;
         have = next;
         float *t = cur; cur = nxt; nxt = t;
+    }
+    if (lagged) {
+        hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, (const float *)workspace, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
+                           vol->W, *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef_ptr(vol, workspace),
+                           (double *)nullptr, (const double *)nullptr, vol->D, kLagPatch | kLagFlush, stash_ptr(vol, workspace));
+        TRX_CHECK_LAUNCH();
     }
     if (cur != st->flow) {  // odd number of double-buffered steps: result lives in flow_tmp
         const size_t bytes = (size_t)vol->B * vol->ndim * vol->D * vol->H * vol->W * sizeof(float);
