@@ -1,5 +1,6 @@
 #!/bin/bash
-# development: finalize-kernel ablations (build/libtrx_fin{1,2}.so swapped in for the product library on the GPU box's copy)
+# development: finalize-kernel ablations (build/libtrx_fin{1,2}.so swapped in for the product library on the GPU box's copy).
+# Build them here first:  for a in 1 2; do make -B HIPFLAGS="<the Makefile's HIPFLAGS> -DTRX_FIN_ABLATE=$a"; cp torchregister_amd/lib/libtrx.so build/libtrx_fin$a.so; done; make -B
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cp $R/torchregister_amd/lib/libtrx.so /tmp/libtrx_orig.so
