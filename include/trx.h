@@ -8,7 +8,8 @@
  * [host]; `stream` is a hipStream_t passed as void*.  No entry point allocates, synchronises
  * or calls back into the host: everything is enqueued on `stream` and is graph-capturable.
  * Return value: 0 (TRX_OK) or a negative trx_status; nothing throws.
- * Thread-compatible: no global state, one host thread per GPU/stream may call concurrently.
+ * Thread-compatible: no global state (the library reads no environment variable and keeps no settings: every choice a
+ * caller can make travels in the argument structs), one host thread per GPU/stream may call concurrently.
  *
  * Data layout (fp32, contiguous): volumes [B][D][H][W] (2-D: D = 1, ndim = 2), pair p of a
  * batch at base + p * stride elements (stride 0 = one volume shared by all pairs).
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TRX_VERSION 100 /* 0.1.0 */
+#define TRX_VERSION 200 /* 0.2.0: trx_volumes.flags, early stop in trx_flow_state */
 #define TRX_PSTRIDE 12  /* floats per pair in theta / param / adam / best_theta arrays */
 
 typedef enum {
@@ -36,8 +37,16 @@ typedef enum {
     TRX_ERR_NDIM = -2,      /* ndim not 2 or 3 (or D != 1 with ndim 2) */
     TRX_ERR_WORKSPACE = -3, /* workspace too small: see trx_*_workspace_bytes */
     TRX_ERR_HIP = -4,       /* a HIP launch failed (hipGetLastError) */
-    TRX_ERR_CAPACITY = -5   /* loss-curve buffer shorter than the requested iterations */
+    TRX_ERR_CAPACITY = -5   /* trx_*_run: `iters` exceeds losses_capacity (the per-pair device counters cannot be read without a
+                               sync, so callers that split a run over several calls keep the running total themselves) */
 } trx_status;
+
+/* trx_volumes.flags: per-call path selection (0 = the library picks; the others exist so that every path can be tested
+ * against the others through the same entry points - results never depend on the path beyond fp32 rounding). */
+#define TRX_FLAG_GATHER_PATH 1u    /* affine entry points: the un-tiled row-walking kernel instead of the LDS-tiled ones */
+#define TRX_FLAG_SINGLE_GEOM 2u    /* affine entry points: one tile geometry for every pair (no per-pair GeomA / GeomR choice) */
+#define TRX_FLAG_TWO_PASS_FLOW 4u  /* trx_flow_run: keep the moments pass of every iteration (no fusion into the previous update) */
+#define TRX_FLAG_NO_STREAM 8u      /* affine steps: never take the y-streaming kernel (tile kernels only) */
 
 /* A batch of B independent (moving, target) pairs. */
 typedef struct {
@@ -49,6 +58,7 @@ typedef struct {
     /* Optional base-coordinate tables of affine_grid(align_corners=False): xn[W], yn[H], zn[D] =
      * fp32 linspace(-1,1,S)*(S-1)/S as ATen builds them.  NULL -> closed form (2i+1)/S-1. */
     const float *xn, *yn, *zn;
+    unsigned flags;        /* TRX_FLAG_* (0 for normal use) */
 } trx_volumes;
 
 /* L = w_mse*MSE + w_ncc*ncc_alpha*(1-NCC) + w_ssd*ssd_alpha*SSD
@@ -136,6 +146,15 @@ typedef struct {
     int losses_capacity;
     int *step;          /* [B] */
     float smooth_weight; /* extension: lambda * mean squared forward differences of the flow */
+    /* Early stop of ref:warpings.py:231-233 (`if losses_train[-1] <= self.stop_crit: break`), decided on the device, per pair, with
+     * no host sync: once the recorded loss of iteration k is <= stop_crit the update of iteration k is still applied (the reference
+     * steps before it tests) and every later iteration of this and of later calls is a no-op for that pair - step[b] stays k + 1 =
+     * the number of recorded losses.  stopped == NULL disables the test. */
+    float stop_crit;
+    int *stopped;        /* [B] in/out, 0 before the run; non-zero once pair b has stopped */
+    /* optional [B][ndim][D][H][W]: the flow of the LAST FORWARD (the one the last recorded loss was computed from, i.e. before
+     * that iteration's update) - what the reference's flow_register.flow holds after optimize() (ref:warpings.py:194-196,211). */
+    float *flow_last;
 } trx_flow_state;
 
 size_t trx_flow_workspace_bytes(const trx_volumes *vol);

@@ -77,20 +77,22 @@ def test_f1_step_vs_oracle(eng, shape, tname):
     assert abs(s.eval_loss(th.cuda())[0, 0].item() - loss) <= 1e-6 * max(1.0, abs(loss))
 
 
-def test_forced_gather_path_matches_tile_path(eng, monkeypatch):
-    """TRX_AFFINE_PATH=gather (development switch) runs the un-tiled kernel: same results to fp32 rounding."""
+def test_forced_gather_path_matches_tile_path(eng):
+    """trx_volumes.flags = TRX_FLAG_GATHER_PATH runs the un-tiled kernel, TRX_FLAG_SINGLE_GEOM the one-geometry tile kernel: same
+    results as the default per-pair GeomA / GeomR kernel to fp32 rounding."""
     shape = (40, 48, 64)
     tgt, mov = ph.blobs(shape, 5).cuda(), ph.blobs(shape, 6).cuda()
     th = torch.tensor(generic(THETAS["small_rot"]), dtype=torch.float32)[None]
     outs = []
-    for path in ("tile", "gather"):
-        monkeypatch.setenv("TRX_AFFINE_PATH", path)
-        s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=1e-4, init=th, capacity=3)
+    from torchregister_amd import _lib
+    for flags in (0, _lib.FLAG_GATHER_PATH, _lib.FLAG_SINGLE_GEOM):
+        s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=1e-4, init=th, capacity=3, flags=flags)
         s.run(3)
         torch.cuda.synchronize()
         outs.append((s.losses.clone(), s.theta.clone()))
-    assert torch.allclose(outs[0][0], outs[1][0], rtol=2e-6, atol=1e-5)
-    assert torch.allclose(outs[0][1], outs[1][1], rtol=0, atol=2e-6)
+    for o in outs[1:]:
+        assert torch.allclose(outs[0][0], o[0], rtol=2e-6, atol=1e-5)
+        assert torch.allclose(outs[0][1], o[1], rtol=0, atol=2e-6)
 
 
 def test_batch_of_mixed_thetas(eng):

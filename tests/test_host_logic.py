@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/trx.h but not exported by libtrx.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.trx_version() == 100
+    assert lib.trx_version() == 200
     assert b"workspace" in lib.trx_status_string(-3)
 
 
@@ -66,6 +66,8 @@ def test_more_argument_validation_without_gpu():
     oc.kind = 0
     assert lib.trx_affine_step(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(st), P(16), need - 1, None) == -3
     assert lib.trx_affine_run(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(st), -1, P(16), need, None) == -1
+    st.losses, st.losses_capacity = 16, 5                                 # more iterations than the loss curve holds
+    assert lib.trx_affine_run(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(st), 6, P(16), need, None) == -5
     assert lib.trx_affine_accumulate(ctypes.byref(v), P(16), P(16), 0, None) == -3
     assert lib.trx_affine_loss(ctypes.byref(v), ctypes.byref(lc), P(16), None, P(16), need, None) == -1
     # a volume of 2^31 voxels is refused (32-bit voxel indices inside one volume)
@@ -78,6 +80,8 @@ def test_more_argument_validation_without_gpu():
     assert lib.trx_flow_workspace_bytes(ctypes.byref(v)) > 0
     assert lib.trx_flow_step(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(fs), P(16), 1 << 30, None) == -1   # null flow
     assert lib.trx_flow_warp(ctypes.byref(v), None, 1, P(16), None) == -1
+    fs.flow, fs.losses, fs.losses_capacity = 16, 16, 3
+    assert lib.trx_flow_run(ctypes.byref(v), ctypes.byref(lc), ctypes.byref(oc), ctypes.byref(fs), 4, P(16), 1 << 30, None) == -5
     # local-window NCC extension
     assert lib.trx_lncc_workspace_bytes(4, 1, 8, 8, 8) == 0
     assert lib.trx_lncc_workspace_bytes(2, 1, 3, 8, 8) == 0               # 2-D needs D == 1
@@ -97,6 +101,44 @@ def test_more_argument_validation_without_gpu():
     assert lib.trx_kde_pdf_backward(P(16), P(16), None, 2, 10000, 256, 3.0, P(16), None) == -1
     for code, word in ((-1, b"arg"), (-2, b"dim"), (-4, b"HIP"), (-5, b"loss-curve")):
         assert word.lower() in lib.trx_status_string(code).lower()
+
+
+def test_ctypes_structs_match_the_header_layout():
+    """The ctypes mirrors of the C structs are checked against sizes computed by the C compiler from include/trx.h itself."""
+    import subprocess
+    import tempfile
+    from torchregister_amd import _lib
+    src = '#include <stdio.h>\n#include "trx.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(trx_volumes), sizeof(trx_loss_cfg),' \
+          ' sizeof(trx_opt_cfg), sizeof(trx_affine_state), sizeof(trx_flow_state), offsetof(trx_volumes, flags), offsetof(trx_flow_state, stopped));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        got = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    want = [ctypes.sizeof(_lib.Volumes), ctypes.sizeof(_lib.LossCfg), ctypes.sizeof(_lib.OptCfg), ctypes.sizeof(_lib.AffineState),
+            ctypes.sizeof(_lib.FlowState), _lib.Volumes.flags.offset, _lib.FlowState.stopped.offset]
+    assert got == want
+
+
+def test_library_reads_no_environment_variable():
+    """include/trx.h promises no global state: the product library must not import getenv (dev knobs are compiled out)."""
+    import subprocess
+    from torchregister_amd import _lib
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH]).decode()
+    assert "getenv" not in syms
+
+
+def test_flow_register_host_checks():
+    import torchregister_amd as tr
+    from torchregister_amd.warpings import smooth_regulariser
+    with pytest.raises(IndexError):                                       # the reference indexes weights[i] (ADVICE r1)
+        tr.flow_register((8, 8), criterions=[nn.MSELoss(), tr.NCCLoss()], weights=[1.0], flow_model="direct")
+    fl = torch.randn(2, 3, 5, 6, 7, dtype=torch.float64)
+    want = 0.0
+    for b in range(2):
+        for d in range(3):
+            df = fl[b].diff(dim=1 + d)
+            want = want + 2.5 / 3 * (df * df).mean()
+    assert abs(smooth_regulariser(fl, 2.5).item() - want.item()) < 1e-12
 
 
 def test_cpu_tensors_fail_loudly():

@@ -1,0 +1,75 @@
+// Micro-benchmark (development): does ds_read_b64 accept a 4-byte-aligned address on gfx950 (each lane reads the dwords
+// (x, x + 1) of one box row, lanes one dword apart), does it return the right data, and what does it cost against ds_read2_b32?
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/lds_unaligned.hip -o build/lds_unaligned && build/lds_unaligned
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int KIND>   // 0: ds_read2_b32 (x, x+1)   1: ds_read_b64 at a 4-byte aligned address   2: ds_read_b64 at an 8-byte aligned address
+__global__ __launch_bounds__(512) void k(float *out, unsigned long long *ticks, int iters, int stride_dw)
+{
+    __shared__ __attribute__((aligned(16))) float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += 512) lds[i] = (float)i;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // lane l of wave w starts at dword w * 64 + l * stride_dw + 1 (odd for stride 1/2: never 8-byte aligned for even lanes)
+    unsigned a = (unsigned)(uintptr_t)lds + (unsigned)(wave * 64 + lane * stride_dw + (KIND == 2 ? 0 : 1)) * 4u;
+    if (KIND == 2) a &= ~7u;
+    f2 acc = {0.f, 0.f};
+    f2 v[8];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if constexpr (KIND == 0) asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=v"(v[i]) : "v"(a + i * 176u));
+            else asm volatile("ds_read_b64 %0, %1" : "=v"(v[i]) : "v"(a + i * 176u));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc += v[i];
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[(size_t)blockIdx.x * 512 * 2 + threadIdx.x * 2] = v[0].x;
+    out[(size_t)blockIdx.x * 512 * 2 + threadIdx.x * 2 + 1] = v[0].y;
+    if (acc.x == 1.2345f) out[0] = acc.y;
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
+template <int KIND>
+static void run(const char *name, int stride_dw, int blocks)
+{
+    float *out; unsigned long long *tk;
+    hipMalloc(&out, (size_t)blocks * 512 * 2 * 4); hipMalloc(&tk, blocks * 8);
+    const int iters = 2000;
+    hipLaunchKernelGGL((k<KIND>), dim3(blocks), dim3(512), 0, 0, out, tk, iters, stride_dw);
+    hipDeviceSynchronize();
+    std::vector<float> h(1024); std::vector<unsigned long long> t(blocks);
+    hipMemcpy(h.data(), out, 1024 * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(t.data(), tk, blocks * 8, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int th = 0; th < 512; th++) {
+        const int lane = th & 63, wave = th >> 6;
+        int dw = wave * 64 + lane * stride_dw + (KIND == 2 ? 0 : 1);
+        if (KIND == 2) dw &= ~1;
+        if (h[th * 2] != (float)dw || h[th * 2 + 1] != (float)(dw + 1)) bad++;
+    }
+    double s = 0; for (auto v : t) s += (double)v;
+    s /= blocks;
+    // per CU: blocks/256 blocks x 8 waves x iters x 8 reads
+    const double reads_per_cu = (double)(blocks / 256) * 8 * iters * 8;
+    printf("%-34s lane stride %d dw, %d blocks/CU: %s, %.2f LDS cycles per wave-instruction per CU\n", name, stride_dw, blocks / 256, bad ? "WRONG DATA" : "data ok", s / reads_per_cu);
+    hipFree(out); hipFree(tk);
+}
+
+int main()
+{
+    for (int blocks : {256, 512}) {
+        for (int st : {1, 2}) {
+            run<0>("ds_read2_b32 (x, x+1)", st, blocks);
+            run<1>("ds_read_b64 4-byte aligned", st, blocks);
+            run<2>("ds_read_b64 8-byte aligned", st, blocks);
+        }
+    }
+    return 0;
+}

@@ -4,7 +4,7 @@
 gives `tr.Register(mode=...).optim(moving, target, ...)` / `reg(moving)` backed by hand-written
 HIP kernels in lib/libtrx.so (C ABI: include/trx.h).  There is no CPU fallback.
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 from ._engine import AffineSolver, FlowSolver, LossSpec, SlabFlowSolver  # noqa: F401
 from .torchregister import Register  # noqa: F401

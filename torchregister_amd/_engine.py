@@ -4,7 +4,6 @@ PyTorch is used for device memory and streams only; all arithmetic of the hot pa
 libtrx.so.  Tensors must be fp32 CUDA(HIP) tensors; anything else raises.
 """
 import ctypes
-import os
 
 import torch
 
@@ -60,7 +59,8 @@ def base_tables(spatial, device):
 class _Batch:
     """A batch of volumes [B, C, *spatial] described for the C ABI."""
 
-    def __init__(self, moving, target=None, tables=True):
+    def __init__(self, moving, target=None, tables=True, flags=0):
+        self.flags = int(flags)
         _require_gpu(moving, "moving")
         if moving.dim() not in (4, 5):
             raise ValueError(f"expected [B,C,H,W] or [B,C,D,H,W], got {tuple(moving.shape)}")
@@ -88,6 +88,7 @@ class _Batch:
         v.moving_stride = self.C * self.nvox if moving_stride is None else moving_stride
         v.target_stride = (self.target.shape[1] * self.nvox if self.target is not None else 0) if target_stride is None else target_stride
         v.ndim, v.B, v.D, v.H, v.W = self.nd, self.B, D, H, W
+        v.flags = self.flags
         if self.tables is not None:
             if self.nd == 3:
                 v.zn, v.yn, v.xn = (t.data_ptr() for t in self.tables)
@@ -128,9 +129,9 @@ class AffineSolver:
     """
 
     def __init__(self, moving, target, mode="affine", loss=None, optimizer="sgd", lr=1e-5, init=None, capacity=1000,
-                 betas=(0.9, 0.999), eps=1e-8):
+                 betas=(0.9, 0.999), eps=1e-8, flags=0):
         self.lib = _lib.load()
-        self.batch = _Batch(moving, target)
+        self.batch = _Batch(moving, target, flags=flags)
         if self.batch.C != 1 or self.batch.target.shape[1] != 1:
             raise ValueError("the optimiser path takes single-channel volumes [B,1,...]")
         if self.batch.target.shape[0] != self.batch.B:
@@ -179,9 +180,15 @@ class AffineSolver:
         st.step, st.grad = self.step.data_ptr(), self.grad.data_ptr()
         self.state = st
         self.loss_c = self.loss.c()
+        self.enqueued = 0   # iterations enqueued so far (host-side mirror of the device counter `step`)
 
     def run(self, iters):
         """Enqueue `iters` iterations on the current stream (no host sync)."""
+        iters = int(iters)
+        if self.enqueued + iters > self.capacity:
+            raise _lib.TrxError(f"loss-curve capacity exceeded: {self.enqueued} iterations enqueued + {iters} requested > capacity "
+                                f"{self.capacity} (create the solver with a larger `capacity`)")
+        self.enqueued += iters
         with torch.cuda.device(self.batch.device):
             rc = self.lib.trx_affine_run(ctypes.byref(self.vol), ctypes.byref(self.loss_c), ctypes.byref(self.opt),
                                          ctypes.byref(self.state), int(iters), _lib.ptr(self.workspace), self.ws_bytes,
@@ -254,9 +261,12 @@ class FlowSolver:
     """Direct dense flow-field optimisation (the flow itself is the parameter), batched."""
 
     def __init__(self, moving, target, loss=None, optimizer="sgd", lr=1e-3, init=None, capacity=1000, smooth_weight=0.0,
-                 betas=(0.9, 0.999), eps=1e-8):
+                 betas=(0.9, 0.999), eps=1e-8, stop_crit=None, keep_last=False, flags=0):
+        """stop_crit: the reference's early stop (ref:warpings.py:231-233), tested on the device per pair - a pair whose recorded loss
+        is <= stop_crit keeps that iteration's update and ignores every later iteration; `step[b]` = number of recorded losses.
+        keep_last: also keep `flow_last`, the flow of the last forward (what the reference's flow_register.flow holds)."""
         self.lib = _lib.load()
-        self.batch = _Batch(moving, target, tables=False)
+        self.batch = _Batch(moving, target, tables=False, flags=flags)
         if self.batch.C != 1:
             raise ValueError("the optimiser path takes single-channel volumes [B,1,...]")
         b, nd, dev = self.batch.B, self.batch.nd, self.batch.device
@@ -283,9 +293,20 @@ class FlowSolver:
         st.adam_v = self.adam_v.data_ptr() if adam else None
         st.losses, st.losses_capacity, st.step = self.losses.data_ptr(), self.capacity, self.step.data_ptr()
         st.smooth_weight = float(smooth_weight)
+        self.stopped = torch.zeros(b, dtype=torch.int32, device=dev) if stop_crit is not None else None
+        self.flow_last = torch.empty(shape, device=dev) if (keep_last or stop_crit is not None) else None
+        st.stop_crit = float(stop_crit) if stop_crit is not None else 0.0
+        st.stopped = self.stopped.data_ptr() if self.stopped is not None else None
+        st.flow_last = self.flow_last.data_ptr() if self.flow_last is not None else None
         self.state = st
+        self.enqueued = 0
 
     def run(self, iters):
+        iters = int(iters)
+        if self.enqueued + iters > self.capacity:
+            raise _lib.TrxError(f"loss-curve capacity exceeded: {self.enqueued} iterations enqueued + {iters} requested > capacity "
+                                f"{self.capacity} (create the solver with a larger `capacity`)")
+        self.enqueued += iters
         with torch.cuda.device(self.batch.device):
             rc = self.lib.trx_flow_run(ctypes.byref(self.vol), ctypes.byref(self.loss_c), ctypes.byref(self.opt),
                                        ctypes.byref(self.state), int(iters), _lib.ptr(self.workspace), self.ws_bytes,
@@ -351,7 +372,7 @@ class SlabFlowSolver:
     The loss curve holds the WHOLE-volume loss on every rank."""
 
     def __init__(self, moving_full, target_slab, z_offset, loss=None, optimizer="sgd", lr=1e-3, capacity=1000, betas=(0.9, 0.999),
-                 eps=1e-8, group=None, smooth_weight=0.0):
+                 eps=1e-8, group=None, smooth_weight=0.0, stop_crit=None, flags=0):
         self.lib = _lib.load()
         _require_gpu(moving_full, "moving_full")
         _require_gpu(target_slab, "target_slab")
@@ -389,12 +410,19 @@ class SlabFlowSolver:
         v.moving, v.target = self.moving.data_ptr(), self.target.data_ptr()
         v.moving_stride, v.target_stride = self.D_full * H * W, self.Ds * H * W
         v.ndim, v.B, v.D, v.H, v.W = 3, 1, self.Ds, H, W
+        v.flags = int(flags)
         self.vol = v
         self.ws_bytes = self.lib.trx_flow_workspace_bytes(ctypes.byref(v))
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self._adam = adam
         self._partials_valid = False
-        self._fuse = os.environ.get("TRX_FLOW_FUSE_NEXT", "1") != "0"
+        self._fuse = not (int(flags) & _lib.FLAG_TWO_PASS_FLOW)
+        # early stop (same device-side test as FlowSolver: the whole-volume loss is identical on every rank, so every rank stops at
+        # the same iteration without exchanging anything); flow_last = this slab of the flow of the last forward
+        self.stop_crit = stop_crit
+        self.stopped = torch.zeros(1, dtype=torch.int32, device=dev) if stop_crit is not None else None
+        self.flow_last = torch.empty(shape, device=dev) if stop_crit is not None else None
+        self.enqueued = 0
 
     def _state(self):
         st = _lib.FlowState()
@@ -404,6 +432,9 @@ class SlabFlowSolver:
         st.adam_v = self.adam_v.data_ptr() if self._adam else None
         st.losses, st.losses_capacity, st.step = self.losses.data_ptr(), self.capacity, self.step_t.data_ptr()
         st.smooth_weight = self.smooth
+        st.stop_crit = float(self.stop_crit) if self.stop_crit is not None else 0.0
+        st.stopped = self.stopped.data_ptr() if self.stopped is not None else None
+        st.flow_last = self.flow_last.data_ptr() if self.flow_last is not None else None
         return st
 
     def boundary_planes(self):
@@ -415,13 +446,15 @@ class SlabFlowSolver:
         import torch.distributed as dist
         if not self.smooth or not (dist.is_available() and dist.is_initialized()):
             return
-        rank = dist.get_rank(self.group) if rank is None else rank
+        rank = dist.get_rank(self.group) if rank is None else rank   # rank INSIDE the group = position of the slab along Z
+        # P2POp takes GLOBAL ranks: translate the group-relative neighbours (a sub-group need not start at global rank 0)
+        peer = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
         lo, hi = self.boundary_planes()
         ops = []
         if self.has_lo:
-            ops += [dist.P2POp(dist.isend, lo, rank - 1, self.group), dist.P2POp(dist.irecv, self.halo_lo, rank - 1, self.group)]
+            ops += [dist.P2POp(dist.isend, lo, peer(rank - 1), self.group), dist.P2POp(dist.irecv, self.halo_lo, peer(rank - 1), self.group)]
         if self.has_hi:
-            ops += [dist.P2POp(dist.isend, hi, rank + 1, self.group), dist.P2POp(dist.irecv, self.halo_hi, rank + 1, self.group)]
+            ops += [dist.P2POp(dist.isend, hi, peer(rank + 1), self.group), dist.P2POp(dist.irecv, self.halo_hi, peer(rank + 1), self.group)]
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
@@ -466,6 +499,9 @@ class SlabFlowSolver:
     def run(self, iters):
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if self.enqueued + int(iters) > self.capacity:
+            raise _lib.TrxError(f"loss-curve capacity exceeded: {self.enqueued} + {int(iters)} > {self.capacity}")
+        self.enqueued += int(iters)
         for _ in range(int(iters)):
             if multi:
                 self.exchange_halos()

@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtrx.so")
 PSTRIDE = 12
 OPT_SGD, OPT_ADAM = 0, 1
 PARAM_AFFINE, PARAM_RIGID = 0, 1
+# trx_volumes.flags (include/trx.h)
+FLAG_GATHER_PATH, FLAG_SINGLE_GEOM, FLAG_TWO_PASS_FLOW, FLAG_NO_STREAM = 1, 2, 4, 8
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int_p = ctypes.POINTER(ctypes.c_int)
@@ -29,7 +31,7 @@ class Volumes(ctypes.Structure):
     _fields_ = [("moving", ctypes.c_void_p), ("target", ctypes.c_void_p),
                 ("moving_stride", ctypes.c_size_t), ("target_stride", ctypes.c_size_t),
                 ("ndim", ctypes.c_int), ("B", ctypes.c_int), ("D", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
-                ("xn", ctypes.c_void_p), ("yn", ctypes.c_void_p), ("zn", ctypes.c_void_p)]
+                ("xn", ctypes.c_void_p), ("yn", ctypes.c_void_p), ("zn", ctypes.c_void_p), ("flags", ctypes.c_uint)]
 
 
 class LossCfg(ctypes.Structure):
@@ -52,7 +54,8 @@ class AffineState(ctypes.Structure):
 class FlowState(ctypes.Structure):
     _fields_ = [("flow", ctypes.c_void_p), ("flow_tmp", ctypes.c_void_p), ("adam_m", ctypes.c_void_p),
                 ("adam_v", ctypes.c_void_p), ("losses", ctypes.c_void_p), ("losses_capacity", ctypes.c_int),
-                ("step", ctypes.c_void_p), ("smooth_weight", ctypes.c_float)]
+                ("step", ctypes.c_void_p), ("smooth_weight", ctypes.c_float), ("stop_crit", ctypes.c_float),
+                ("stopped", ctypes.c_void_p), ("flow_last", ctypes.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/trx.h declares (tests check this)

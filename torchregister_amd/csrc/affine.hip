@@ -12,7 +12,9 @@
 //   dL/dtheta = cy * sum(y J) + cw * sum(w J) + c0 * sum(J).
 // The streaming kernel accumulates {Sy, Sw, Syy, Sww, Syw} and sum(q J) for q in {1, y, w};
 // the coefficients only exist after the pass, in the finalise kernel.
-#include <cstdlib>
+#ifdef TRX_DEV
+#include <cstdlib>   // getenv: development builds only (tools/kbench.hip); the product library reads no environment variable
+#endif
 
 #include "trx_common.h"
 
@@ -261,7 +263,11 @@ static TileGeom tile_geom(const trx_volumes &v)
     //  - many columns: the split (1..4) that minimises  (slot rounds * 512 / blocks) * (1 + 1.5 / tiles per block)  - the
     //    idle tail of the last round against the per-block prologue / epilogue (8 x 182^3: 181 us unsplit, 173 us split in 2).
     const int ncol = t.ntx * t.ntz;
-    static const int target = [] { const char *e = getenv("TRX_TILE_TARGET_BLOCKS"); return e ? atoi(e) : 0; }();   // development override
+#ifdef TRX_DEV
+    static const int target = [] { const char *e = getenv("TRX_TILE_TARGET_BLOCKS"); return e ? atoi(e) : 0; }();   // development override (kbench sweeps)
+#else
+    constexpr int target = 0;
+#endif
     const long cols = (long)v.B * ncol;
     int ys = 1;
     if (target > 0) {
@@ -1514,12 +1520,12 @@ constexpr int kTargetBlocks = 2048;
 
 using namespace trx;
 
-// 0 = primary geometry only, 1 = GeomA / GeomR chosen per pair inside one two-body kernel, 2 = the same choice as a pair of
-// single-body launches.  TRX_AFFINE_DUAL overrides (development).
-static int use_dual()
+// 0 = primary geometry only (TRX_FLAG_SINGLE_GEOM), 1 = GeomA / GeomR chosen per pair inside one two-body kernel, 2 = the same choice
+// as a pair of single-body launches (compile-time alternative, TRX_DUAL_DEFAULT).
+static int use_dual(const trx_volumes *vol)
 {
-    static const int v = [] { const char *e = getenv("TRX_AFFINE_DUAL"); return e ? atoi(e) : TRX_DUAL_DEFAULT; }();
-    return TRX_TILE_CFG == 0 ? v : 0;
+    if (vol->flags & TRX_FLAG_SINGLE_GEOM) return 0;
+    return TRX_TILE_CFG == 0 ? TRX_DUAL_DEFAULT : 0;
 }
 
 // partial rows per pair that a tile-path launch may write (the dual grid is sized for the geometry with more blocks)
@@ -1549,8 +1555,7 @@ extern "C" size_t trx_affine_workspace_bytes(const trx_volumes *vol)
 static bool use_tile_path(const trx_volumes *vol)
 {
     if (vol->ndim != 3) return false;
-    const char *e = getenv("TRX_AFFINE_PATH");   // development switch: "gather" forces the untiled kernel
-    return !(e && e[0] == 'g');
+    return !(vol->flags & TRX_FLAG_GATHER_PATH);   // the un-tiled kernel stays reachable so that the tests can compare the two
 }
 
 // MODE 0 / 1 dispatch: LDS-tiled kernel for 3-D, row-walking gather kernel otherwise.
@@ -1589,10 +1594,10 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             TRX_CHECK_LAUNCH();
             v.xn = tab; v.yn = tab + v.W; v.zn = tab + v.W + v.H;
         }
-        if (dual && use_dual()) {
+        if (dual && use_dual(vol)) {
             const TileGeom ta = tile_geom<GeomA>(*vol), tr = tile_geom<GeomR>(*vol);
             const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
-            launch_dual<MODE>(dim3(gx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual());
+            launch_dual<MODE>(dim3(gx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol));
             TRX_CHECK_LAUNCH();
             *nblk = gx;
             return TRX_OK;
@@ -1621,11 +1626,10 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     hipStream_t s = (hipStream_t)stream;
     float *partials = (float *)workspace;
     int nblk = 0;
-    // Rigid runs start from a random pose (reference: torch.rand, up to 1 rad) and live at large rotations: their F1 pass picks
-    // GeomA / GeomR per pair in the kernel.  Affine runs start at the identity and use the primary kernel, whose GeomA code is
-    // 2-5 % faster near the identity than the same body inside the dual kernel (code layout); beyond ~0.1 rad they gather from L2.
-    static const bool dual_affine = [] { const char *e = getenv("TRX_AFFINE_DUAL_STEPS"); return e && atoi(e) != 0; }();   // development: affine-mode steps too
-    rc = launch_f1<0>(vol, st->theta, partials, &nblk, s, st->mode == TRX_PARAM_RIGID || dual_affine);
+    // Every step picks GeomA / GeomR per pair in the kernel (TRX_FLAG_SINGLE_GEOM: the primary geometry only).  Rigid runs start from a
+    // random pose (reference: torch.rand, up to 1 rad) and live at large rotations; affine runs start at the identity, where the
+    // GeomA body is all that runs, but may rotate away from it: the single-geometry kernel then gathers from L2 at 3.2x the cost.
+    rc = launch_f1<0>(vol, st->theta, partials, &nblk, s, true);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
     if (vol->ndim == 3)
@@ -1645,13 +1649,14 @@ extern "C" int trx_affine_accumulate(const trx_volumes *vol, const float *theta,
     if (!theta || !workspace) return TRX_ERR_ARG;
     if (workspace_bytes < trx_affine_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
     int nblk = 0;
-    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream, false);   // the kernel of an affine step (profiling aid)
+    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream, true);   // the kernel of a step (profiling aid)
 }
 
 extern "C" int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
                               const trx_affine_state *st, int iters, void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (iters < 0) return TRX_ERR_ARG;
+    if (iters < 0 || !st) return TRX_ERR_ARG;
+    if (st->losses && iters > st->losses_capacity) return TRX_ERR_CAPACITY;
     for (int i = 0; i < iters; i++) {
         int rc = trx_affine_step(vol, loss, opt, st, workspace, workspace_bytes, stream);
         if (rc) return rc;
@@ -1690,11 +1695,11 @@ extern "C" int trx_affine_warp(const trx_volumes *vol, const float *theta, int c
         trx_volumes v = *vol;
         v.B = vol->B * channels;                       // geometry: every (pair, channel) is one slab of blocks
         TileGeom t = tile_geom(v);
-        if (use_dual()) {
+        if (use_dual(vol)) {
             const TileGeom ta = tile_geom<GeomA>(v), tr = tile_geom<GeomR>(v);
             v.B = vol->B;
             const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
-            launch_dual<3>(dim3(gx, vol->B * channels), s, v, theta, ta, tr, channels, out, use_dual());
+            launch_dual<3>(dim3(gx, vol->B * channels), s, v, theta, ta, tr, channels, out, use_dual(vol));
             TRX_CHECK_LAUNCH();
             return TRX_OK;
         }
@@ -1733,10 +1738,10 @@ extern "C" int trx_affine_warp_backward(const trx_volumes *vol, const float *the
         // caller-less tables: the row-walking gather kernel below; the workspace is sized for single-channel tiles.)
         TileGeom t = tile_geom(*vol);
         int rows = t.blocks_per_pair;
-        if (use_dual()) {
+        if (use_dual(vol)) {
             const TileGeom ta = tile_geom<GeomA>(*vol), tr = tile_geom<GeomR>(*vol);
             rows = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
-            launch_dual<2>(dim3(rows, vol->B), s, v, theta, ta, tr, 1, partials, use_dual());
+            launch_dual<2>(dim3(rows, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol));
         } else {
             hipLaunchKernelGGL((affine_tile_kernel<2>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
         }

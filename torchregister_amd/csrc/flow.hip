@@ -9,8 +9,6 @@
 //   pass B  flow_update_kernel  : re-sample + derivative, dL/dflow, SGD/Adam update in place
 // replacing SpatialTransformer.forward -> criterion -> backward -> optimizer.step of
 // ref:warpings.py:208-220 when the parameter is the flow itself.
-#include <cstdlib>
-
 #include "trx_common.h"
 
 namespace trx {
@@ -18,7 +16,19 @@ namespace trx {
 struct FlowCoef {   // per pair, written by flow_coef_kernel, read by pass B (wave-uniform)
     float k1, k2, my, mw, q;   // dL/dw_p = k1*(y-my) + k2*(w-mw) + q*(w-y)
     float step_size, inv_sqrt_bc2, sm[3];  // Adam scalars; smoothness gradient scale per dim
+    int mode;                  // kUpd*: what the update kernel does for this pair in this iteration (early stop, see flow_coef_kernel)
 };
+// Early stop (ref:warpings.py:231-233) without a host sync.  stopped[b]: 0 running; 1 the loss of the last executed iteration was <= stop_crit
+// (its update has been / is being applied, as in the reference, which steps before it tests) and a double-buffered flow still differs
+// between its two buffers; 2 stopped and settled.  The host keeps enqueueing iterations and swapping its buffer pointers; for a stopped
+// pair they are no-ops:
+//   kUpdNormal      the usual update
+//   kUpdHit         the usual update, and the flow it starts from is kept in flow_last (the flow of the last forward)
+//   kUpdCopy        flow_out = flow (first iteration after a hit, double-buffered flows only: both buffers hold the final flow afterwards)
+//   kUpdSkip        nothing
+//   kUpdTransition  lagged regulariser (the hit is seen one coefficient kernel late, the update of the hit iteration is already in
+//                   `flow`, the flow it started from is still in `flow_out`): flow_last = flow_out, then flow_out = flow
+constexpr int kUpdNormal = 0, kUpdHit = 1, kUpdCopy = 2, kUpdSkip = 3, kUpdTransition = 4;
 
 // Z-slab partition of ONE volume (BASELINE config 5): target / flow / optimiser state of a rank hold planes
 // [zoff, zoff + D) of a Dm-deep volume; `moving` is the whole volume (replicated: it is constant, so no halo
@@ -133,7 +143,8 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
                                                          float *__restrict__ losses, int losses_capacity, int *__restrict__ step,
                                                          float *__restrict__ terms, FlowCoef *__restrict__ coef,
                                                          double *__restrict__ mom_out, const double *__restrict__ mom_in, int D_full,
-                                                         int lag = 0, double *__restrict__ stash = nullptr)
+                                                         int lag = 0, double *__restrict__ stash = nullptr, float stop_crit = 0.f,
+                                                         int *__restrict__ stopped = nullptr, int double_buffered = 0)
 {
     // lag (fused steps with the smoothness term, trx_flow_run): the data moments S[0..4] describe THIS iteration's flow, the
     // smoothness sums S[5..7] the PREVIOUS one (they are collected by the update kernel, which is where the neighbours of a flow are
@@ -161,6 +172,7 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
     __syncthreads();
     if (tid != 0) return;
     const int t_step = step ? step[b] : 0;   // issued early: its latency hides under the fp64 arithmetic below
+    const int stp = stopped ? stopped[b] : 0;
     double S[8];
     for (int j = 0; j < 8; j++) {
         double t = 0.0;
@@ -173,6 +185,12 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
     }
     if (mom_in)                  // slab mode, pass B: sums of the WHOLE volume
         for (int j = 0; j < 8; j++) S[j] = mom_in[b * 8 + j];
+    if (stp != 0) {              // this pair has stopped: nothing is recorded any more, the update kernel only settles the buffers
+        if (lag & kLagFlush) return;
+        coef[b].mode = (stp == 1 && double_buffered) ? kUpdCopy : kUpdSkip;
+        stopped[b] = 2;
+        return;
+    }
     D = D_full;
     const double n = (double)D * H * W;
     const double Sy = S[0], Sw = S[1], Syy = S[2], Sww = S[3], Syw = S[4];
@@ -185,6 +203,7 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
     // smoothness (extension): lambda/ndim * sum_d mean_{c,p}(forward difference along d)^2
     const int ext[3] = {ndim == 3 ? D : H, ndim == 3 ? H : W, W};
     FlowCoef c;
+    c.mode = kUpdNormal;
     c.sm[0] = c.sm[1] = c.sm[2] = 0.f;
     if (smooth_weight != 0.f) {
         double reg = 0.0;
@@ -199,8 +218,16 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
             total += (double)smooth_weight / ndim * reg;
         } else {
             const int tp = t_step - 1;
-            if ((lag & kLagPatch) && losses && tp >= 0 && tp < losses_capacity)
-                losses[(size_t)b * losses_capacity + tp] = (float)(stash[b] + (double)smooth_weight / ndim * reg);
+            if ((lag & kLagPatch) && tp >= 0) {
+                const float done = (float)(stash[b] + (double)smooth_weight / ndim * reg);   // the complete loss of iteration t - 1
+                if (losses && tp < losses_capacity) losses[(size_t)b * losses_capacity + tp] = done;
+                if (stopped && done <= stop_crit) {   // the reference would have left its loop after the update of iteration t - 1: that is now
+                    if (lag & kLagFlush) { stopped[b] = 1; return; }   // (the run ends here anyway; the next call settles the buffers)
+                    coef[b].mode = kUpdTransition;
+                    stopped[b] = 2;
+                    return;
+                }
+            }
             if (lag & kLagFlush) return;
             stash[b] = total;
         }
@@ -217,6 +244,11 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
     } else {
         c.step_size = oc.lr;
         c.inv_sqrt_bc2 = 1.f;
+    }
+    // early stop on the complete loss of THIS iteration (a lagged regulariser term is tested one coefficient kernel later, above)
+    if (stopped && lag == 0 && (float)total <= stop_crit) {
+        c.mode = kUpdHit;
+        stopped[b] = 1;
     }
     coef[b] = c;
     if (losses && t < losses_capacity) losses[(size_t)b * losses_capacity + t] = (float)total;
@@ -238,7 +270,8 @@ template <int ND, int MODE, bool SMOOTH, bool PIPE = false, bool NEXT = false>
 __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol, const float *flow,
                                                                 float *flow_out, float *__restrict__ adam_m,
                                                                 float *__restrict__ adam_v, const FlowCoef *__restrict__ coef,
-                                                                trx_opt_cfg oc, Slab slab, float *__restrict__ next_partials = nullptr)
+                                                                trx_opt_cfg oc, Slab slab, float *__restrict__ next_partials = nullptr,
+                                                                float *__restrict__ flow_last = nullptr, int save_last = 0)
 {
     static_assert(!NEXT || MODE == 0, "the fused next-iteration moments ride on the update");
     float nv[kFlowNP] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -250,6 +283,20 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
     const float *fl = flow + (size_t)b * ND * nvox;   // may alias fo (in-place update): no restrict
     float *fo = flow_out + (size_t)b * ND * nvox;
     const FlowCoef c = coef[b];
+    float *__restrict__ fkeep = nullptr;   // != nullptr: this update also keeps the flow it starts from (the flow of the last forward)
+    if constexpr (MODE == 0) {
+        if (c.mode >= kUpdCopy) {          // a pair that has stopped early (block-uniform): settle the buffers, no arithmetic
+            if (c.mode != kUpdSkip && fo != fl) {
+                float *__restrict__ keep = (c.mode == kUpdTransition && flow_last) ? flow_last + (size_t)b * ND * nvox : nullptr;
+                for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < (size_t)ND * nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
+                    if (keep) keep[i] = fo[i];
+                    fo[i] = fl[i];
+                }
+            }
+            return;   // (a fused update leaves next_partials as they are: the coefficient kernel of a stopped pair does not read them)
+        }
+        if (flow_last && (save_last || c.mode == kUpdHit)) fkeep = flow_last + (size_t)b * ND * nvox;
+    }
     const size_t dstride[3] = {ND == 3 ? (size_t)H * W : (size_t)W, ND == 3 ? (size_t)W : 1, 1};
     // As in pass A: the flow / target of voxel k+1 are requested before the gather of voxel k is
     // consumed (each thread owns its voxels, so reading ahead of the in-place update is safe).
@@ -324,6 +371,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
                     p = p - c.step_size * g;
                 }
                 fo[ch * nvox + i] = p;
+                if (fkeep) fkeep[ch * nvox + i] = f0;
                 if constexpr (NEXT) pnew[ch] = p;
             }
         }
@@ -423,8 +471,8 @@ static unsigned flow_grid_x(const trx_volumes &v)
 {
     const size_t nvox = (size_t)v.D * v.H * v.W;
     size_t nb = (nvox + TRX_BLOCK - 1) / TRX_BLOCK;
-    static const size_t total = [] { const char *e = getenv("TRX_FLOW_BLOCKS"); return (size_t)(e ? atoi(e) : 4096); }();   // development knob
-    size_t cap = (total + v.B - 1) / v.B;  // ~4096 blocks in flight overall
+    const size_t total = 4096;             // blocks in flight overall (measured sweep: 2048 .. 8192 within 2 %)
+    size_t cap = (total + v.B - 1) / v.B;
     if (cap < 64) cap = 64;
     return (unsigned)(nb < cap ? nb : cap);
 }
@@ -471,39 +519,37 @@ static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth
 
 template <int MODE>
 static int launch_update(const trx_volumes *vol, const float *flow, float *flow_out, float *m, float *v, const FlowCoef *coef,
-                         const trx_opt_cfg &oc, bool smooth, hipStream_t s, Slab slab = Slab{0, -1, nullptr, nullptr}, float *next_partials = nullptr)
+                         const trx_opt_cfg &oc, bool smooth, hipStream_t s, Slab slab = Slab{0, -1, nullptr, nullptr}, float *next_partials = nullptr,
+                         float *flow_last = nullptr, int save_last = 0)
 {
     if (slab.Dm < 0) slab.Dm = vol->D;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
+#define TRX_LAUNCH_UPD(...) hipLaunchKernelGGL((flow_update_kernel<__VA_ARGS__>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials, flow_last, save_last)
     if constexpr (MODE == 0) {
         if (next_partials && smooth) {
-            if (vol->ndim == 2)
-                hipLaunchKernelGGL((flow_update_kernel<2, 0, true, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
-            else
-                hipLaunchKernelGGL((flow_update_kernel<3, 0, true, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
+            if (vol->ndim == 2) TRX_LAUNCH_UPD(2, 0, true, false, true);
+            else TRX_LAUNCH_UPD(3, 0, true, false, true);
             TRX_CHECK_LAUNCH();
             return TRX_OK;
         }
         if (next_partials && !smooth) {   // the update + the next iteration's pass A in one kernel
-            if (vol->ndim == 2)
-                hipLaunchKernelGGL((flow_update_kernel<2, 0, false, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
-            else if (oc.kind != TRX_OPT_ADAM)
-                hipLaunchKernelGGL((flow_update_kernel<3, 0, false, true, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
-            else
-                hipLaunchKernelGGL((flow_update_kernel<3, 0, false, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials);
+            if (vol->ndim == 2) TRX_LAUNCH_UPD(2, 0, false, false, true);
+            else if (oc.kind != TRX_OPT_ADAM) TRX_LAUNCH_UPD(3, 0, false, true, true);
+            else TRX_LAUNCH_UPD(3, 0, false, false, true);
             TRX_CHECK_LAUNCH();
             return TRX_OK;
         }
     }
     if (vol->ndim == 3) {
         const bool pipe = (MODE == 0) && !smooth && oc.kind != TRX_OPT_ADAM;
-        if (smooth) hipLaunchKernelGGL((flow_update_kernel<3, MODE, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab);
-        else if (pipe) hipLaunchKernelGGL((flow_update_kernel<3, MODE, false, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab);
-        else hipLaunchKernelGGL((flow_update_kernel<3, MODE, false>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab);
+        if (smooth) TRX_LAUNCH_UPD(3, MODE, true);
+        else if (pipe) TRX_LAUNCH_UPD(3, MODE, false, true);
+        else TRX_LAUNCH_UPD(3, MODE, false);
     } else {
-        if (smooth) hipLaunchKernelGGL((flow_update_kernel<2, MODE, true>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab);
-        else hipLaunchKernelGGL((flow_update_kernel<2, MODE, false>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab);
+        if (smooth) TRX_LAUNCH_UPD(2, MODE, true);
+        else TRX_LAUNCH_UPD(2, MODE, false);
     }
+#undef TRX_LAUNCH_UPD
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
@@ -511,7 +557,8 @@ static int launch_update(const trx_volumes *vol, const float *flow, float *flow_
 // have_moments: the partials of `cur` are already in the workspace (written by the previous iteration's fused update);
 // fuse_next: let this iteration's update write the partials of the flow it produces.
 static int flow_step_impl(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_flow_state *st,
-                          float *cur, float *nxt, void *workspace, hipStream_t s, bool have_moments = false, bool fuse_next = false, int lag = 0)
+                          float *cur, float *nxt, void *workspace, hipStream_t s, bool have_moments = false, bool fuse_next = false, int lag = 0,
+                          bool last_of_call = false)
 {
     const bool smooth = st->smooth_weight != 0.f;
     float *partials = (float *)workspace;
@@ -520,9 +567,10 @@ static int flow_step_impl(const trx_volumes *vol, const trx_loss_cfg *loss, cons
     if (rc) return rc;
     hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, partials, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
                        vol->W, *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr, (const double *)nullptr, vol->D,
-                       lag, stash_ptr(vol, workspace));
+                       lag, stash_ptr(vol, workspace), st->stop_crit, st->stopped, (int)(cur != nxt));
     TRX_CHECK_LAUNCH();
-    return launch_update<0>(vol, cur, nxt, st->adam_m, st->adam_v, coef, *opt, smooth, s, Slab{0, -1, nullptr, nullptr}, fuse_next ? partials : nullptr);
+    return launch_update<0>(vol, cur, nxt, st->adam_m, st->adam_v, coef, *opt, smooth, s, Slab{0, -1, nullptr, nullptr}, fuse_next ? partials : nullptr,
+                            st->flow_last, last_of_call ? 1 : 0);
 }
 
 static int check_flow_args(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_flow_state *st,
@@ -548,8 +596,9 @@ extern "C" int trx_flow_run(const trx_volumes *vol, const trx_loss_cfg *loss, co
     const bool smooth = st->smooth_weight != 0.f;
     float *cur = st->flow, *nxt = smooth ? st->flow_tmp : st->flow;
     // Inside one call the update of iteration i also produces the moments of iteration i + 1 (no smoothness term): after the
-    // first iteration every step is coefficient kernel + one streaming kernel.  TRX_FLOW_FUSE_NEXT=0 keeps the two-pass steps.
-    static const bool fuse = [] { const char *e = getenv("TRX_FLOW_FUSE_NEXT"); return !(e && atoi(e) == 0); }();
+    // first iteration every step is coefficient kernel + one streaming kernel.  TRX_FLAG_TWO_PASS_FLOW keeps the two-pass steps.
+    const bool fuse = !(vol->flags & TRX_FLAG_TWO_PASS_FLOW);
+    if (st->losses && iters > st->losses_capacity) return TRX_ERR_CAPACITY;
     // With the smoothness term every update of a run of >= 2 iterations is the fused one (its regulariser sums lag by one iteration,
     // see flow_coef_kernel) and one coefficient-kernel launch after the loop completes the last recorded loss.
     const bool lagged = fuse && smooth && iters >= 2;
@@ -557,7 +606,7 @@ extern "C" int trx_flow_run(const trx_volumes *vol, const trx_loss_cfg *loss, co
     for (int i = 0; i < iters; i++) {
         const bool next = lagged || (fuse && !smooth && (i + 1 < iters));
         const int lag = (lagged && i >= 1) ? (kLagRecord | (i >= 2 ? kLagPatch : 0)) : 0;
-        rc = flow_step_impl(vol, loss, opt, st, cur, nxt, workspace, s, have, next, lag);
+        rc = flow_step_impl(vol, loss, opt, st, cur, nxt, workspace, s, have, next, lag, i + 1 == iters);
         if (rc) return rc;
         have = next;
         float *t = cur; cur = nxt; nxt = t;
@@ -565,7 +614,7 @@ extern "C" int trx_flow_run(const trx_volumes *vol, const trx_loss_cfg *loss, co
     if (lagged) {
         hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, (const float *)workspace, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
                            vol->W, *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef_ptr(vol, workspace),
-                           (double *)nullptr, (const double *)nullptr, vol->D, kLagPatch | kLagFlush, stash_ptr(vol, workspace));
+                           (double *)nullptr, (const double *)nullptr, vol->D, kLagPatch | kLagFlush, stash_ptr(vol, workspace), st->stop_crit, st->stopped, 1);
         TRX_CHECK_LAUNCH();
     }
     if (cur != st->flow) {  // odd number of double-buffered steps: result lives in flow_tmp
@@ -676,11 +725,11 @@ extern "C" int trx_flow_slab_update(const trx_volumes *vol, int z_offset, int D_
     FlowCoef *coef = coef_ptr(vol, workspace);
     hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, (const float *)workspace, 0, vol->ndim, vol->D, vol->H, vol->W,
                        *loss, *opt, st->smooth_weight, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr,
-                       global_moments, D_full);
+                       global_moments, D_full, 0, (double *)nullptr, st->stop_crit, st->stopped, (int)smooth);
     TRX_CHECK_LAUNCH();
     // with the regulariser the update reads neighbours of the OLD flow: it is written to flow_tmp (the caller swaps)
     return launch_update<0>(vol, st->flow, smooth ? st->flow_tmp : st->flow, st->adam_m, st->adam_v, coef, *opt, smooth, s,
-                            Slab{z_offset, D_full, halo_lo, halo_hi});
+                            Slab{z_offset, D_full, halo_lo, halo_hi}, nullptr, st->flow_last, st->flow_last ? 1 : 0);
 }
 
 // Slab counterpart of the fused step of trx_flow_run (no smoothness term, 3-D): the update also leaves the slab's block partials of
@@ -699,10 +748,10 @@ extern "C" int trx_flow_slab_update_fused(const trx_volumes *vol, int z_offset, 
     FlowCoef *coef = coef_ptr(vol, workspace);
     hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, (const float *)workspace, 0, vol->ndim, vol->D, vol->H, vol->W,
                        *loss, *opt, 0.f, st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr,
-                       global_moments, D_full);
+                       global_moments, D_full, 0, (double *)nullptr, st->stop_crit, st->stopped, 0);
     TRX_CHECK_LAUNCH();
     return launch_update<0>(vol, st->flow, st->flow, st->adam_m, st->adam_v, coef, *opt, false, s, Slab{z_offset, D_full, nullptr, nullptr},
-                            (float *)workspace);
+                            (float *)workspace, st->flow_last, st->flow_last ? 1 : 0);
 }
 
 extern "C" int trx_flow_slab_moments_ready(const trx_volumes *vol, int z_offset, int D_full, double *moments, void *workspace,

@@ -219,6 +219,17 @@ class _FlowLossFn(torch.autograd.Function):
         return grad_out * dflow, None, None, None
 
 
+def smooth_regulariser(flow, weight):
+    """weight / ndim * sum_d mean_{c,p} (forward difference of the flow along d)^2, per pair, summed over pairs - the definition the
+    fused kernels use (flow_coef_kernel in csrc/flow.hip), for the paths whose loss is assembled by torch."""
+    nd = flow.dim() - 2
+    reg = 0.0
+    for d in range(nd):
+        df = flow.diff(dim=2 + d)
+        reg = reg + (df * df).flatten(1).mean(dim=1).sum()
+    return float(weight) / nd * reg
+
+
 class flow_register(nn.Module):
     """Dense flow-field registration (ref:warpings.py:178-242).
 
@@ -239,6 +250,8 @@ class flow_register(nn.Module):
         self.img_size = tuple(int(s) for s in img_size)
         self.flow_model = flow_model
         self.criterions = [nn.MSELoss(), NCCLoss(), NMILoss()] if criterions is None else criterions
+        if len(weights) < len(self.criterions):
+            raise IndexError("fewer weights than criterions")   # the reference indexes weights[i] (ref:warpings.py:213-214)
         self.weights, self.lr, self.max_epochs, self.stop_crit = weights, lr, max_epochs, stop_crit
         self.optimizer_kind, self.smooth_weight = optimizer, smooth_weight
         if flow_model == "unet":
@@ -259,7 +272,7 @@ class flow_register(nn.Module):
             return y
         return self.warp(x, self.flow)
 
-    def optimize(self, moving, target, device=None, debug=True, grad_edges=False, check_every=50):
+    def optimize(self, moving, target, device=None, debug=True, grad_edges=False):
         if grad_edges:
             raise NotImplementedError("grad_edges=True is not supported (SURVEY Q6)")
         spec = loss_spec_from(self.criterions, self.weights[: len(self.criterions)])
@@ -275,30 +288,20 @@ class flow_register(nn.Module):
             return self._optimize_unet(moving, target, spec, debug)
         if spec is None:
             return self._optimize_generic(moving, target, debug)
+        # The whole loop is ONE call: the early stop of ref:warpings.py:231-233 is tested on the device after every iteration (per
+        # pair: a batch is B independent registrations), a pair that has converged ignores the remaining iterations, and the flow
+        # of its last forward is kept beside the final one - exactly the state the reference leaves behind, with one host sync.
         solver = FlowSolver(moving, target, loss=spec, optimizer=self.optimizer_kind, lr=self.lr, capacity=max(1, self.max_epochs),
-                            smooth_weight=self.smooth_weight)
-        done, message = 0, "Reached max epochs"
-        last_forward = None
-        while done < self.max_epochs:
-            n = min(check_every, self.max_epochs - done)
-            # the flow that produced loss[done-1] is the one BEFORE that step's update: the reference
-            # keeps the flow of its last forward (ref:warpings.py:211,231-233 / torchregister.py:81)
-            if done + n == self.max_epochs:
-                solver.run(n - 1)
-                last_forward = solver.flow.clone()
-                solver.run(1)
-            else:
-                solver.run(n)
-            done += n
-            ls = solver.losses[0, done - n:done]
-            hit = torch.nonzero(ls <= self.stop_crit)
-            if len(hit):           # early stop (checked every `check_every` iterations, one host sync each)
-                message = "Converged to %f" % self.stop_crit
-                done = done - n + int(hit[0]) + 1
-                break
-        self.flow = last_forward if last_forward is not None else solver.flow
+                            smooth_weight=self.smooth_weight, stop_crit=self.stop_crit, keep_last=True)
+        solver.run(self.max_epochs)
+        done = solver.step.cpu()                       # iterations executed per pair (the only host sync)
+        n = int(done.max()) if self.max_epochs > 0 else 0
+        self.flow = solver.flow_last if self.max_epochs > 0 else solver.flow
         self.final_flow = solver.flow
-        self.losses = solver.losses[:, :done]
+        self.losses = solver.losses[:, :n]             # pairs that stopped earlier are NaN-padded behind their own `iterations`
+        self.iterations = done
+        self.solver = solver
+        message = "Converged to %f" % self.stop_crit if bool((solver.stopped != 0).all()) else "Reached max epochs"
         if debug:
             print("Optimization ended with status: %s" % message)
 
@@ -314,6 +317,8 @@ class flow_register(nn.Module):
             else:
                 y = self.warp(moving, flow)
                 err = sum(w * c(target, y) for c, w in zip(self.criterions, self.weights))
+            if self.smooth_weight:
+                err = err + smooth_regulariser(flow, self.smooth_weight)
             err.backward()
             self.optimizer.step()
             self.flow = flow.detach()
@@ -336,6 +341,8 @@ class flow_register(nn.Module):
             last = fl.detach().clone()
             y = self.warp(moving, fl)
             err = sum(w * c(target, y) for c, w in zip(self.criterions, self.weights))
+            if self.smooth_weight:
+                err = err + smooth_regulariser(fl, self.smooth_weight)
             err.backward()
             opt.step()
             losses.append(err.item())
