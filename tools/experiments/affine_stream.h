@@ -1,3 +1,16 @@
+// EXPERIMENT (round 2) - NOT part of libtrx.so.  Build: hipcc ... -DTRX_DEV -DTRX_EXPERIMENT_STREAM tools/kbench.hip.
+// Result on MI355X, 8 x 256^3 (profiles/r02a_stream_v4_ablation.txt; tile kernel in the same runs: 300-316 us per launch):
+//   all 41 sums agree with the tile kernel to 2e-8 ... 1e-7 relative, but the full kernel needs 360-385 us.
+//   staging alone (ring DMA + targets, no gather; earlier symmetric variant): 204-208 us - the y ring and the 64-wide rows do cut the
+//   memory side to the rate of a plain read of the same bytes (tile kernel, staging alone: 234 us);
+//   bookkeeping alone: 100-112 us; gather + bookkeeping with NO memory traffic: 258-272 us.  A step is only 4 rows per thread
+//   (the ring must hold the rows of three steps in 72 KB), so one barrier, one counted wait, the plan read-back and the DMA issue
+//   are paid every 4 rows where the tile kernel pays its per-tile costs every 8.  Variants tried: per-wave scalar bookkeeping
+//   (221 us of it: the CU's single scalar pipe saturates), a dedicated producer wave (one wave cannot issue 20 LDS-DMA per step:
+//   ~200 cycles each, 463 us), rows dealt to waves (unbalanced barrier arrival), pieces dealt round-robin (this file).
+// Kept because the loader half is sound and measured; what would make it win is a step of >= 8 rows, i.e. a ring of 32 rows, which
+// does not fit two blocks per CU.
+//
 // Y-STREAMING variant of the F1 pass (3-D, MODE 0: moments + sum(qJ)) for transforms near the identity - where every affine run
 // starts and, after a rigid pre-alignment, stays.  Included by affine.hip inside namespace trx.
 //
@@ -17,8 +30,12 @@
 // Numerics: identical per-voxel arithmetic to tile_body's fast loop (coordinates bitwise ATen's at the identity); only the order in
 // which a thread's voxels are added differs (one thread: one (x, z) column along the whole segment).
 
+#ifndef TRX_STREAM_DBG
+#define TRX_STREAM_DBG 0   // development ablation (tools/kbench.hip): bits: 1 = no box DMA, 2 = no target loads, 4 = no gather
+#endif
+
 struct StreamCfg {
-    static constexpr int TX = 64, TZ = 8, SR = 4, Threads = 512, Waves = 8;
+    static constexpr int TX = 64, TZ = 8, SR = 4, Waves = 8, Threads = Waves * 64;   // a wave = one z plane of the column
     static constexpr int R = 16;                     // ring rows (slot = source row & 15); slot 16 duplicates slot 0 so that row + 1 is always at + RowBytes
     static constexpr int NP = 14, BW = 76, BW4 = 19; // planes and floats (float4 slots) per ring row
     static constexpr int PPL = 3;                    // planes per DMA piece: 3 x 19 = 57 float4 slots <= 64 lanes, contiguous in LDS
@@ -28,7 +45,6 @@ struct StreamCfg {
     static constexpr int ReduceScratch = Waves * 16 * 65 + Waves * 16;
     static constexpr int BoxAlloc = RingFloats > ReduceScratch ? RingFloats : ReduceScratch;
     static constexpr int Ahead = 2;                  // steps of look-ahead of the loader
-    static constexpr int Chunk = 16;                 // steps per geometry refresh (64 output rows: one row per lane)
 };
 
 struct StreamGeom {
@@ -81,12 +97,10 @@ __device__ __forceinline__ bool stream_fits(const float *__restrict__ th, float 
 // s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt(int n)
 {
-    n = n > 31 ? 31 : n;
 #define TRX_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
     switch (n) {
         TRX_W(0) TRX_W(1) TRX_W(2) TRX_W(3) TRX_W(4) TRX_W(5) TRX_W(6) TRX_W(7) TRX_W(8) TRX_W(9) TRX_W(10) TRX_W(11) TRX_W(12) TRX_W(13) TRX_W(14) TRX_W(15)
-        TRX_W(16) TRX_W(17) TRX_W(18) TRX_W(19) TRX_W(20) TRX_W(21) TRX_W(22) TRX_W(23) TRX_W(24) TRX_W(25) TRX_W(26) TRX_W(27) TRX_W(28) TRX_W(29) TRX_W(30)
-    default: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
     }
 #undef TRX_W
 }
@@ -126,6 +140,9 @@ __global__ __launch_bounds__(StreamCfg::Threads, 4) void affine_stream_kernel(tr
     if ((ncol & 7) == 0) col = (cb & 7) * (ncol >> 3) + (cb >> 3);
     const int X0 = (col % sg.ntx) * C::TX, Z0 = (col / sg.ntx) * C::TZ;
     const int nx = min(C::TX, W - X0), nz = min(C::TZ, D - Z0);
+    const int s_begin = seg * sg.steps_per_seg, s_end = min(s_begin + sg.steps_per_seg, sg.nsteps);
+    const unsigned box_lds = (unsigned)(uintptr_t)box;
+
     const bool wave_on = wave < nz;                       // a wave = one z plane of the column
     const bool act = (lane < nx) && wave_on;
     const int x = X0 + (lane < nx ? lane : 0), z = Z0 + (wave_on ? wave : 0);
@@ -133,6 +150,7 @@ __global__ __launch_bounds__(StreamCfg::Threads, 4) void affine_stream_kernel(tr
     const float base_x = unnorm<3>(xn, fW) + hW * fmaf(t00 - 1.0f, xn, fmaf(t02, zn, t03));
     const float base_y = hH * fmaf(t10, xn, fmaf(t12, zn, t13));
     const float base_z = unnorm<3>(zn, fD) + hD * fmaf(t20, xn, fmaf(t22 - 1.0f, zn, t23));
+    const unsigned toffb = (unsigned)((z * H) * W + x) * 4u;         // this thread's target offset inside a row block
 
     // pre-image of the (x, z) rectangle of the column relative to the image of its (X0, Z0) corner
     float elo[3], ehi[3];
@@ -154,12 +172,9 @@ __global__ __launch_bounds__(StreamCfg::Threads, 4) void affine_stream_kernel(tr
     const float corner_x = uni(unnorm<3>(cxn, fW) + hW * fmaf(t00 - 1.0f, cxn, fmaf(t02, czn, t03)));
     const float corner_y = uni(hH * fmaf(t10, cxn, fmaf(t12, czn, t13)));
     const float corner_z = uni(unnorm<3>(czn, fD) + hD * fmaf(t20, cxn, fmaf(t22 - 1.0f, czn, t23)));
-
     // LDS-DMA slot of a lane inside a piece (3 planes x 19 float4): plane pz, float4 dx4; byte offset inside the volume
     const int pz = lane / C::BW4, dx4 = lane - pz * C::BW4;
     const unsigned rb0 = (unsigned)((pz * H) * W + dx4 * 4) * 4u;
-    const unsigned box_lds = (unsigned)(uintptr_t)box;
-    const unsigned toffb = (unsigned)((z * H) * W + x) * 4u;     // this thread's target offset inside a row block
 
     F1Acc acc;
 #pragma unroll
@@ -168,27 +183,27 @@ __global__ __launch_bounds__(StreamCfg::Threads, 4) void affine_stream_kernel(tr
         for (int c = 0; c < 3; c++) acc.AB[q][c] = (f2)(0.f);
     acc.M01 = acc.M23 = (f2)(0.f);
     acc.M4 = 0.f;
-
-    float sxv, syv, szv;   // VGPR copies of the uniform slopes (the per-row yn is then the single SGPR operand)
-    asm("v_mov_b32 %0, %1" : "=v"(sxv) : "s"(sx));
-    asm("v_mov_b32 %0, %1" : "=v"(syv) : "s"(sy));
-    asm("v_mov_b32 %0, %1" : "=v"(szv) : "s"(sz));
     int rs_s, ps_s;        // LDS strides (bytes) in SGPRs: ring row, plane
     asm("s_mov_b32 %0, %1" : "=s"(rs_s) : "i"(C::RowBytes));
     asm("s_mov_b32 %0, %1" : "=s"(ps_s) : "i"(C::BW * 4));
 
-    const int s_begin = seg * sg.steps_per_seg, s_end = min(s_begin + sg.steps_per_seg, sg.nsteps);
-
-    // ---- geometry of a chunk of steps, one STEP per lane (lanes 0 .. Chunk + Ahead + 1), and the row tables, one ROW per lane
-    int g_rlo = 0, g_rhi = 0, g_xlo = 0, g_xhi = 0, g_zlo = 0, g_zhi = 0;
-    float yn_l = 0.f, yid_l = 0.f;
-    int chunk0 = -1 << 30;
+    // ---- The PLAN of a run of steps is computed lane-parallel, ONE STEP PER LANE (lane k = step plan0 + k; every wave keeps its own
+    // copy), and read per step with a few v_readlane: wave-uniform bookkeeping done step by step on the scalar unit costs eight waves x
+    // two blocks of it per CU and saturates the CU's one scalar pipe (measured: 221 us per launch of bookkeeping alone).
+    int g_rlo, g_rhi, g_xlo, g_xhi, g_zlo, g_zhi;   // source rows / x / z range of the step (inclusive)
+    int g_new = 0, g_cnt = 0, g_key = 0;             // first row the step has to request, number of them; packed slot extents of its rows
+    float g_yn[C::SR], g_yid[C::SR];                 // row constants of the step's 4 output rows
+    int plan0 = 0;
     const float slack = 0.05f;
-    auto chunk_geometry = [&](int s0) {
-        chunk0 = s0;
-        const int y0 = min((s0 + lane) * C::SR, H - 1), y3 = min((s0 + lane) * C::SR + C::SR - 1, H - 1);
-        const float a0 = ytab[y0], a3 = ytab[y3];
-        const float cy0 = unnorm<3>(a0, fH) + fmaf(sy, a0, corner_y), cy3 = unnorm<3>(a3, fH) + fmaf(sy, a3, corner_y);
+    auto plan_geometry = [&](int s0) {
+        plan0 = s0;
+#pragma unroll
+        for (int j = 0; j < C::SR; j++) {
+            g_yn[j] = ytab[min((s0 + lane) * C::SR + j, H - 1)];
+            g_yid[j] = unnorm<3>(g_yn[j], fH);
+        }
+        const float a0 = g_yn[0], a3 = g_yn[C::SR - 1];
+        const float cy0 = g_yid[0] + fmaf(sy, a0, corner_y), cy3 = g_yid[C::SR - 1] + fmaf(sy, a3, corner_y);
         g_rlo = (int)floorf(cy0 + elo[1] - slack);
         g_rhi = (int)floorf(cy3 + ehi[1] + slack) + 1;
         const float cx0 = fmaf(sx, a0, corner_x), cx3 = fmaf(sx, a3, corner_x);
@@ -197,21 +212,35 @@ __global__ __launch_bounds__(StreamCfg::Threads, 4) void affine_stream_kernel(tr
         const float cz0 = fmaf(sz, a0, corner_z), cz3 = fmaf(sz, a3, corner_z);
         g_zlo = (int)floorf(fminf(cz0, cz3) + elo[2] - slack);
         g_zhi = (int)floorf(fmaxf(cz0, cz3) + ehi[2] + slack) + 1;
-        yn_l = ytab[min(s0 * C::SR + lane, H - 1)];
-        yid_l = unnorm<3>(yn_l, fH);
     };
-    auto rl = [&](int v, int s) { return __builtin_amdgcn_readlane(v, s - chunk0); };   // geometry of step s (chunk0 <= s < chunk0 + 20)
+    auto rl = [&](int v, int st) { return __builtin_amdgcn_readlane(v, st - plan0); };   // value of step st (plan0 <= st < plan0 + 64)
 
-    // ---- loader state (wave-uniform)
     int ox = 0, oz = 0;            // window origin of the current segment (ox % 4 == 0)
-    int Lrow = 0;                  // source rows < Lrow have been requested under the current anchor
-    int seg_end = s_end;           // first step that does not fit the current anchor (re-anchor there)
-    unsigned long long m_piece[C::NPIECE];   // exec masks of the DMA pieces: slot needed by the steps being loaded AND inside the volume
-    int m_key = -1;
+    int seg_end = s_end;           // first step outside the current segment (window left, plan exhausted, or end of the block)
+    // exec masks and LDS / plane offsets of the DMA pieces that are not empty, compacted (np_act of them)
+    unsigned long long m_act[C::NPIECE];
+    int p_act[C::NPIECE];
+    int np_act = 0, m_key = -1;
 #pragma unroll
-    for (int p = 0; p < C::NPIECE; p++) m_piece[p] = 0;
+    for (int p = 0; p < C::NPIECE; p++) { m_act[p] = 0; p_act[p] = 0; }
 
+    // After (ox, oz) is chosen: which steps of the plan the window holds, the rows each step must request (rows below were requested
+    // by its predecessor) and the slot extents its rows must cover (steps t .. t + 2 read them), all lane-parallel.
+    auto plan_segment = [&](int s_anchor) {
+        const bool holds = (g_xlo >= ox) && (g_xhi <= ox + C::BW - 1) && (g_zlo >= oz) && (g_zhi <= oz + C::NP - 1);
+        const int k0 = s_anchor - plan0;
+        const unsigned long long bad = (__builtin_amdgcn_ballot_w64(!holds) | (1ull << 61)) >> k0 << k0;   // the plan serves 61 steps (t + 2 is read)
+        seg_end = min(s_end, plan0 + (int)__builtin_ctzll(bad));
+        const int prev_hi = __shfl_up(g_rhi, 1);
+        g_new = (lane == k0) ? g_rlo : max(g_rlo, prev_hi + 1);
+        g_cnt = max(0, g_rhi - g_new + 1);
+        const int x0a = min(g_xlo, min(__shfl_down(g_xlo, 1), __shfl_down(g_xlo, 2))), x1a = max(g_xhi, max(__shfl_down(g_xhi, 1), __shfl_down(g_xhi, 2)));
+        const int z0a = min(g_zlo, min(__shfl_down(g_zlo, 1), __shfl_down(g_zlo, 2))), z1a = max(g_zhi, max(__shfl_down(g_zhi, 1), __shfl_down(g_zhi, 2)));
+        const int nx0 = max(x0a, ox) - ox, nx1 = min(x1a, ox + C::BW - 1) - ox, nz0 = max(z0a, oz) - oz, nz1 = min(z1a, oz + C::NP - 1) - oz;
+        g_key = (nx0 >> 2) | ((nx1 >> 2) << 8) | (nz0 << 16) | (nz1 << 24);
+    };
     auto dma = [&](const char *gbase, unsigned lds_addr, unsigned long long mask) {
+        if (TRX_STREAM_DBG & 1) return;
         unsigned long long sv;
         unsigned m0s;
         asm volatile("s_mov_b64 %[sv], exec\n\t"
@@ -225,90 +254,88 @@ __global__ __launch_bounds__(StreamCfg::Threads, 4) void affine_stream_kernel(tr
                      : [lds] "s"(lds_addr), [base] "s"(gbase), [off] "v"(rb0), [mk] "s"(mask)
                      : "memory");
     };
-
-    // Request the source rows step t needs and has not got yet (rows of whole 76-float x 14-plane slabs, masked to what steps t and
-    // t + 1 can touch).  Returns the number of vector-memory instructions THIS wave issued.  Piece q = row * NPIECE + p goes to wave q & 7.
+    // Request the source rows step t needs and has not got yet: whole 76-float x 3-plane pieces, masked to the slots steps t .. t + 2
+    // can touch.  The (row, piece) pairs of the step are numbered q = 0, 1, ... and pair q goes to wave q & 7, so every wave issues the
+    // same number of DMAs (+-1): the step's barrier then waits for nobody in particular.  Returns this wave's vector-memory instructions.
     auto issue_rows = [&](int t) -> int {
         if (t >= seg_end) return 0;
-        const int xlo = rl(g_xlo, t), xhi = rl(g_xhi, t), zlo = rl(g_zlo, t), zhi = rl(g_zhi, t);
-        if (xlo < ox || xhi > ox + C::BW - 1 || zlo < oz || zhi > oz + C::NP - 1) {   // the window no longer holds this step: drain and re-anchor there
-            seg_end = t;
-            return 0;
-        }
-        // slots that steps t .. t + 2 can touch (the rows requested now are read by those steps at most: stream_fits bounds the rows
-        // alive at once), clamped to the window
-        const int t1 = min(t + 1, s_end - 1), t2 = min(t + 2, s_end - 1);
-        const int nx0 = max(min(xlo, min(rl(g_xlo, t1), rl(g_xlo, t2))), ox) - ox, nx1 = min(max(xhi, max(rl(g_xhi, t1), rl(g_xhi, t2))), ox + C::BW - 1) - ox;
-        const int nz0 = max(min(zlo, min(rl(g_zlo, t1), rl(g_zlo, t2))), oz) - oz, nz1 = min(max(zhi, max(rl(g_zhi, t1), rl(g_zhi, t2))), oz + C::NP - 1) - oz;
-        const int key = (nx0 >> 2) | ((nx1 >> 2) << 8) | (nz0 << 16) | (nz1 << 24);
+        const int key = rl(g_key, t);
         if (key != m_key) {
             m_key = key;
+            const int nx0 = key & 0xff, nx1 = (key >> 8) & 0xff, nz0 = (key >> 16) & 0xff, nz1 = (key >> 24) & 0xff;
             const int gx = ox + dx4 * 4;
-            const bool xok = (dx4 >= (nx0 >> 2)) && (dx4 <= (nx1 >> 2)) && (gx >= 0) && (gx + 4 <= W);
+            const bool xok = (dx4 >= nx0) && (dx4 <= nx1) && (gx >= 0) && (gx + 4 <= W);
+            np_act = 0;
 #pragma unroll
             for (int p = 0; p < C::NPIECE; p++) {
                 const int pl = p * C::PPL + pz;
                 const int gz = oz + pl;
                 const bool ok = (lane < C::PPL * C::BW4) && (pl < C::NP) && xok && (pl >= nz0) && (pl <= nz1) && (gz >= 0) && (gz < D);
-                m_piece[p] = __builtin_amdgcn_ballot_w64(ok);
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(ok);
+                if (mk) {
+#pragma unroll
+                    for (int k = 0; k < C::NPIECE; k++)
+                        if (k == np_act) { m_act[k] = mk; p_act[k] = p; }
+                    np_act++;
+                }
             }
         }
-        const int rhi = rl(g_rhi, t);
+        const int lo = rl(g_new, t), cnt = rl(g_cnt, t);
+        // pairs per row: the non-empty pieces; when a row of the step lies outside the volume (zero padding: every piece) all of them
+        const int npp = (lo >= 0 && lo + cnt <= H) ? np_act : C::NPIECE;
+        const int total = cnt * npp;
         int n = 0;
-        // piece p of row `row` goes to wave (row * NPIECE + p) & 7: at most one piece of a row per wave (NPIECE <= 8)
-        for (int row = max(Lrow, rl(g_rlo, t)); row <= rhi; row++) {
-            const int p = (wave - row * C::NPIECE) & 7;
-            if (p >= C::NPIECE) continue;
+        int row = lo, k = wave;                          // pair q = wave, wave + 8, ... -> (row, piece index k)
+        for (int q = wave; q < total; q += 8) {
+            while (k >= npp) { k -= npp; row++; }
             const int slot = row & (C::R - 1);
-            const unsigned loff = (unsigned)(slot * C::RowBytes + p * (C::PPL * C::BW * 4));
+            const unsigned loff = (unsigned)(slot * C::RowBytes);
             if ((unsigned)row < (unsigned)H) {
-                unsigned long long mk = 0;
+                if (k < np_act) {
+                    unsigned long long mk = 0;
+                    int pp = 0;
 #pragma unroll
-                for (int k = 0; k < C::NPIECE; k++) mk = (k == p) ? m_piece[k] : mk;
-                if (mk) {
-                    const char *gb = reinterpret_cast<const char *>(mov + ((ptrdiff_t)(oz + p * C::PPL) * H + row) * W + ox);
-                    dma(gb, box_lds + loff, mk);
+                    for (int i = 0; i < C::NPIECE; i++) { mk = (i == k) ? m_act[i] : mk; pp = (i == k) ? p_act[i] : pp; }
+                    const char *gb = reinterpret_cast<const char *>(mov + ((ptrdiff_t)(oz + pp * C::PPL) * H + row) * W + ox);
+                    dma(gb, box_lds + loff + pp * (C::PPL * C::BW * 4), mk);
                     n++;
-                    if (slot == 0) { dma(gb, box_lds + loff + C::R * C::RowBytes, mk); n++; }
+                    if (slot == 0) { dma(gb, box_lds + loff + pp * (C::PPL * C::BW * 4) + C::R * C::RowBytes, mk); n++; }
                 }
-            } else if (lane < C::PPL * C::BW4 && (p * C::PPL + pz) < C::NP) {   // a row outside the volume: zero padding
-                float4 *d = reinterpret_cast<float4 *>(reinterpret_cast<char *>(box) + loff) + lane;
+            } else if (lane < C::PPL * C::BW4 && (k * C::PPL + pz) < C::NP) {   // a row outside the volume: zero padding (LDS stores)
+                float4 *d = reinterpret_cast<float4 *>(reinterpret_cast<char *>(box) + loff + k * (C::PPL * C::BW * 4)) + lane;
                 *d = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (slot == 0) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(d) + C::R * C::RowBytes) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            k += 8;
         }
-        Lrow = max(Lrow, rhi + 1);
         return n;
     };
     // target values of step t for this thread (4 rows) -> tv; rows past the end of the volume are clamped (and skipped by the gather)
-    auto issue_targets = [&](int t, float (&tv)[C::SR]) -> int {
-        if (t >= s_end) return 0;
+    auto issue_targets = [&](int t, float (&tv)[C::SR]) {
 #pragma unroll
         for (int j = 0; j < C::SR; j++) {
             const int y = min(t * C::SR + j, H - 1);
+            if (TRX_STREAM_DBG & 2) { tv[j] = 1.f; continue; }
             asm volatile("global_load_dword %0, %1, %2" : "=v"(tv[j]) : "v"(toffb), "s"(tgt + (size_t)y * W) : "memory");
         }
-        return C::SR;
     };
-
     typedef const __attribute__((address_space(3))) f2u *lds_f2;
-    // ---- the 4 rows of step s for this thread, gathered from the ring
+    int bpb = 0;                   // LDS byte address of (x = 0, ring slot 0, z = 0) under the current window
     auto gather_step = [&](int s, float (&tv)[C::SR]) {
-        const int bpb = (int)box_lds - (oz * C::BW + ox) * 4;      // LDS byte address of (x = 0, ring slot 0, z = 0)
-        const int rbase = s * C::SR - chunk0 * C::SR;               // lane of the step's first row in the row tables
         float yn_r[C::SR], yid_r[C::SR];
 #pragma unroll
         for (int j = 0; j < C::SR; j++) {
-            yn_r[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yn_l), rbase + j));
-            yid_r[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yid_l), rbase + j));
+            yn_r[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_yn[j]), s - plan0));
+            yid_r[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_yid[j]), s - plan0));
         }
-        const int nrow = min(C::SR, H - s * C::SR);                 // (uniform) rows of this step inside the volume
+        if (!wave_on || (TRX_STREAM_DBG & 4)) return;                // (uniform per wave) a z plane past the volume
+        const int nrow = min(C::SR, H - s * C::SR);                  // (uniform) rows of this step inside the volume
         struct Fetch { f2 r00, r01, r10, r11; float fx, fy, fz; };
         auto fetch = [&](int j) -> Fetch {
             const float yn = yn_r[j];
-            const float ix = fmaf(sxv, yn, base_x);
-            const float iy = yid_r[j] + fmaf(syv, yn, base_y);
-            const float iz = fmaf(szv, yn, base_z);
+            const float ix = fmaf(sx, yn, base_x);
+            const float iy = yid_r[j] + fmaf(sy, yn, base_y);
+            const float iz = fmaf(sz, yn, base_z);
             int a0, a1, a2, a3, ry;
             asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a0) : "v"(floor_to_int(ix)), "s"(bpb));
             asm("v_and_b32 %0, 15, %1" : "=v"(ry) : "v"(floor_to_int(iy)));
@@ -321,7 +348,6 @@ __global__ __launch_bounds__(StreamCfg::Threads, 4) void affine_stream_kernel(tr
             f.fx = __builtin_amdgcn_fractf(ix); f.fy = __builtin_amdgcn_fractf(iy); f.fz = __builtin_amdgcn_fractf(iz);
             return f;
         };
-        if (!wave_on) return;                                        // (uniform per wave) a z plane past the volume
         Fetch cur = fetch(0);
 #pragma unroll
         for (int j = 0; j < C::SR; j++) {
@@ -335,29 +361,32 @@ __global__ __launch_bounds__(StreamCfg::Threads, 4) void affine_stream_kernel(tr
         }
     };
 
-    // ---- one step: wait for its rows (everything but the youngest batch), barrier, request the rows of step s + Ahead, gather
-    int last_batch = 0;
+    // ---- one step.  Issue order of a wave:  ... R(s+1) | T(s+1)  [wait: all but these]  barrier  R(s+2) | gather(s) ...
+    //   T(s+1): this thread's target values of the NEXT step into the other register set (needs no barrier),
+    //   wait:   everything older than R(s+1) + T(s+1) has landed, i.e. this wave's share of the rows and its targets of step s,
+    //   R(s+2): rows of step s + 2 into ring slots every wave has left (they were read in step s - 1 at the latest).
+    int nrows_last = 0;            // vector-memory instructions of this wave in R(s + 1)
     auto step = [&](int s, float (&use)[C::SR], float (&load)[C::SR]) {
-        wait_vmcnt(last_batch);
+        issue_targets(s + 1, load);
+        wait_vmcnt(nrows_last + ((TRX_STREAM_DBG & 2) ? 0 : C::SR));
 #pragma unroll
         for (int j = 0; j < C::SR; j++) asm volatile("" : "+v"(use[j]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                             // every wave's pieces of step s are in LDS; everyone has left step s - 1
-        last_batch = issue_rows(s + C::Ahead) + issue_targets(s + C::Ahead, load);
+        __syncthreads();
+        nrows_last = issue_rows(s + C::Ahead);
         gather_step(s, use);
     };
 
-    float tvA[C::SR], tvB[C::SR], tvC[C::SR];   // target values of steps s, s + 1, s + 2 (rotating roles, no copies: three call sites of step)
+    float tvA[C::SR], tvB[C::SR];   // target values of the step being gathered / of the next one (ping-pong: two call sites of step)
 #pragma unroll
-    for (int j = 0; j < C::SR; j++) tvA[j] = tvB[j] = tvC[j] = 0.f;
+    for (int j = 0; j < C::SR; j++) tvA[j] = tvB[j] = 0.f;
 
     int s = s_begin;
     while (s < s_end) {
-        // ---------------- anchor a segment at step s: window origin, zero padding, fill the pipeline (steps s and s + 1)
+        // ---------------- anchor a segment at step s: plan, window origin, zero padding, fill the pipeline (rows of steps s and s + 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                             // nobody gathers from the ring any more, nothing is in flight
-        if (s - chunk0 < 0 || s - chunk0 >= C::Chunk) chunk_geometry(s);
-        bool zero_ring;
+        plan_geometry(s);
         {
             const int xlo = rl(g_xlo, s), xhi = rl(g_xhi, s), zlo = rl(g_zlo, s), zhi = rl(g_zhi, s);
             // leave the window's slack on the side the pre-image drifts to as y grows
@@ -365,54 +394,47 @@ __global__ __launch_bounds__(StreamCfg::Threads, 4) void affine_stream_kernel(tr
             if (ox > (xlo & ~3)) ox = xlo & ~3;
             oz = (sz >= 0.f) ? zlo : zhi - (C::NP - 1);
             if (oz > zlo) oz = zlo;
-            // cells of the window outside the volume are never written by a DMA: they hold the zero padding
-            zero_ring = (ox < 0) || (ox + C::BW > W) || (oz < 0) || (oz + C::NP > D) || (rl(g_rlo, s) < 0);
         }
-        seg_end = s_end;
+        bpb = (int)box_lds - (oz * C::BW + ox) * 4;
+        plan_segment(s);
+        if (seg_end <= s) seg_end = s + 1;                           // (cannot happen while stream_fits holds; never spin)
         m_key = -1;
-        Lrow = -(1 << 28);
-        if (zero_ring) {
+        // cells of the window outside the volume are never written by a DMA: they hold the zero padding
+        if ((ox < 0) || (ox + C::BW > W) || (oz < 0) || (oz + C::NP > D) || (rl(g_rlo, s) < 0)) {
             for (int i = tid; i < C::RingFloats / 4; i += C::Threads) reinterpret_cast<float4 *>(box)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
         }
         issue_rows(s);
         issue_targets(s, tvA);
-        last_batch = issue_rows(s + 1) + issue_targets(s + 1, tvB);
-        if (seg_end <= s) seg_end = s + 1;                           // (cannot happen while stream_fits holds; never spin)
-        // ---------------- the steps of the segment; the target registers rotate A -> B -> C through three call sites
-        int ph = 0;
+        nrows_last = issue_rows(s + 1);
+        // ---------------- the steps of the segment, two per trip (the target registers ping-pong)
         while (s < seg_end) {
-            if (s - chunk0 >= C::Chunk) chunk_geometry(s);           // (the lanes of the old chunk were valid up to step chunk0 + 63 for the loader)
-            if (ph == 0) step(s, tvA, tvC);
-            else if (ph == 1) step(s, tvB, tvA);
-            else step(s, tvC, tvB);
-            ph = (ph == 2) ? 0 : ph + 1;
+            step(s, tvA, tvB);
+            s++;
+            if (s >= seg_end) break;   // odd number of steps: the next anchor reloads the targets into A
+            step(s, tvB, tvA);
             s++;
         }
-        // seg_end < s_end: the window was left; loop back and re-anchor at step s == seg_end
+        // seg_end < s_end: the window was left (or the plan exhausted); loop back and re-anchor at step s == seg_end
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();                                                 // the ring becomes the reduction scratch
 
-    if (!act) {
+    float vals[NP41];
+#pragma unroll
+    for (int i = 0; i < NP41; i++) vals[i] = 0.f;
+    if (act) {
+        vals[0] = acc.M01.x; vals[1] = acc.M01.y; vals[2] = acc.M23.x; vals[3] = acc.M23.y; vals[4] = acc.M4;
+        int o = 5;
 #pragma unroll
         for (int q = 0; q < 3; q++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) acc.AB[q][c] = (f2)(0.f);
-        acc.M01 = acc.M23 = (f2)(0.f);
-        acc.M4 = 0.f;
+            for (int c = 0; c < 3; c++) {
+                const float a = acc.AB[q][c].x;
+                vals[o++] = xn * a; vals[o++] = acc.AB[q][c].y; vals[o++] = zn * a; vals[o++] = a;
+            }
     }
-    float vals[NP41];
-    vals[0] = acc.M01.x; vals[1] = acc.M01.y; vals[2] = acc.M23.x; vals[3] = acc.M23.y; vals[4] = acc.M4;
-    int o = 5;
-#pragma unroll
-    for (int q = 0; q < 3; q++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float a = acc.AB[q][c].x;
-            vals[o++] = xn * a; vals[o++] = acc.AB[q][c].y; vals[o++] = zn * a; vals[o++] = a;
-        }
     block_reduce_store_nw<NP41, C::Waves>(vals, partials + ((size_t)b * rows_per_pair + bx) * NP41, box);
 }
 #pragma clang diagnostic pop

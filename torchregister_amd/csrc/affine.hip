@@ -1207,6 +1207,10 @@ static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const fl
 
 #pragma clang diagnostic pop
 
+#ifdef TRX_EXPERIMENT_STREAM
+#include "../../tools/experiments/affine_stream.h"   // y-streaming F1 kernel: a measured alternative, not part of the library
+#endif
+
 // closed-form base coordinates for callers that pass no tables: (2i+1)/S - 1
 __global__ void fill_tables_kernel(float *__restrict__ tab, int W, int H, int D)
 {
