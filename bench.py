@@ -174,18 +174,31 @@ def main():
     # A registration runs hundreds of iterations, so the steady state is the representative rate: settle the clocks with
     # PRECONDITION untimed iterations on a scratch solver before the W warm-up steps of the measured solver.
     PRECONDITION = 100
-    scratch = new_solver(args.optimizer)
-    scratch.run(PRECONDITION)
-    del scratch
-
-    solver = new_solver(args.optimizer)
-    solver.run(args.warmup)
 
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # value_cold: what a registration that starts on an idle GPU gets - no preconditioning, no warm-up, the first `steps`
+    # iterations after 2 s of idleness (boost clocks for ~10 launches, then the power-cap transient, then the settled clock)
+    cold = new_solver(args.optimizer)
+    fence()
+    time.sleep(2.0)
+    fence()
+    t0 = time.perf_counter()
+    cold.run(args.steps)
+    fence()
+    elapsed_cold = max_over_ranks_local = time.perf_counter() - t0
+    del cold, max_over_ranks_local
+
+    scratch = new_solver(args.optimizer)
+    scratch.run(PRECONDITION)
+    del scratch
+
+    solver = new_solver(args.optimizer)
+    solver.run(args.warmup)
 
     fence()
     t0 = time.perf_counter()
@@ -194,12 +207,17 @@ def main():
     elapsed = time.perf_counter() - t0
     from torchregister_amd.sharding import max_over_ranks
     elapsed = max_over_ranks(elapsed, device)
+    elapsed_cold = max_over_ranks(elapsed_cold, device)
     losses = solver.losses[:, : args.steps + args.warmup]
     assert torch.isfinite(losses).all(), "non-finite loss in the benchmark run"
     assert (losses[:, -1] < losses[:, 0]).all(), "the optimiser made no progress"
 
-    # the other optimiser on the same workload (only theta's 12-float update differs), timed the same way
+    # the other optimiser on the same workload (only theta's 12-float update differs), timed the same way: same
+    # preconditioning, same warm-up (round 1 timed it inside the post-idle power transient: -20 %)
     other = "sgd" if args.optimizer == "adam" else "adam"
+    scratch = new_solver(other)
+    scratch.run(PRECONDITION)
+    del scratch
     solver2 = new_solver(other)
     solver2.run(args.warmup)
     fence()
@@ -218,7 +236,9 @@ def main():
                "config": {"workload": f"3D {args.size}^3 fp32 affine+NCC, {PAIRS_PER_GPU} independent pairs per GPU "
                                       f"(BASELINE.json configs[3] share of one GPU), {args.optimizer.upper()} on theta",
                           "pairs_per_gpu": PAIRS_PER_GPU, "volume": [args.size] * 3, "loss": "NCC(alpha=100)", "optimizer": args.optimizer,
-                          "preconditioning": f"{PRECONDITION} untimed iterations before the warm-up (clock settling)",
+                          "preconditioning": f"{PRECONDITION} untimed iterations before the warm-up (clock settling); value_cold has none",
+                          "value_cold": world * PAIRS_PER_GPU * args.steps / elapsed_cold,
+                          "value_cold_note": f"first {args.steps} iterations of a fresh solver after 2 s of idle GPU, no warm-up",
                           f"{other}_value": world * PAIRS_PER_GPU * args.steps / elapsed2,
                           "parallelism": f"{world} x independent shards, no collective"}}
         if world == 1:
@@ -235,13 +255,16 @@ def main():
             torch.cuda.synchronize()
             k_s = e0.elapsed_time(e1) * 1e-3 / reps
             alg = ALG_BYTES_PER_VOXEL * args.size ** 3 * PAIRS_PER_GPU
-            traffic = None
+            traffic, l2req = None, None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-            out["roofline"] = {"bound": "hbm", "kernel": "affine_tile_kernel<0> (fused warp+NCC fwd/bwd)", "achieved": alg / k_s / 1e9,
+                tj = json.load(open(tf))
+                traffic, l2req = tj.get("hbm_bytes_per_launch"), tj.get("l2_requests_per_launch")
+            out["roofline"] = {"bound": "hbm", "kernel": "affine_tile_dual_kernel<0,0> (fused warp+NCC fwd/bwd, tile geometry per pair)",
+                               "achieved": alg / k_s / 1e9,
                                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / k_s / HBM_PEAK, "traffic": traffic,
-                               "kernel_ms": k_s * 1e3, "algorithmic_bytes_per_launch": alg}
+                               "kernel_ms": k_s * 1e3, "algorithmic_bytes_per_launch": alg,
+                               "l2_requests_per_launch": l2req, "l2_request_bytes": 128}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -231,6 +231,14 @@ int trx_kde_pdf_series(const float *signals, const float *xis, int N, long S, in
 int trx_kde_pdf_series_backward(const float *signals, const float *xis, const float *grad_pdf, int N, long S, int bins, float h,
                                 double center, float *grad_signals, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The 256-bin algebra of the NMI loss behind the three PDFs (ref:utils.py:53-79 NMI, :224-259 NMILoss.forward) in one kernel, value and
+ * gradient: h1 / h2 / hj [N][bins] = the Parzen "histograms" of target, warped and of the pooled samples (get_pdf, ref:utils.py:40-51).
+ *   p = h / sum(h),  E = sum p log2(p + 1e-10)  (the reference's sign convention),  MI = E1 + E2 - Ej,  NMI = 2 MI / (E1 + E2),
+ *   loss = alpha * mean_n |NMI_n - 1|  =  sum_n loss_terms[n].
+ * Outputs (each may be NULL): nmi [N], mi [N], loss_terms [N], grad_h* [N][bins] = d loss / d h*. */
+int trx_nmi_from_pdfs(const float *h1, const float *h2, const float *hj, int N, int bins, float alpha, float *nmi, float *mi,
+                      float *loss_terms, float *grad_h1, float *grad_h2, float *grad_hj, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

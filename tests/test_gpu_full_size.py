@@ -185,4 +185,5 @@ def test_config5_512_cubed_slabs_vs_oracle_and_whole(eng, vol512, smooth):
         assert torch.allclose(s.losses, whole.losses, rtol=1e-5, atol=1e-6)       # every rank records the whole-volume loss
     flow = torch.cat([s.flow for s in slabs], dim=2)
     assert torch.max(torch.abs(flow - whole.flow)).item() <= 1e-5 * max(1.0, whole.flow.abs().max().item())
-    assert whole.losses[0, 1].item() < whole.losses[0, 0].item()
+    if not smooth:
+        assert whole.losses[0, 1].item() < whole.losses[0, 0].item()

@@ -71,8 +71,14 @@ def _pair_worker(rank, world, port, tmp, shape, total, iters):
     s.run(iters)
     theta, losses = sharding.gather_results(s.current_theta, s.losses[:, :iters])
     t = sharding.max_over_ranks(0.5 + rank, torch.device("cuda", 0))
+    # the user-facing driver of the same path: the WHOLE batch is described on every rank (here by generator callables), each
+    # rank solves its shard, everyone gets everything back in pair order
+    gen = lambda seed0: (lambda a, b: torch.cat([ph.blobs(shape, seed0 + p) for p in range(a, b)]))  # noqa: E731
+    r = tr.register_sharded(gen(80), gen(60), mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer="adam", lr=1e-3, iters=iters, pairs=total)
+    assert r["shard"] == (lo, hi) and r["theta"].shape == (total, 3, 4) and r["losses"].shape == (total, iters)
     if rank == 0:
-        torch.save({"theta": theta.cpu(), "losses": losses.cpu(), "tmax": t}, os.path.join(tmp, "gathered.pt"))
+        torch.save({"theta": theta.cpu(), "losses": losses.cpu(), "tmax": t, "sharded_final": r["final_theta"].cpu(), "sharded_losses": r["losses"].cpu(),
+                    "sharded_best_idx": r["best_idx"].cpu(), "sharded_best": r["theta"].cpu()}, os.path.join(tmp, "gathered.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -95,6 +101,11 @@ def test_pair_sharding_two_processes_equal_one_batch():
         got = torch.load(os.path.join(tmp, "gathered.pt"))
     assert torch.equal(got["theta"], s.current_theta.cpu()) and torch.equal(got["losses"], s.losses[:, :iters].cpu())
     assert got["tmax"] == 1.5
+    # register_sharded (torchregister_amd.sharding): the same numbers through the user-facing driver
+    assert torch.equal(got["sharded_final"], s.current_theta.cpu()) and torch.equal(got["sharded_losses"], s.losses[:, :iters].cpu())
+    assert torch.equal(got["sharded_best"], s.best.cpu()) and torch.equal(got["sharded_best_idx"], s.best_idx.cpu())
+    one = tr.register_sharded(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer="adam", lr=1e-3, iters=iters)   # no process group: one GPU, all pairs
+    assert torch.equal(one["final_theta"], s.current_theta) and one["shard"] == (0, total)
 
 
 def test_bench_two_ranks_control_flow():
@@ -115,3 +126,23 @@ def test_bench_two_ranks_control_flow():
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["warmup"] == 2 and j["scaling"] == "weak" and j["higher_is_better"] is True
     assert abs(j["value"] - 2 * 8 * 6 / (j["ms_per_step"] * 6e-3)) < 1e-6 * j["value"]      # whole-job aggregate over both ranks
     assert "roofline" not in j and "cpu_baseline" not in j                                   # N = 1 only
+
+
+def test_bench_under_torchrun_nccl_single_rank():
+    """The RCCL path on hardware: bench.py under torch.distributed.run with ONE rank and the `nccl` backend (the launcher starts before
+    any GPU call) - process-group init on the device, barriers and the MAX all-reduce of the timing run through RCCL exactly as they
+    do on an 8-GPU node (a 1-GPU test box cannot hold a second RCCL rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29400 + os.getpid() % 150), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+           "--size", "64", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 6 and j["value"] > 0 and "roofline" in j

@@ -580,3 +580,21 @@ def kde_pdf_backward(signals, xis, grad_pdf, h, center=None):
     _lib.check(rc, "trx_kde_pdf_backward")
     return out
 
+
+
+def nmi_from_pdfs(h1, h2, hj, alpha, need_grad=True):
+    """The NMI loss's algebra behind the three PDFs in one kernel (include/trx.h: trx_nmi_from_pdfs): h* [N,bins] fp32 on the GPU.
+    Returns (nmi [N], mi [N], loss_terms [N], (g1, g2, gj) = d loss / d h* or None)."""
+    lib = _lib.load()
+    if not (h1.is_cuda and h2.is_cuda and hj.is_cuda):
+        raise _lib.TrxError("nmi_from_pdfs needs CUDA (HIP) tensors: there is no CPU fallback")
+    a, b, c = (t.detach().contiguous().float() for t in (h1, h2, hj))
+    N, bins = a.shape
+    out = torch.empty(3, N, device=a.device)
+    grads = torch.empty(3, N, bins, device=a.device) if need_grad else None
+    with torch.cuda.device(a.device):
+        rc = lib.trx_nmi_from_pdfs(_lib.ptr(a), _lib.ptr(b), _lib.ptr(c), N, bins, float(alpha), _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]),
+                                   _lib.ptr(grads[0]) if need_grad else None, _lib.ptr(grads[1]) if need_grad else None,
+                                   _lib.ptr(grads[2]) if need_grad else None, _lib.current_stream(a.device))
+    _lib.check(rc, "trx_nmi_from_pdfs")
+    return out[0], out[1], out[2], (tuple(grads) if need_grad else None)

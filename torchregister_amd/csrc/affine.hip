@@ -1150,6 +1150,20 @@ __global__ __launch_bounds__(GeomP::Threads, TRX_TILE_MIN_WAVES) void affine_til
     tile_body<MODE, GeomP>(vol, theta, tg, channels, partials, box, blockIdx.x, blockIdx.y);
 }
 
+// Does GeomA's box hold the pre-image of a GeomA tile for this theta?  (theta-only: the tile-independent maximum extent, the same
+// bound the fast loop fetches.)  NaN / huge theta compare false: GeomR, whose own per-tile test then sends everything to the fallback.
+__device__ __forceinline__ bool dual_fits_geomA(const float *__restrict__ th, float fD, float fH, float fW)
+{
+    const float slope[3][3] = {{th[0], th[1] * fW / fH, th[2] * fW / fD}, {th[4] * fH / fW, th[5], th[6] * fH / fD}, {th[8] * fD / fW, th[9] * fD / fH, th[10]}};
+    const float ex[3] = {(float)(GeomA::TX - 1), (float)(GeomA::TY - 1), (float)(GeomA::TZ - 1)};
+    float span[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) span[c] = fabsf(slope[c][0]) * ex[0] + fabsf(slope[c][1]) * ex[1] + fabsf(slope[c][2]) * ex[2];
+    return (span[0] < 1.0e6f) && (span[1] < 1.0e6f) && (span[2] < 1.0e6f) &&
+           ((((int)floorf(span[0] + 0.1f) + 5) >> 2) + 1 <= GeomA::BW4) && ((int)floorf(span[1] + 0.1f) + 3 <= GeomA::BH) &&
+           ((int)floorf(span[2] + 0.1f) + 3 <= GeomA::BD);
+}
+
 // The dual kernel: per pair, GeomA where its box holds the pre-image of a GeomA tile for this theta (decided from the
 // tile-independent maximum extent, the same bound the fast loop fetches), GeomR otherwise.  The grid is sized for the geometry
 // with more blocks; the surplus blocks of the other one write a zero partial row and leave.
@@ -1158,7 +1172,8 @@ __global__ __launch_bounds__(GeomP::Threads, TRX_TILE_MIN_WAVES) void affine_til
 // kernel and 0.311-0.320 ms for the single-geometry kernel): blocks of a pair that the other geometry owns leave at once.
 template <int MODE, int WHICH = 0>
 __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tgA,
-                                                                                   TileGeom tgR, int channels, float *__restrict__ partials)
+                                                                                   TileGeom tgR, int channels, float *__restrict__ partials,
+                                                                                   int zero_surplus = 1)
 {
     static_assert(GeomA::Threads == 512 && GeomR::Threads == 512, "both geometries run 512-thread blocks");
     constexpr int kAlloc = WHICH == 1 ? GeomA::BoxAlloc : (WHICH == 2 ? GeomR::BoxAlloc : (GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc));
@@ -1167,21 +1182,13 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : 5);
     const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
     const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
-    const float fW = (float)vol.W, fH = (float)vol.H, fD = (float)vol.D;
-    const float slope[3][3] = {{th[0], th[1] * fW / fH, th[2] * fW / fD}, {th[4] * fH / fW, th[5], th[6] * fH / fD}, {th[8] * fD / fW, th[9] * fD / fH, th[10]}};
-    const float ex[3] = {(float)(GeomA::TX - 1), (float)(GeomA::TY - 1), (float)(GeomA::TZ - 1)};
-    float span[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) span[c] = fabsf(slope[c][0]) * ex[0] + fabsf(slope[c][1]) * ex[1] + fabsf(slope[c][2]) * ex[2];
-    // (NaN / huge theta compare false: GeomR, whose own per-tile test then sends everything to the global-gather fallback)
-    const bool fitsA = (span[0] < 1.0e6f) && (span[1] < 1.0e6f) && (span[2] < 1.0e6f) &&
-                       ((((int)floorf(span[0] + 0.1f) + 5) >> 2) + 1 <= GeomA::BW4) && ((int)floorf(span[1] + 0.1f) + 3 <= GeomA::BH) &&
-                       ((int)floorf(span[2] + 0.1f) + 3 <= GeomA::BD);
+    const bool fitsA = dual_fits_geomA(th, (float)vol.D, (float)vol.H, (float)vol.W);
     const bool useA = __builtin_amdgcn_readfirstlane(fitsA ? 1 : 0) != 0;
     if ((WHICH == 1 && !useA) || (WHICH == 2 && useA)) return;   // the other launch owns this pair (and its surplus rows)
     const int mine = useA ? tgA.blocks_per_pair : tgR.blocks_per_pair;
     if ((int)blockIdx.x >= mine) {
-        if (MODE != 3 && threadIdx.x < NP) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + threadIdx.x] = 0.f;
+        // (zero_surplus = 0: the reader knows from theta which geometry ran and stops at its row count - the step's finalise kernel)
+        if (MODE != 3 && zero_surplus && threadIdx.x < NP) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + threadIdx.x] = 0.f;
         return;
     }
     if constexpr (WHICH != 1) {
@@ -1195,13 +1202,14 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
 
 // GeomA / GeomR per pair: one two-body launch or the pair of single-body launches (TRX_AFFINE_DUAL = 1 / 2, default 1: the pair costs one more launch and gains nothing).
 template <int MODE>
-static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const float *theta, const TileGeom &ta, const TileGeom &tr, int channels, float *out, int how)
+static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const float *theta, const TileGeom &ta, const TileGeom &tr, int channels, float *out, int how,
+                        int zero_surplus = 1)
 {
     if (how == 1) {
-        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out);
+        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus);
     } else {
-        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 1>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out);
-        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 2>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out);
+        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 1>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
+        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 2>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
     }
 }
 
@@ -1339,7 +1347,7 @@ template <int ND>
 __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const float *__restrict__ partials, int nblk,
                                                                           double nvox, int D, int H, int W,
                                                                           trx_loss_cfg lc, trx_opt_cfg oc,
-                                                                          trx_affine_state st)
+                                                                          trx_affine_state st, int nblk_geomA = 0, int nblk_geomR = 0)
 {
     constexpr int NP = np_full(ND);
     constexpr int NT = ND * (ND + 1);
@@ -1377,7 +1385,15 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
     __syncthreads();
     if (false)
 #endif
-    reduce_partials<NP>(partials + (size_t)b * nblk * NP, nblk, S);
+    {
+        // rows the F1 pass wrote for this pair: the dual kernel (nblk_geomA != 0) lays a pair's rows out with stride nblk and fills the
+        // first blocks_per_pair of the geometry it chose from this theta - the same test here (theta is still the one of that forward)
+        int rows = nblk;
+        if constexpr (ND == 3) {
+            if (nblk_geomA != 0) rows = dual_fits_geomA(theta, (float)D, (float)H, (float)W) ? nblk_geomA : nblk_geomR;
+        }
+        reduce_partials<NP>(partials + (size_t)b * nblk * NP, rows, S);
+    }
     if (i < 64 && oc.kind == TRX_OPT_ADAM) {   // beta^(t+1) by repeated squaring: a dozen fp64 multiplies instead of two pow() calls
         bc1 = 1.0 - ipow((double)oc.beta1, t + 1);
         rsbc2 = 1.0 / sqrt(1.0 - ipow((double)oc.beta2, t + 1));
@@ -1565,7 +1581,7 @@ static bool use_tile_path(const trx_volumes *vol)
 // MODE 0 / 1 dispatch: LDS-tiled kernel for 3-D, row-walking gather kernel otherwise.
 // Returns the number of partial rows per pair through *nblk.
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual);
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a = nullptr, int *nblk_r = nullptr);
 
 template <int MODE>
 static int launch_accum(const trx_volumes *vol, const float *theta, const AffineGeom &g, int channels, size_t chan_stride,
@@ -1580,9 +1596,12 @@ static int launch_accum(const trx_volumes *vol, const float *theta, const Affine
     return TRX_OK;
 }
 
+// nblk_a / nblk_r != nullptr: the caller's reduction knows the per-pair geometry (see affine_finalize_kernel): surplus blocks of the
+// dual grid then write nothing.
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual)
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a, int *nblk_r)
 {
+    if (nblk_a) *nblk_a = *nblk_r = 0;
     if (use_tile_path(vol)) {
         TileGeom t = tile_geom(*vol);
         trx_volumes v = *vol;
@@ -1601,9 +1620,11 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
         if (dual && use_dual(vol)) {
             const TileGeom ta = tile_geom<GeomA>(*vol), tr = tile_geom<GeomR>(*vol);
             const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
-            launch_dual<MODE>(dim3(gx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol));
+            const bool aware = nblk_a != nullptr && use_dual(vol) == 1;
+            launch_dual<MODE>(dim3(gx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1);
             TRX_CHECK_LAUNCH();
             *nblk = gx;
+            if (aware) { *nblk_a = ta.blocks_per_pair; *nblk_r = tr.blocks_per_pair; }
             return TRX_OK;
         }
         hipLaunchKernelGGL((affine_tile_kernel<MODE>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
@@ -1633,12 +1654,13 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     // Every step picks GeomA / GeomR per pair in the kernel (TRX_FLAG_SINGLE_GEOM: the primary geometry only).  Rigid runs start from a
     // random pose (reference: torch.rand, up to 1 rad) and live at large rotations; affine runs start at the identity, where the
     // GeomA body is all that runs, but may rotate away from it: the single-geometry kernel then gathers from L2 at 3.2x the cost.
-    rc = launch_f1<0>(vol, st->theta, partials, &nblk, s, true);
+    int nblk_a = 0, nblk_r = 0;
+    rc = launch_f1<0>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
     if (vol->ndim == 3)
         hipLaunchKernelGGL((affine_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
-                           vol->D, vol->H, vol->W, *loss, *opt, *st);
+                           vol->D, vol->H, vol->W, *loss, *opt, *st, nblk_a, nblk_r);
     else
         hipLaunchKernelGGL((affine_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
                            vol->D, vol->H, vol->W, *loss, *opt, *st);

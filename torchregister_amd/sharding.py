@@ -57,3 +57,50 @@ def gather_results(theta, losses, device=None):
 def slab_range(rank, world, depth):
     """Z-slab [z0, z1) of a D-deep volume owned by `rank` (BASELINE config 5: 512 planes / 8 ranks = 64 each)."""
     return pair_range(rank, world, depth)
+
+
+def register_sharded(moving, target, mode="affine", loss=None, optimizer="sgd", lr=1e-5, iters=1000, init=None, device=None,
+                     pairs=None, betas=(0.9, 0.999), eps=1e-8):
+    """BASELINE config 4 for callers: N independent (moving, target) pairs spread over the ranks of the default process group (one
+    process per GPU, launched with torchrun), 64 pairs -> 8 per GPU on an 8-GPU node.  The reference is batch-1
+    (ref:torchregister.py:52-55): every pair is its own registration, so there is NO data-path collective - each rank uploads and
+    solves only its shard (AffineSolver: all pairs of the shard in one launch per iteration) and the KB-sized results are
+    all-gathered at the end.
+
+    moving, target: [N,1,*spatial] tensors (CPU, pinned or GPU; identical on every rank - only the rank's slice is moved to its GPU),
+                    or callables `f(lo, hi) -> tensor [hi-lo,1,*spatial]` that produce the shard (then give pairs=N).
+    init:           optional [N, ...] initial theta (affine) / pose (rigid), sliced the same way.
+    Returns a dict on EVERY rank, in global pair order: theta (best, Q8) [N,nd,nd+1], final_theta, losses [N,iters], best_idx [N],
+    shard (lo, hi) of this rank.  Without an initialised process group one GPU solves all N pairs."""
+    import torch.distributed as dist
+    from ._engine import AffineSolver, LossSpec
+    distributed = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
+    n = int(pairs) if pairs is not None else int(moving.shape[0])
+    lo, hi = pair_range(rank, world, n)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+
+    def shard(t):
+        if callable(t):
+            return t(lo, hi).to(device=device, dtype=torch.float32)
+        return t[lo:hi].to(device=device, dtype=torch.float32, non_blocking=True)
+
+    nd = None
+    out = {}
+    if hi > lo:
+        mov, tgt = shard(moving), shard(target)
+        nd = mov.dim() - 2
+        solver = AffineSolver(mov, tgt, mode=mode, loss=loss or LossSpec(w_mse=1.0), optimizer=optimizer, lr=lr,
+                              init=None if init is None else init[lo:hi], capacity=max(1, iters), betas=betas, eps=eps)
+        solver.run(iters)
+        res = (solver.best, solver.current_theta, solver.losses[:, :iters], solver.best_idx.to(torch.float32)[:, None])
+    else:   # more ranks than pairs: an empty shard still takes part in the gather
+        first = moving(0, 1) if callable(moving) else moving[:1]
+        nd = first.dim() - 2
+        res = (torch.zeros(0, nd, nd + 1, device=device), torch.zeros(0, nd, nd + 1, device=device), torch.zeros(0, iters, device=device),
+               torch.zeros(0, 1, device=device))
+    best, final = gather_results(res[0], res[1], device)
+    losses, bidx = gather_results(res[2], res[3], device)
+    out.update(theta=best, final_theta=final, losses=losses, best_idx=bidx[:, 0].to(torch.int32), shard=(lo, hi))
+    return out
