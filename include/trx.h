@@ -135,6 +135,11 @@ int trx_affine_warp(const trx_volumes *vol, const float *theta, int channels, fl
 int trx_affine_warp_backward(const trx_volumes *vol, const float *theta, int channels, const float *grad_out,
                              float *dtheta, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Theta (ref:utils.py:287-310: pose vector -> affine matrix, 6 floats in 3-D / 3 in 2-D) and its vector-Jacobian product, for
+ * callers that assemble dL/dtheta themselves: theta_out[B][TRX_PSTRIDE] = Theta(pose[B][TRX_PSTRIDE]) and / or
+ * dpose_out[B][TRX_PSTRIDE] = J(pose)^T dtheta[B][TRX_PSTRIDE] (fp64 inside, as in trx_affine_step's rigid branch). */
+int trx_theta_chain(const float *pose, const float *dtheta, int ndim, int B, float *theta_out, float *dpose_out, void *stream);
+
 /* ------------------------------------------------------------------ dense flow (SpatialTransformer) */
 typedef struct {
     float *flow;        /* [B][ndim][D][H][W] in/out */

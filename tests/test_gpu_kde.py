@@ -69,3 +69,44 @@ def test_nmi_loss_matches_torch_formulation():
     assert abs(got.item() - l64) <= max(1e-5 * abs(l64), 2 * abs(l32 - l64)), (got.item(), l32, l64)
     gmax = g64.abs().max().item()
     assert (ypc.grad.cpu().double() - g64).abs().max().item() <= max(1e-4 * gmax, 2 * (g32 - g64).abs().max().item())
+
+
+@pytest.mark.parametrize("N,bins", [(4, 256), (8, 256), (1, 64), (3, 1000)])
+def test_nmi_algebra_kernel_vs_torch_autograd(N, bins):
+    """trx_nmi_from_pdfs (normalisation, entropies, NMI, alpha * mean|NMI - 1| and d loss / d PDFs in one kernel) against the same
+    algebra written with torch in fp64 (ref:utils.py:62-79, :257-258)."""
+    import torchregister_amd._engine as eng
+    g = torch.Generator().manual_seed(N * 1000 + bins)
+    hs = [(0.05 + torch.rand(N, bins, generator=g)) * (0.5 + torch.rand(N, 1, generator=g)) for _ in range(3)]
+    hs[2] = 0.5 * (hs[0] + hs[1]) * (0.7 + 0.6 * torch.rand(N, bins, generator=g))
+    alpha = 1000.0
+    hd = [h.double().requires_grad_() for h in hs]
+    ps = [h / h.sum(dim=1, keepdim=True) for h in hd]
+    e = [torch.sum(p * torch.log2(p + 1e-10), dim=1) for p in ps]
+    mi = e[0] + e[1] - e[2]
+    nmi = 2 * mi / (e[0] + e[1])
+    loss = torch.mean(torch.abs(nmi - 1.0) * alpha)
+    loss.backward()
+    gn, gm, terms, grads = eng.nmi_from_pdfs(*[h.cuda() for h in hs], alpha)
+    assert np.max(np.abs(gn.cpu().numpy() - nmi.detach().numpy())) <= 2e-6 * np.max(np.abs(nmi.detach().numpy()))
+    assert np.max(np.abs(gm.cpu().numpy() - mi.detach().numpy())) <= 2e-6 * np.max(np.abs(mi.detach().numpy())) + 1e-7
+    assert abs(terms.sum().item() - loss.item()) <= 2e-6 * abs(loss.item())
+    for got, h in zip(grads, hd):
+        ref = h.grad.numpy()
+        assert np.max(np.abs(got.cpu().numpy() - ref)) <= 2e-6 * np.max(np.abs(ref))
+
+
+def test_nmi_loss_caches_the_target_side_only_while_it_is_unchanged():
+    import torchregister_amd.utils as U
+    shape = (48, 48, 48)
+    y, yp = ph.blobs(shape, 5).cuda(), ph.blobs(shape, 6).cuda()
+    crit = U.NMILoss()
+    a = crit(y, yp).item()
+    assert crit._cache.get("ykey") is not None and "h1" in crit._cache
+    b = crit(y, yp).item()                       # second call: the target's patches / extrema / PDF come from the cache
+    assert a == b
+    fresh = U.NMILoss()(y, yp).item()
+    assert a == fresh
+    y.mul_(1.5)                                  # in-place change of the target: the cache must not be used
+    c = crit(y, yp).item()
+    assert c == U.NMILoss()(y, yp).item() and c != a

@@ -284,3 +284,28 @@ def test_readme_pipeline_rigid_affine_flow():
     assert mismatch(warped3) < mismatch(warped2)
     assert tuple(warping.theta.shape) == (1, 3, *shape)          # the flow field, voxel units (ref:README.md:80)
     assert torch.isfinite(tr.norm(torch.abs(warping.theta))).all()
+
+
+@pytest.mark.parametrize("mode,shape", [("affine", (40, 44, 48)), ("rigid", (40, 44, 48)), ("affine", (72, 80)), ("rigid", (72, 80))])
+def test_default_criterion_fast_loop_equals_generic_autograd_loop(tr, monkeypatch, mode, shape):
+    """criterion=None (MSE + NCC + NMI, ref:warpings.py:33-35) runs a dedicated loop without autograd and without a per-iteration host
+    sync (warpings._nmi_affine_loop); it must follow the generic loop (HIP warp as an autograd op + torch NMI algebra + torch SGD,
+    sample lines from .item() extrema like the reference) - loss curve 2e-5 of its maximum, theta 2e-6."""
+    import torchregister_amd.warpings as w
+    nd = len(shape)
+    tgt = ph.blobs(shape, 77).cuda()
+    th = torch.tensor(ph.THETA_STAR3 if nd == 3 else ph.THETA_STAR2)[None].cuda()
+    mov = tr.get_affine_warp(th, tgt) + 0.0
+    init = torch.tensor([0.05, -0.03, 0.04, 0.1, -0.1, 0.05][: 6 if nd == 3 else 3]) if mode == "rigid" else None
+    runs = {}
+    for which in ("fast", "generic"):
+        if which == "generic":
+            monkeypatch.setattr(w, "_nmi_fast_path", lambda *a, **k: None)
+        reg = tr.Register(mode, device="cuda", criterion=None, weight=[0.3, 0.5, 0.2], init=init)
+        reg.optim(mov, tgt, lr=2e-5, max_epochs=8)
+        runs[which] = (reg.losses.detach().flatten().cpu().double().numpy(), reg.final_theta.cpu().double().numpy(), reg.theta.cpu().double().numpy())
+    lf, tf, bf = runs["fast"]
+    lg, tg, bg = runs["generic"]
+    assert len(lf) == len(lg) == 8 and lg[-1] < lg[0]
+    assert np.max(np.abs(lf - lg)) <= 2e-5 * np.max(np.abs(lg)), (lf, lg)
+    assert np.max(np.abs(tf - tg)) <= 2e-6 and np.max(np.abs(bf - bg)) <= 2e-6

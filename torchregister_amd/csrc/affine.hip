@@ -1523,6 +1523,37 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_warp_kernel(trx_volumes vol,
     }
 }
 
+// Theta (ref:utils.py:287-310) and its vector-Jacobian product for callers that assemble dL/dtheta themselves (the default-criterion
+// loop: NMI's gradient arrives outside the fused step): one wave per pair, fp64 like the finalise kernel.
+template <int ND>
+__global__ __launch_bounds__(64) void theta_chain_kernel(const float *__restrict__ pose, const float *__restrict__ dtheta, float *__restrict__ theta_out,
+                                                         float *__restrict__ dpose_out)
+{
+    constexpr int NT = ND * (ND + 1), NPOSE = (ND == 3) ? 6 : 3;
+    const int b = blockIdx.x, i = threadIdx.x;
+    float p[NPOSE];
+#pragma unroll
+    for (int k = 0; k < NPOSE; k++) p[k] = pose[(size_t)b * TRX_PSTRIDE + k];
+    if (theta_out) {
+        double th[NT];
+        theta_from_pose<ND>(p, th);
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < NT; k++) v = (k == i) ? th[k] : v;
+        if (i < NT) theta_out[(size_t)b * TRX_PSTRIDE + i] = (float)v;
+    }
+    if (dtheta && dpose_out) {
+        double g[NT], dx[NPOSE];
+#pragma unroll
+        for (int k = 0; k < NT; k++) g[k] = (double)dtheta[(size_t)b * TRX_PSTRIDE + k];
+        pose_vjp<ND>(p, g, dx);
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPOSE; k++) v = (k == i) ? dx[k] : v;
+        if (i < NPOSE) dpose_out[(size_t)b * TRX_PSTRIDE + i] = (float)v;
+    }
+}
+
 static int check_vol(const trx_volumes *v, bool need_target)
 {
     if (!v || !v->moving || (need_target && !v->target)) return TRX_ERR_ARG;
@@ -1783,6 +1814,17 @@ extern "C" int trx_affine_warp_backward(const trx_volumes *vol, const float *the
         hipLaunchKernelGGL((affine_bwd_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, g.nblk, vol->D, vol->H, vol->W, dtheta);
     else
         hipLaunchKernelGGL((affine_bwd_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, g.nblk, vol->D, vol->H, vol->W, dtheta);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+extern "C" int trx_theta_chain(const float *pose, const float *dtheta, int ndim, int B, float *theta_out, float *dpose_out, void *stream)
+{
+    if (!pose || B < 1 || (!theta_out && !(dtheta && dpose_out))) return TRX_ERR_ARG;
+    if (ndim != 2 && ndim != 3) return TRX_ERR_NDIM;
+    hipStream_t s = (hipStream_t)stream;
+    if (ndim == 3) hipLaunchKernelGGL((theta_chain_kernel<3>), dim3(B), dim3(64), 0, s, pose, dtheta, theta_out, dpose_out);
+    else hipLaunchKernelGGL((theta_chain_kernel<2>), dim3(B), dim3(64), 0, s, pose, dtheta, theta_out, dpose_out);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }

@@ -151,13 +151,48 @@ def get_pdf(data, steps=256, bandwidth=2, value_range=None):
     return PDF(signals, line, h=bandwidth, value_range=(lo, hi))   # the sample line spans exactly the signals' range
 
 
-def NMI(img1, img2, bins=256, bandwidth=0.1):
-    # the six .item() calls of the reference's three get_pdf (ref:utils.py:40-48) as one host sync: the joint sample's extrema are
-    # those of the two images
-    hi1, lo1, hi2, lo2 = torch.stack([img1.detach().amax(), img1.detach().amin(), img2.detach().amax(), img2.detach().amin()]).tolist()
-    h1 = get_pdf(img1, steps=bins, bandwidth=bandwidth, value_range=(hi1, lo1))
+def _nmi_pdfs(img1, img2, bins, bandwidth, cache=None):
+    """The three Parzen "histograms" of NMI (ref:utils.py:55-60).  The six .item() calls of the reference's three get_pdf
+    (ref:utils.py:40-48) are one host sync (the joint sample's extrema are those of the two images).  `cache`: a dict owned by the
+    caller in which the quantities that depend on img1 only (its extrema and PDF) survive from call to call while img1 is the same
+    unmodified tensor - in a registration loop img1 is the fixed target."""
+    key = None
+    if cache is not None and not img1.requires_grad:
+        key = (img1.data_ptr(), img1._version, tuple(img1.shape), int(bins), float(bandwidth))
+    if key is not None and cache.get("key") == key:
+        hi1, lo1, h1 = cache["hi1"], cache["lo1"], cache["h1"]
+        hi2, lo2 = torch.stack([img2.detach().amax(), img2.detach().amin()]).tolist()
+    else:
+        hi1, lo1, hi2, lo2 = torch.stack([img1.detach().amax(), img1.detach().amin(), img2.detach().amax(), img2.detach().amin()]).tolist()
+        h1 = get_pdf(img1, steps=bins, bandwidth=bandwidth, value_range=(hi1, lo1))
+        if key is not None:
+            cache.update(key=key, hi1=hi1, lo1=lo1, h1=h1.detach())
     h2 = get_pdf(img2, steps=bins, bandwidth=bandwidth, value_range=(hi2, lo2))
     hj = get_pdf(torch.stack((img1, img2), dim=1), steps=bins, bandwidth=bandwidth, value_range=(max(hi1, hi2), min(lo1, lo2)))
+    return h1, h2, hj
+
+
+class _NmiAlgebraFn(torch.autograd.Function):
+    """alpha * mean|NMI - 1| from the three PDFs and its gradient wrt them, ONE kernel (trx_nmi_from_pdfs) in place of ~25 torch
+    launches forward and ~40 backward on [N, 256] tensors.  Returns (loss, nmi, mi); only `loss` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, h1, h2, hj, alpha):
+        nmi, mi, terms, grads = _engine.nmi_from_pdfs(h1, h2, hj, alpha, need_grad=True)
+        ctx.save_for_backward(*grads)
+        ctx.mark_non_differentiable(nmi, mi)
+        return terms.sum(), nmi, mi
+
+    @staticmethod
+    def backward(ctx, gl, _gn, _gm):
+        g1, g2, gj = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        return (g1 * gl if need[0] else None), (g2 * gl if need[1] else None), (gj * gl if need[2] else None), None
+
+
+def NMI(img1, img2, bins=256, bandwidth=0.1):
+    """ref:utils.py:53-79: (normalised mutual information, mutual information) per sample of the batch, differentiable."""
+    h1, h2, hj = _nmi_pdfs(img1, img2, bins, bandwidth)
     p1 = h1 / h1.sum(dim=1, keepdim=True)
     p2 = h2 / h2.sum(dim=1, keepdim=True)
     pj = hj / hj.sum(dim=1, keepdim=True)
@@ -170,20 +205,35 @@ def NMI(img1, img2, bins=256, bandwidth=0.1):
 
 
 class NMILoss(nn.Module):
-    """alpha * mean|NMI - 1| on 2^d patches of a nearest-resampled 200^d copy (ref:utils.py:224-259)."""
+    """alpha * mean|NMI - 1| on 2^d patches of a nearest-resampled 200^d copy (ref:utils.py:224-259).  On the GPU the PDFs are HIP
+    kernels (csrc/kde.hip) and everything behind them - normalisation, entropies, NMI, |NMI - 1|, and the backward of all of it - is one
+    more (trx_nmi_from_pdfs); the target's patches and PDF are kept between calls while the target tensor is unchanged."""
 
     def __init__(self, alpha=1000, bins=256, patch_size=100, bandwidth=3):
         super().__init__()
         self.bins, self.alpha, self.patch, self.bandwidth = bins, alpha, patch_size, bandwidth
+        self._cache = {}
+
+    def _patches(self, t):
+        r = self.patch * 2
+        nd = t.dim() - 2
+        t = F.interpolate(t, size=(r,) * nd, mode="nearest")
+        return t.view((2 ** nd) * t.shape[0] * t.shape[1], *([self.patch] * nd))
 
     def forward(self, y, yp):
-        r = self.patch * 2
-        nd = y.dim() - 2
-        y = F.interpolate(y, size=(r,) * nd, mode="nearest")
-        yp = F.interpolate(yp, size=(r,) * nd, mode="nearest")
-        y = y.view((2 ** nd) * y.shape[0] * y.shape[1], *([self.patch] * nd))
-        yp = yp.view((2 ** nd) * yp.shape[0] * yp.shape[1], *([self.patch] * nd))
-        nmi, _ = NMI(y, yp, self.bins, self.bandwidth)
+        fused = y.is_cuda and yp.is_cuda and y.dtype == torch.float32 and self.bins <= 1024
+        if fused and not y.requires_grad:
+            ykey = (y.data_ptr(), y._version, tuple(y.shape))
+            if self._cache.get("ykey") != ykey:
+                self._cache = {"ykey": ykey, "y": self._patches(y)}
+            yq = self._cache["y"]
+        else:
+            yq = self._patches(y)
+        ypq = self._patches(yp)
+        if fused:
+            h1, h2, hj = _nmi_pdfs(yq, ypq, self.bins, self.bandwidth, cache=self._cache)
+            return _NmiAlgebraFn.apply(h1, h2, hj, float(self.alpha))[0]
+        nmi, _ = NMI(yq, ypq, self.bins, self.bandwidth)
         return torch.mean(torch.abs(nmi - 1.0) * self.alpha)
 
 

@@ -12,10 +12,12 @@ Compatibility notes:
   Q6  grad_edges=True crashes in the reference (reflect-pad by 5000 voxels); here it raises.
   Q8  returns [final, best]; "best" = first strict minimum, theta of that forward.
 """
+import ctypes
 import os
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _engine
 from ._engine import AffineSolver, FlowSolver, LossSpec
@@ -139,6 +141,7 @@ def _generic_loop(moving, target, mode, criterions, weights, lr, epochs, init, o
     for _ in range(epochs):
         opt.zero_grad()
         theta = make()
+        theta_fwd = theta.detach().clone()      # the theta of THIS forward (in affine mode `theta` is the parameter itself: the step changes it in place)
         warped = get_affine_warp(theta, moving)
         err = sum(w * c(target, warped) for c, w in rest)
         if fused is not None:
@@ -148,11 +151,120 @@ def _generic_loop(moving, target, mode, criterions, weights, lr, epochs, init, o
         v = err.item()
         losses.append(v)
         if best is None or v < best[0]:
-            best = (v, theta.detach().clone(), warped.detach())
+            best = (v, theta_fwd, warped.detach())
     final_theta = make().detach().clone()
     final_warped = get_affine_warp(final_theta, moving)
     res = dict(losses=torch.tensor(losses), final_theta=final_theta, best_theta=best[1], best_idx=int(torch.tensor(losses).argmin()))
     return [final_warped, best[2]], [final_theta, best[1]], res
+
+
+def _nmi_fast_path(moving, target, criterions, weights, optimizer):
+    """(fused LossSpec, NMILoss, its weight) if the criterion list is fused terms + exactly one NMILoss with a non-zero weight on one pair
+    of fp32 GPU volumes optimised by SGD - the reference's default criterion (ref:warpings.py:33-35: [MSE, NCC, NMI]) - else None."""
+    if optimizer != "sgd" or moving.shape[0] != 1 or moving.shape[1] != 1 or not moving.is_cuda or moving.dtype != torch.float32:
+        return None
+    nmis = [(c, float(w)) for c, w in zip(criterions, weights) if type(c) is NMILoss and float(w) != 0.0]
+    others = [(c, w) for c, w in zip(criterions, weights) if not (type(c) is NMILoss and float(w) != 0.0)]
+    if len(nmis) != 1 or nmis[0][0].bins > 512:
+        return None
+    spec = loss_spec_from([c for c, _ in others], [w for _, w in others]) if others else LossSpec()
+    if spec is None:
+        return None
+    return spec, nmis[0][0], nmis[0][1]
+
+
+def _nmi_affine_loop(moving, target, mode, spec, nmi, w_nmi, lr, epochs, init):
+    """The loop of ref:warpings.py:67-93 / :138-159 for `fused terms + NMI` without autograd and without a host sync per iteration:
+      F1 step (lr = 0) -> loss and d/dtheta of the MSE / NCC / SSD terms;  HIP warp -> the NMI loss's 2^d patches -> Parzen PDFs (one
+      launch for the warped image's PDF and its half of the pooled one: both sample lines as 2 x bins "bins") -> trx_nmi_from_pdfs (loss
+      and d/dPDF) -> one PDF backward -> nearest-upsample backward -> HIP warp backward -> d/dtheta;  SGD on theta (rigid: Theta's
+      vector-Jacobian product, trx_theta_chain).
+    The reference builds each sample line from .item() extrema (ref:utils.py:40-48, two host syncs per PDF); here the extrema stay
+    on the device (torch.lerp between them, the same line to an ulp).  The series form of the PDF kernels needs the window to be at
+    least as wide as the value range: checked ONCE from the extrema of moving and target (a warped value is a convex combination of
+    moving's voxels and the zero padding).  Returns None when that does not hold (the generic loop then runs the exponential kernels)."""
+    from . import _lib
+    nd = moving.dim() - 2
+    dev = moving.device
+    bins, h, patch = int(nmi.bins), float(nmi.bandwidth), int(nmi.patch)
+    lo_m, hi_m, lo_t, hi_t = torch.stack([moving.amin(), moving.amax(), target.amin(), target.amax()]).tolist()     # the one sync, before the loop
+    lo, hi = min(lo_m, lo_t, 0.0), max(hi_m, hi_t, 0.0)
+    if hi - lo > h:
+        return None
+    center = 0.5 * (lo + hi)
+    nt, npose = nd * (nd + 1), (6 if nd == 3 else 3)
+    rigid = mode == "rigid"
+    fused = AffineSolver(moving, target, mode="affine", loss=spec, lr=0.0, capacity=max(1, epochs))
+    lib = fused.lib
+    have_fused = (spec.w_mse != 0.0) or (spec.w_ncc != 0.0) or (spec.w_ssd != 0.0)
+    theta = fused.theta                                    # [1, 12] padded: the theta of the next forward, shared with the F1 solver
+    if rigid:
+        pose = torch.zeros(1, _engine.PSTRIDE, device=dev)
+        pose[0, :npose] = init.to(dev).float().reshape(-1)
+        dpose = torch.zeros_like(pose)
+        _lib.check(lib.trx_theta_chain(_lib.ptr(pose), None, nd, 1, _lib.ptr(theta), None, _lib.current_stream(dev)), "trx_theta_chain")
+    elif init is not None:
+        theta.copy_(_engine.pad_theta(init.to(dev).reshape(1, nd, nd + 1), nd))
+    fused.param.copy_(theta)
+    size = (2 * patch,) * nd
+    npatch = 2 ** nd
+
+    def patches(t):
+        return F.interpolate(t, size=size, mode="nearest").view(npatch, -1)
+
+    yq = patches(target)                                   # fixed target: patches, extrema and PDF once
+    ylo, yhi = torch.aminmax(yq)
+    ramp = (torch.arange(bins, device=dev, dtype=torch.float32) / (bins - 1)).expand(npatch, bins).contiguous()
+    h1 = _engine.kde_pdf(yq, torch.lerp(yhi, ylo, ramp), h, center)
+    hist_loss = torch.zeros(max(1, epochs), device=dev)
+    hist_theta = torch.zeros(max(1, epochs) + 1, _engine.PSTRIDE, device=dev)
+    grad_nmi = torch.zeros(1, _engine.PSTRIDE, device=dev)
+    alpha = float(nmi.alpha) * float(w_nmi)
+    vol = fused.vol
+    ws, ws_bytes = fused.workspace, fused.ws_bytes
+    stream = _lib.current_stream(dev)
+    for t in range(epochs):
+        hist_theta[t].copy_(theta[0])
+        if have_fused:
+            fused.run(1)                                   # loss_f -> fused.losses[0, t], d/dtheta -> fused.grad (theta untouched: lr = 0)
+        warped = torch.empty_like(moving)
+        _lib.check(lib.trx_affine_warp(ctypes.byref(vol), _lib.ptr(theta), 1, _lib.ptr(warped), stream), "trx_affine_warp")
+        warped.requires_grad_()
+        with torch.enable_grad():
+            up = F.interpolate(warped, size=size, mode="nearest")
+        ypq = up.detach().view(npatch, -1)
+        plo, phi = torch.aminmax(ypq)
+        xis = torch.cat([torch.lerp(phi, plo, ramp), torch.lerp(torch.maximum(phi, yhi), torch.minimum(plo, ylo), ramp)], dim=1)   # [P, 2 bins]
+        pdf = _engine.kde_pdf(ypq, xis, h, center)          # warped: its own PDF | its half of the pooled PDF
+        hj = 0.5 * (pdf[:, bins:] + _engine.kde_pdf(yq, xis[:, bins:].contiguous(), h, center))
+        _, _, terms, (_, g2, gj) = _engine.nmi_from_pdfs(h1, pdf[:, :bins], hj, alpha)
+        gs = _engine.kde_pdf_backward(ypq, xis, torch.cat([g2, 0.5 * gj], dim=1), h, center)
+        (gw,) = torch.autograd.grad(up, warped, gs.view_as(up))
+        _lib.check(lib.trx_affine_warp_backward(ctypes.byref(vol), _lib.ptr(theta), 1, _lib.ptr(gw), _lib.ptr(grad_nmi), _lib.ptr(ws), ws_bytes, stream),
+                   "trx_affine_warp_backward")
+        total = terms.sum()
+        g = grad_nmi
+        if have_fused:
+            total = total + fused.losses[0, t]
+            g = g + fused.grad
+        hist_loss[t] = total
+        if rigid:
+            _lib.check(lib.trx_theta_chain(_lib.ptr(pose), _lib.ptr(g), nd, 1, None, _lib.ptr(dpose), stream), "trx_theta_chain")
+            pose.sub_(dpose, alpha=lr)
+            _lib.check(lib.trx_theta_chain(_lib.ptr(pose), None, nd, 1, _lib.ptr(theta), None, stream), "trx_theta_chain")
+        else:
+            theta.sub_(g, alpha=lr)
+        fused.param.copy_(theta)
+    hist_theta[epochs].copy_(theta[0])
+    unpad = lambda v: v[:nt].reshape(1, nd, nd + 1).clone()  # noqa: E731
+    final_theta = unpad(hist_theta[epochs])
+    if epochs == 0:
+        best_idx, best_theta = 0, final_theta.clone()
+    else:
+        best_idx = int(torch.argmin(hist_loss[:epochs]))     # first minimum = first strict improvement (Q8); the loop's only other sync
+        best_theta = unpad(hist_theta[best_idx])
+    res = dict(losses=hist_loss[:epochs].clone(), final_theta=final_theta, best_theta=best_theta, best_idx=best_idx)
+    return [get_affine_warp(final_theta, moving), get_affine_warp(best_theta, moving)], [final_theta, best_theta], res
 
 
 def _affine_family(mode, moving, target, lr, epochs, device, debug, criterions, weights, grad_edges, honor_criterion,
@@ -166,7 +278,11 @@ def _affine_family(mode, moving, target, lr, epochs, device, debug, criterions, 
         init = torch.rand((6 if nd == 3 else 3), device=moving.device)      # ref:utils.py:316-321 (Q9)
     spec = loss_spec_from(criterions, weights)
     if spec is None:
-        warped, theta, res = _generic_loop(moving, target, mode, criterions, weights, lr, epochs, init, optimizer)
+        out = None
+        fast = _nmi_fast_path(moving, target, criterions, weights, optimizer)
+        if fast is not None:
+            out = _nmi_affine_loop(moving, target, mode, fast[0], fast[1], fast[2], lr, epochs, init)
+        warped, theta, res = out if out is not None else _generic_loop(moving, target, mode, criterions, weights, lr, epochs, init, optimizer)
     else:
         B = moving.shape[0]
         init_b = None if init is None else (init.reshape(1, -1).expand(B, -1) if mode == "rigid" else init.reshape(-1, nd, nd + 1).expand(B, nd, nd + 1))
