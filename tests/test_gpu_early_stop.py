@@ -179,7 +179,10 @@ def test_flow_register_direct_stops_like_the_reference_loop(shape):
 
 
 def test_flow_register_unet_stops_like_the_reference_loop():
-    """flow_model='unet' (the reference's model): the loop is the reference's own (host-side test after every step)."""
+    """flow_model='unet' (the reference's model): the loop is the reference's own (host-side test after every step).  Two same-seed GPU
+    runs of the U-Net are not bit-reproducible (MIOpen's convolution backward), so the checks are self-consistent ones: a run stops at
+    the first of ITS OWN recorded losses that is <= stop_crit, never earlier, never later; `.flow` is the flow of the last forward (the
+    weights have moved since)."""
     import torchregister_amd as tr
     shape = (160, 160)
     mov, tgt = _pair(shape)
@@ -192,17 +195,13 @@ def test_flow_register_unet_stops_like_the_reference_loop():
 
     probe = run(6, -1.0)
     L = probe.losses[0].cpu().numpy().astype(np.float64)
-    k = int(np.argmin(L[:5]))
-    if k == 0:
-        pytest.skip("the first loss is the minimum of this seed: no mid-run threshold to place")
-    crit = float(L[k]) * (1 + 1e-4)
-    first = int(np.nonzero(L <= crit)[0][0])
+    assert len(L) == 6                                           # never
+    assert run(6, 1e9).losses.shape[1] == 1                      # at once: one forward, one step, stop
+    crit = float(np.sort(L)[2])                                  # somewhere inside the curve's range
     fr = run(6, crit)
-    assert fr.losses.shape[1] == first + 1
-    replay = run(first + 1, -1.0)                       # the same run cut after the same number of iterations
-    # (MIOpen's convolution backward is not bit-reproducible from run to run and the random-init U-Net amplifies that: two
-    #  same-seed runs of this model differ by ~2 % of the flow's range after a few iterations, measured)
-    assert torch.max(torch.abs(fr.flow - replay.flow)).item() <= 0.1 * max(1e-3, replay.flow.abs().max().item())
+    mine = fr.losses[0].cpu().numpy()
+    assert 1 <= len(mine) <= 6
+    assert np.all(mine[:-1] > crit) and (mine[-1] <= crit or len(mine) == 6)
     with torch.no_grad():
         assert not torch.allclose(fr.flow, fr.model.features(mov), atol=1e-7)   # the weights moved after the last forward
 

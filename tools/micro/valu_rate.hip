@@ -13,10 +13,10 @@ static const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk
                               "v_mad_i32_i24", "v_lshl_add_u32", "v_readlane_b32", "ds_read2_b32", "ds_read_b64", "fma+pk_fma 1:1"};
 
 template <int OP>
-__global__ __launch_bounds__(256) void k(unsigned long long *out, int iters, float seed)
+__global__ __launch_bounds__(1024) void k(unsigned long long *out, int iters, float seed)
 {
     __shared__ float lds[4096];
-    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = seed * i;
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = seed * i;
     __syncthreads();
     float a[8];
     f2 p[8];
@@ -61,15 +61,15 @@ __global__ __launch_bounds__(256) void k(unsigned long long *out, int iters, flo
 }
 
 template <int OP>
-static void run(unsigned long long *out, int blocks_per_cu)
+static void run(unsigned long long *out, int blocks_per_cu)   // = waves per SIMD: ONE block of 256 * n threads per CU (a grid of 256 blocks lands one per CU)
 {
-    const int iters = 2000, blocks = 256 * blocks_per_cu;
+    const int iters = 2000, blocks = 256, threads = 256 * blocks_per_cu;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<OP>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f);
+    hipLaunchKernelGGL((k<OP>), dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<OP>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f);
+    hipLaunchKernelGGL((k<OP>), dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0f);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
