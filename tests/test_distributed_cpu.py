@@ -69,3 +69,43 @@ def test_single_process_identity():
     assert sharding.max_over_ranks(3.5) == 3.5
     a, b = sharding.gather_results(torch.ones(2, 3, 4), torch.zeros(2, 7))
     assert a.shape == (2, 3, 4) and b.shape == (2, 7)
+
+
+def _subgroup_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from torchregister_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    groups = [dist.new_group([0, 1]), dist.new_group([2, 3])]     # two independent slab partitions in one job; the second starts at global rank 2
+    g = groups[rank // 2]
+    below, above = sharding.neighbour_global_ranks(g)
+    # the halo exchange of SlabFlowSolver.exchange_halos with these peers: every rank sends its global rank as the "boundary plane"
+    mine = torch.full((4,), float(rank))
+    got_lo, got_hi = torch.full((4,), -1.0), torch.full((4,), -1.0)
+    ops = []
+    if below is not None:
+        ops += [dist.P2POp(dist.isend, mine, below, g), dist.P2POp(dist.irecv, got_lo, below, g)]
+    if above is not None:
+        ops += [dist.P2POp(dist.isend, mine, above, g), dist.P2POp(dist.irecv, got_hi, above, g)]
+    for r in dist.batch_isend_irecv(ops):
+        r.wait()
+    q.put((rank, below, above, got_lo[0].item(), got_hi[0].item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_neighbours_inside_a_subgroup_gloo():
+    """P2POp peers are GLOBAL ranks.  Four ranks, two sub-groups {0,1} and {2,3}: inside the second one the lower slab is
+    global rank 2 and its upper neighbour global rank 3 (group ranks 0 and 1) - the planes must travel between exactly those."""
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, None, 1, -1.0, 1.0), (1, 0, None, 0.0, -1.0), (2, None, 3, -1.0, 3.0), (3, 2, None, 2.0, -1.0)]

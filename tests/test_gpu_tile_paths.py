@@ -220,3 +220,28 @@ def test_straddling_float4_moves_between_tiles(eng):
                                                      oracle.base_tables(shape, np.float64))
         assert abs(s.losses[0, 0].item() - total) <= 2e-5 * max(1.0, abs(total))
         assert np.max(np.abs(s.grad[0, :12].cpu().numpy().reshape(3, 4) - dth)) <= 2e-4 * np.max(np.abs(dth))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_identity_gradient_same_on_every_path(eng, shape):
+    """At theta = identity every sample sits exactly on a voxel: the trilinear derivative is one-sided there and the side is decided by
+    the last bit of the un-normalised coordinate, so the C oracle (fp64) is no arbiter (test_f1_step_vs_oracle checks the loss only).
+    All kernels of the library reproduce ATen's coordinate arithmetic bit for bit at the identity (trx_common.h: unnorm<ND>, the
+    host-built base tables), so they take the SAME side: the gradient of the tiled kernels (GeomA through the dual kernel, the
+    single-geometry kernel) and of the un-tiled row-walking kernel must agree to fp32 summation error - and the small identity fixtures
+    ID3 / ID2 (test_gpu_affine.py) pin that common value to the reference's own autograd result."""
+    from torchregister_amd import _lib
+    tgt = ph.blobs(shape, 77)
+    mov = ph.blobs(shape, 78) + 0.1 * ph.vol(shape, 0.013, "sin")
+    th = torch.eye(3, 4)[None]
+    grads, losses = [], []
+    for flags in (0, _lib.FLAG_SINGLE_GEOM, _lib.FLAG_GATHER_PATH):
+        s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(w_ncc=1.0, w_mse=0.5), lr=0.0, init=th, capacity=1, flags=flags)
+        s.run(1)
+        torch.cuda.synchronize()
+        grads.append(s.grad[0, :12].cpu().double().numpy())
+        losses.append(s.losses[0, 0].item())
+    gmax = np.max(np.abs(grads[2]))
+    for g, l in zip(grads[:2], losses[:2]):
+        assert abs(l - losses[2]) <= 2e-6 * max(1.0, abs(losses[2]))
+        assert np.max(np.abs(g - grads[2])) <= 2e-5 * gmax, (g, grads[2])

@@ -446,15 +446,14 @@ class SlabFlowSolver:
         import torch.distributed as dist
         if not self.smooth or not (dist.is_available() and dist.is_initialized()):
             return
-        rank = dist.get_rank(self.group) if rank is None else rank   # rank INSIDE the group = position of the slab along Z
-        # P2POp takes GLOBAL ranks: translate the group-relative neighbours (a sub-group need not start at global rank 0)
-        peer = (lambda r: r) if self.group is None else (lambda r: dist.get_global_rank(self.group, r))
+        from .sharding import neighbour_global_ranks
+        below, above = neighbour_global_ranks(self.group)           # P2POp takes GLOBAL ranks; a sub-group need not start at global rank 0
         lo, hi = self.boundary_planes()
         ops = []
         if self.has_lo:
-            ops += [dist.P2POp(dist.isend, lo, peer(rank - 1), self.group), dist.P2POp(dist.irecv, self.halo_lo, peer(rank - 1), self.group)]
+            ops += [dist.P2POp(dist.isend, lo, below, self.group), dist.P2POp(dist.irecv, self.halo_lo, below, self.group)]
         if self.has_hi:
-            ops += [dist.P2POp(dist.isend, hi, peer(rank + 1), self.group), dist.P2POp(dist.irecv, self.halo_hi, peer(rank + 1), self.group)]
+            ops += [dist.P2POp(dist.isend, hi, above, self.group), dist.P2POp(dist.irecv, self.halo_hi, above, self.group)]
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()

@@ -59,6 +59,15 @@ def slab_range(rank, world, depth):
     return pair_range(rank, world, depth)
 
 
+def neighbour_global_ranks(group=None):
+    """(lower, upper) Z neighbours of this rank inside `group` as GLOBAL ranks (None at the ends): torch.distributed.P2POp addresses
+    peers by global rank, the position of a slab along Z is the rank inside the group."""
+    import torch.distributed as dist
+    r, n = dist.get_rank(group), dist.get_world_size(group)
+    to_global = (lambda k: k) if group is None else (lambda k: dist.get_global_rank(group, k))
+    return (to_global(r - 1) if r > 0 else None), (to_global(r + 1) if r + 1 < n else None)
+
+
 def register_sharded(moving, target, mode="affine", loss=None, optimizer="sgd", lr=1e-5, iters=1000, init=None, device=None,
                      pairs=None, betas=(0.9, 0.999), eps=1e-8):
     """BASELINE config 4 for callers: N independent (moving, target) pairs spread over the ranks of the default process group (one
