@@ -43,6 +43,7 @@ static AffineGeom affine_geom(const trx_volumes &v, int target_blocks_total)
 }
 
 constexpr int np_full(int nd) { return 5 + 3 * nd * (nd + 1); }
+constexpr int kNpMse = 13;   // partial-row layout of the MSE / SSD-only step kernel (3-D): sum d^2, then 12 x sum(d J)
 
 // MODE 0: moments + sum(qJ), q in {1,y,w}   (the optimiser step)
 // MODE 1: moments only                       (loss evaluation)
@@ -354,6 +355,17 @@ __device__ __forceinline__ void f1_accumulate_pk(const Samp3 &sm, float yv, floa
         }
         return;
     }
+    if constexpr (MODE == 4) {   // MSE / SSD only (no NCC term): d = w - y carries everything - sum d^2 and sum(d * grad), sum(d * grad * yn)
+        const float d = sm.v - yv;
+        a.M4 = fmaf(d, d, a.M4);
+        const float gq[3] = {sm.dx, sm.dy, sm.dz};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const f2 gu = {gq[c], yn * gq[c]};
+            a.AB[0][c] = gu * d + a.AB[0][c];
+        }
+        return;
+    }
     const f2 yw = {yv, sm.v};
     a.M01 += yw;
     a.M23 = yw * yw + a.M23;
@@ -444,9 +456,12 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
     (void)kNH; (void)kBD; (void)kPlaneSlots;
     // MODE 0: F1 sums, MODE 1: moments only, MODE 2: generic warp backward (`vol.target` = grad_out [B][channels][D][H][W],
     // 12 sums per (pair, channel)), MODE 3: forward warp (writes the warped volume to `partials` = out[B][channels][D][H][W])
-    constexpr int NQ = (MODE == 0) ? 3 : (MODE == 2 ? 1 : 0);
-    constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : 5);
-    constexpr bool kGrad = (MODE == 0) || (MODE == 2);
+    // MODE 4: the step kernel for losses without an NCC term (MSE and / or SSD - what the reference's rigid / affine drivers always run,
+    // SURVEY Q2): 13 sums per block (sum d^2, 12 x sum d J with d = warped - target) instead of 41, 8 accumulation instructions per
+    // voxel instead of 15
+    constexpr int NQ = (MODE == 0) ? 3 : ((MODE == 2 || MODE == 4) ? 1 : 0);
+    constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : (MODE == 4 ? kNpMse : 5));
+    constexpr bool kGrad = (MODE == 0) || (MODE == 2) || (MODE == 4);
     constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);   // blockIdx.y enumerates (pair, channel); channels share theta
     const int b = kPerChannel ? by / channels : by;
     const int ch = kPerChannel ? by - b * channels : 0;
@@ -1123,7 +1138,10 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
     if constexpr (MODE == 3) return;
     float vals[NP];
     int o = 0;
-    if constexpr (MODE != 2) {
+    if constexpr (MODE == 4) {
+        vals[0] = acc.M4;
+        o = 1;
+    } else if constexpr (MODE != 2) {
         vals[0] = acc.M01.x; vals[1] = acc.M01.y; vals[2] = acc.M23.x; vals[3] = acc.M23.y; vals[4] = acc.M4;
         o = 5;
     }
@@ -1179,7 +1197,7 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     constexpr int kAlloc = WHICH == 1 ? GeomA::BoxAlloc : (WHICH == 2 ? GeomR::BoxAlloc : (GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc));
     __shared__ __attribute__((aligned(16))) float box[kAlloc];
     constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);
-    constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : 5);
+    constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : (MODE == 4 ? kNpMse : 5));
     const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
     const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
     const bool fitsA = dual_fits_geomA(th, (float)vol.D, (float)vol.H, (float)vol.W);
@@ -1347,7 +1365,7 @@ template <int ND>
 __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const float *__restrict__ partials, int nblk,
                                                                           double nvox, int D, int H, int W,
                                                                           trx_loss_cfg lc, trx_opt_cfg oc,
-                                                                          trx_affine_state st, int nblk_geomA = 0, int nblk_geomR = 0)
+                                                                          trx_affine_state st, int nblk_geomA = 0, int nblk_geomR = 0, int mse_rows = 0)
 {
     constexpr int NP = np_full(ND);
     constexpr int NT = ND * (ND + 1);
@@ -1392,7 +1410,8 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
         if constexpr (ND == 3) {
             if (nblk_geomA != 0) rows = dual_fits_geomA(theta, (float)D, (float)H, (float)W) ? nblk_geomA : nblk_geomR;
         }
-        reduce_partials<NP>(partials + (size_t)b * nblk * NP, rows, S);
+        if (ND == 3 && mse_rows) reduce_partials<kNpMse>(partials + (size_t)b * nblk * kNpMse, rows, S);   // rows of the MSE / SSD-only step kernel
+        else reduce_partials<NP>(partials + (size_t)b * nblk * NP, rows, S);
     }
     if (i < 64 && oc.kind == TRX_OPT_ADAM) {   // beta^(t+1) by repeated squaring: a dozen fp64 multiplies instead of two pow() calls
         bc1 = 1.0 - ipow((double)oc.beta1, t + 1);
@@ -1404,10 +1423,18 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
     return;
 #endif
 
-    const LossCoef L = loss_from_moments(S, nvox, lc);
     const double scale[3] = {0.5 * W, 0.5 * H, 0.5 * D};
-    const double dth_i = scale[ic / (ND + 1)] * (L.c0 * S[5 + ic] + L.cy * S[5 + NT + ic] + L.cw * S[5 + 2 * NT + ic]);
-    const float lossf = (float)L.total;
+    double dth_i, total;
+    if (ND == 3 && mse_rows) {   // S[0] = sum (w - y)^2, S[1 + i] = sum (w - y) J_i:  L = (w_mse / n + w_ssd alpha) S[0],  dL/dw_p = q (w_p - y_p)
+        const double q = (double)lc.w_mse * 2.0 / nvox + (double)lc.w_ssd * (double)lc.ssd_alpha * 2.0;
+        total = 0.5 * q * S[0];
+        dth_i = scale[ic / (ND + 1)] * q * S[1 + ic];
+    } else {
+        const LossCoef L = loss_from_moments(S, nvox, lc);
+        total = L.total;
+        dth_i = scale[ic / (ND + 1)] * (L.c0 * S[5 + ic] + L.cy * S[5 + NT + ic] + L.cw * S[5 + 2 * NT + ic]);
+    }
+    const float lossf = (float)total;
     // best = first strict minimum, theta of THIS forward (ref:warpings.py:85-93)
     const bool is_best = (t == 0) || (lossf < best_prev);
     if (is_best && i < NT) st.best_theta[(size_t)b * TRX_PSTRIDE + i] = theta_old;
@@ -1663,9 +1690,13 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
         *nblk = t.blocks_per_pair;
         return TRX_OK;
     }
-    AffineGeom g = affine_geom(*vol, kTargetBlocks);
-    *nblk = g.nblk;
-    return launch_accum<MODE>(vol, theta, g, 1, 0, partials, s);
+    if constexpr (MODE == 4) {
+        return TRX_ERR_ARG;   // (the MSE-only rows exist in the tile kernels only; trx_affine_step asks for them on the tile path)
+    } else {
+        AffineGeom g = affine_geom(*vol, kTargetBlocks);
+        *nblk = g.nblk;
+        return launch_accum<MODE>(vol, theta, g, 1, 0, partials, s);
+    }
 }
 
 extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
@@ -1686,12 +1717,15 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     // random pose (reference: torch.rand, up to 1 rad) and live at large rotations; affine runs start at the identity, where the
     // GeomA body is all that runs, but may rotate away from it: the single-geometry kernel then gathers from L2 at 3.2x the cost.
     int nblk_a = 0, nblk_r = 0;
-    rc = launch_f1<0>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r);
+    // without an NCC term only d = warped - target matters: the step kernel then keeps 13 sums instead of 41 (3-D tile path)
+    const bool mse_only = (loss->w_ncc == 0.f) && use_tile_path(vol);
+    rc = mse_only ? launch_f1<4>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r)
+                  : launch_f1<0>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
     if (vol->ndim == 3)
         hipLaunchKernelGGL((affine_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
-                           vol->D, vol->H, vol->W, *loss, *opt, *st, nblk_a, nblk_r);
+                           vol->D, vol->H, vol->W, *loss, *opt, *st, nblk_a, nblk_r, mse_only ? 1 : 0);
     else
         hipLaunchKernelGGL((affine_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
                            vol->D, vol->H, vol->W, *loss, *opt, *st);
