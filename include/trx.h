@@ -194,6 +194,10 @@ int trx_flow_slab_moments(const trx_volumes *vol, int z_offset, int D_full, cons
 int trx_flow_slab_update(const trx_volumes *vol, int z_offset, int D_full, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
                          const trx_flow_state *st, const double *global_moments, const float *halo_lo, const float *halo_hi,
                          void *workspace, size_t workspace_bytes, void *stream);
+/* The cross-slab part of trx_flow_slab_moments' smoothness sums on its own: sum over the slab's top plane of (halo_hi - flow)^2, added to
+ * moments[b][5].  trx_flow_slab_moments(..., halo_hi = NULL, ...) followed by this equals trx_flow_slab_moments with the halo - and lets
+ * the first run while the neighbour's plane is still travelling over xGMI (SlabFlowSolver.run puts the exchange on a side stream). */
+int trx_flow_slab_boundary_smooth(const trx_volumes *vol, const float *flow, const float *halo_hi, double *moments, void *stream);
 /* Without the smoothness term (3-D): the update that also leaves the slab's block partials of the UPDATED flow in the workspace, and the
  * reduction of those partials to the 8 sums - together they replace trx_flow_slab_moments from the second iteration on (one pass over
  * the slab per iteration instead of two; same numbers). */

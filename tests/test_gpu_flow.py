@@ -233,3 +233,23 @@ def test_slab_partition_equals_whole_volume(eng, optimizer, lr, smooth):
     torch.cuda.synchronize()
     assert torch.allclose(one.losses, whole.losses, rtol=1e-6, atol=1e-7)
     assert torch.allclose(one.flow, whole.flow, atol=1e-6)
+
+
+def test_slab_boundary_smooth_term_split(eng):
+    """Pass A with the upper neighbour's plane == pass A without it + trx_flow_slab_boundary_smooth (the split that lets the halo
+    exchange run on a side stream beside pass A, SlabFlowSolver.run)."""
+    shape = (20, 28, 36)
+    tgt, mov = ph.blobs(shape, 31).cuda(), ph.blobs(shape, 32).cuda()
+    kw = dict(loss=eng.LossSpec(w_ncc=1.0), optimizer="sgd", lr=1.0, capacity=2, smooth_weight=2.0)
+    lo = eng.SlabFlowSolver(mov, tgt[:, :, :12].contiguous(), 0, **kw)
+    fl = (0.7 * ph.flow_field(shape, 1.0, 0.05)).cuda()
+    lo.flow.copy_(fl[:, :, :12])
+    lo.halo_hi.copy_(fl[0, :, 12])                      # what the rank above would send: its lowest plane
+    with_halo = lo.local_moments().clone()
+    without = lo.local_moments_without_halo().clone()
+    lo.add_boundary_smooth(without)
+    torch.cuda.synchronize()
+    assert not torch.equal(with_halo[0, 5], lo.local_moments_without_halo()[0, 5])      # the term is not zero
+    assert torch.allclose(with_halo, without, rtol=2e-6, atol=0)        # (pass A carries the term in fp32 block partials, the small kernel in fp64)
+    edge = ((fl[0, :, 12] - fl[0, :, 11]).double() ** 2).sum().item()
+    assert abs((with_halo[0, 5] - lo.local_moments_without_halo()[0, 5]).item() - edge) <= 1e-6 * edge

@@ -495,16 +495,52 @@ class SlabFlowSolver:
         if self.smooth:
             self.flow, self.flow_tmp = self.flow_tmp, self.flow   # the update was written to the other buffer
 
+    def local_moments_without_halo(self):
+        """Pass A with the cross-slab smoothness term left out (it needs the upper neighbour's plane): self.moments."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.trx_flow_slab_moments(ctypes.byref(self.vol), self.z_offset, self.D_full, _lib.ptr(self.flow), int(bool(self.smooth)),
+                                                None, _lib.ptr(self.moments), _lib.ptr(self.workspace), self.ws_bytes, _lib.current_stream(self.device))
+        _lib.check(rc, "trx_flow_slab_moments")
+        return self.moments
+
+    def add_boundary_smooth(self, moments):
+        """Adds the cross-slab smoothness term (top plane against halo_hi) to `moments` ([1,8] fp64), on the current stream."""
+        if not (self.smooth and self.has_hi):
+            return
+        with torch.cuda.device(self.device):
+            rc = self.lib.trx_flow_slab_boundary_smooth(ctypes.byref(self.vol), _lib.ptr(self.flow), _lib.ptr(self.halo_hi), _lib.ptr(moments),
+                                                        _lib.current_stream(self.device))
+        _lib.check(rc, "trx_flow_slab_boundary_smooth")
+
     def run(self, iters):
+        """`iters` iterations.  With more than one rank and the smoothness term, the exchange of the boundary flow planes with the Z
+        neighbours (P2P over xGMI, 3 MB per face at 512^2) runs on a side stream while pass A covers the slab: pass A leaves the one
+        term that needs the neighbour's plane to a small kernel behind the exchange (trx_flow_slab_boundary_smooth).  The 64-byte
+        all-reduce of the sums stays between pass A and pass B, where the algorithm needs it."""
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         if self.enqueued + int(iters) > self.capacity:
             raise _lib.TrxError(f"loss-curve capacity exceeded: {self.enqueued} + {int(iters)} > {self.capacity}")
         self.enqueued += int(iters)
+        overlap = multi and bool(self.smooth)
+        if overlap and getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._edge = torch.zeros(1, 8, dtype=torch.float64, device=self.device)
+        main = torch.cuda.current_stream(self.device)
         for _ in range(int(iters)):
-            if multi:
-                self.exchange_halos()
-            m = self.local_moments()
+            if overlap:
+                self._side.wait_stream(main)                 # the previous update has produced the planes to send
+                with torch.cuda.stream(self._side):
+                    self.exchange_halos()
+                    self._edge.zero_()
+                    self.add_boundary_smooth(self._edge)
+                m = self.local_moments_without_halo()        # main stream: the whole slab, no halo needed
+                main.wait_stream(self._side)
+                m += self._edge
+            else:
+                if multi:
+                    self.exchange_halos()
+                m = self.local_moments()
             if multi:
                 dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.group)   # 64 bytes per iteration
             self.apply(m)

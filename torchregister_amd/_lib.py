@@ -80,6 +80,7 @@ SIGNATURES = {
     "trx_flow_run": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.POINTER(LossCfg), ctypes.POINTER(OptCfg),
                                     ctypes.POINTER(FlowState), ctypes.c_int, _P, ctypes.c_size_t, _P]),
     "trx_flow_slab_moments": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, ctypes.c_size_t, _P]),
+    "trx_flow_slab_boundary_smooth": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, _P, _P, _P]),
     "trx_flow_slab_update": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, ctypes.POINTER(LossCfg),
                                             ctypes.POINTER(OptCfg), ctypes.POINTER(FlowState), _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_flow_slab_update_fused": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, ctypes.POINTER(LossCfg),

@@ -457,6 +457,41 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_warp_bwd_kernel(trx_volumes vo
     }
 }
 
+// Z-slab mode: the one term of pass A that needs a neighbour rank's data - the squared forward differences across the slab's upper
+// face, sum_c sum_{y,x} (halo_hi[c][y][x] - flow[c][D-1][y][x])^2 - as its own small kernel, so that pass A proper (called without a halo)
+// can run while the halo planes are still travelling.  One block, fixed summation order (fp64), added to moments[b][5].
+__global__ __launch_bounds__(1024) void slab_boundary_smooth_kernel(const float *__restrict__ flow, const float *__restrict__ halo_hi, int D, int H, int W,
+                                                                    double *__restrict__ moments)
+{
+    __shared__ double red[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const size_t plane = (size_t)H * W, nvox = (size_t)D * plane;
+    const float *__restrict__ fl = flow + (size_t)b * 3 * nvox + (size_t)(D - 1) * plane;
+    const float *__restrict__ hh = halo_hi + (size_t)b * 3 * plane;
+    double acc = 0.0;
+    for (int c = 0; c < 3; c++)
+        for (size_t i0 = 0; i0 < plane; i0 += 1024 * 8) {
+            float part = 0.f;   // 8 terms in fp32, carried in fp64
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const size_t i = i0 + (size_t)k * 1024 + tid;
+                if (i < plane) {
+                    const float d = hh[c * plane + i] - fl[c * nvox + i];
+                    part = fmaf(d, d, part);
+                }
+            }
+            acc += (double)part;
+        }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; w++) t += red[w];
+        moments[b * 8 + 5] += t;
+    }
+}
+
 static int check_vol_flow(const trx_volumes *v, bool need_target)
 {
     if (!v || !v->moving || (need_target && !v->target)) return TRX_ERR_ARG;
@@ -767,6 +802,19 @@ extern "C" int trx_flow_slab_moments_ready(const trx_volumes *vol, int z_offset,
     hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, (const float *)workspace, (int)flow_grid_x(*vol), vol->ndim, vol->D, vol->H,
                        vol->W, lc, oc, 0.f, (float *)nullptr, 0, (int *)nullptr, (float *)nullptr, (FlowCoef *)nullptr, moments,
                        (const double *)nullptr, D_full);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+// The cross-slab part of the smoothness sums of pass A (see slab_boundary_smooth_kernel): call trx_flow_slab_moments with halo_hi = NULL,
+// then this once the neighbour's plane has arrived; together they equal trx_flow_slab_moments with the halo.
+extern "C" int trx_flow_slab_boundary_smooth(const trx_volumes *vol, const float *flow, const float *halo_hi, double *moments, void *stream)
+{
+    int rc = check_vol_flow(vol, false);
+    if (rc) return rc;
+    if (vol->ndim != 3) return TRX_ERR_NDIM;
+    if (!flow || !halo_hi || !moments) return TRX_ERR_ARG;
+    hipLaunchKernelGGL(slab_boundary_smooth_kernel, dim3(vol->B), dim3(1024), 0, (hipStream_t)stream, flow, halo_hi, vol->D, vol->H, vol->W, moments);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
