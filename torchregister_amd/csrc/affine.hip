@@ -237,7 +237,13 @@ using GeomR = TileCfg<16, 8, 512, 28, 26, 16, 2, 1>;
 // Wide tile (64 x 8 x 8, one row block of 8 per thread): a box row of 64 + halo voxels touches 3.3 L2 lines for 64 voxels where the
 // 32-wide tile touches 2.3 for 32, i.e. 366 instead of 444 box lines per 4096 voxels; the 76 x 13 x 14 box fits |rotation| < ~0.04 rad.
 using GeomW = TileCfg<64, 8, 512, 76, 13, 14, 2, 1, 8>;
-#if TRX_TILE_CFG == 1
+// Deep tile on 512 threads (32 x 16 x 16, sixteen rows per thread, ONE 44 x 23 x 19 box = 76.9 KB, two blocks per CU): per-tile work and the two
+// barriers are paid once per 8192 voxels instead of 4096 and the z halo is 18 / 16 instead of 10 / 8; the box has one plane of slack, so it
+// serves |theta - I| up to ~0.03 rad about x / y only.
+using GeomD = TileCfg<32, 16, 512, 44, 23, 19, 2, 1>;
+#if TRX_TILE_CFG == 4
+using GeomP = GeomD;
+#elif TRX_TILE_CFG == 1
 using GeomP = GeomDeep;   // primary geometry
 #elif TRX_TILE_CFG == 3
 using GeomP = GeomW;
@@ -324,6 +330,9 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #endif
 #ifndef TRX_FIN_ABLATE
 #define TRX_FIN_ABLATE 0
+#endif
+#ifndef TRX_DEEP_TILE
+#define TRX_DEEP_TILE 1   // the step kernels carry GeomD (deep tile) as a third per-pair choice (0: GeomA / GeomR only - measured alternative)
 #endif
 #ifndef TRX_SWP
 #define TRX_SWP 1   // software pipeline of the gather: LDS reads of row j+1 issued before the arithmetic of row j (0: at use)
@@ -696,7 +705,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
                   const unsigned lds0 = dma_lds;
                   unsigned long long sv;
                   unsigned m0s;
-                  static_assert((kPieces >= 6 && kPieces <= 8) || kPieces == 13, "the DMA block below is written for 6, 7, 8 or 13 pieces");
+                  static_assert((kPieces >= 6 && kPieces <= 8) || (kPieces >= 9 && kPieces <= 13), "the DMA block below is written for 6, 7, 8 or 9..13 pieces");
                   // one exec mask + one SGPR-base load per piece; s[100:101] walks the volume by kPP planes per piece
 #if TRX_DMA_EXECZ_SKIP
 #define TRX_DMA_SKIP "s_cbranch_execz 1f\n\t"
@@ -723,7 +732,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
     TRX_DMA_NEXT(1) TRX_DMA_NEXT(2) TRX_DMA_NEXT(3) TRX_DMA_NEXT(4) TRX_DMA_NEXT(5)
 #define TRX_DMA_TAIL "s_mov_b64 exec, %[sv]\n\t" "s_mov_b32 m0, %[m0s]"
                   if constexpr (kZMask) {
-                      static_assert(kPieces == 13, "plane-bit DMA block: 13 pieces");
+                      static_assert(kPieces <= 13, "plane-bit DMA block: up to 13 pieces (the plane bits of pieces a shallower box lacks are never set)");
                       unsigned long long t0, t1;
 #define TRX_DMA_ZSEL(B0, B1)                             \
     "s_bitcmp1_b32 %[zb], " #B0 "\n\t"                   \
@@ -1168,18 +1177,26 @@ __global__ __launch_bounds__(GeomP::Threads, TRX_TILE_MIN_WAVES) void affine_til
     tile_body<MODE, GeomP>(vol, theta, tg, channels, partials, box, blockIdx.x, blockIdx.y);
 }
 
-// Does GeomA's box hold the pre-image of a GeomA tile for this theta?  (theta-only: the tile-independent maximum extent, the same
+// Does geometry G's box hold the pre-image of one of its tiles for this theta?  (theta-only: the tile-independent maximum extent, the same
 // bound the fast loop fetches.)  NaN / huge theta compare false: GeomR, whose own per-tile test then sends everything to the fallback.
-__device__ __forceinline__ bool dual_fits_geomA(const float *__restrict__ th, float fD, float fH, float fW)
+template <class G>
+__device__ __forceinline__ bool dual_fits(const float *__restrict__ th, float fD, float fH, float fW)
 {
     const float slope[3][3] = {{th[0], th[1] * fW / fH, th[2] * fW / fD}, {th[4] * fH / fW, th[5], th[6] * fH / fD}, {th[8] * fD / fW, th[9] * fD / fH, th[10]}};
-    const float ex[3] = {(float)(GeomA::TX - 1), (float)(GeomA::TY - 1), (float)(GeomA::TZ - 1)};
+    const float ex[3] = {(float)(G::TX - 1), (float)(G::TY - 1), (float)(G::TZ - 1)};
     float span[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) span[c] = fabsf(slope[c][0]) * ex[0] + fabsf(slope[c][1]) * ex[1] + fabsf(slope[c][2]) * ex[2];
     return (span[0] < 1.0e6f) && (span[1] < 1.0e6f) && (span[2] < 1.0e6f) &&
-           ((((int)floorf(span[0] + 0.1f) + 5) >> 2) + 1 <= GeomA::BW4) && ((int)floorf(span[1] + 0.1f) + 3 <= GeomA::BH) &&
-           ((int)floorf(span[2] + 0.1f) + 3 <= GeomA::BD);
+           ((((int)floorf(span[0] + 0.1f) + 5) >> 2) + 1 <= G::BW4) && ((int)floorf(span[1] + 0.1f) + 3 <= G::BH) &&
+           ((int)floorf(span[2] + 0.1f) + 3 <= G::BD);
+}
+// The geometry a pair's blocks run (0 = GeomD, the deep tile, step kernels only; 1 = GeomA; 2 = GeomR): evaluated identically by every
+// block of the pair and by the step's finalise kernel.
+__device__ __forceinline__ int dual_choice(const float *__restrict__ th, float fD, float fH, float fW, bool with_deep)
+{
+    if (with_deep && dual_fits<GeomD>(th, fD, fH, fW)) return 0;
+    return dual_fits<GeomA>(th, fD, fH, fW) ? 1 : 2;
 }
 
 // The dual kernel: per pair, GeomA where its box holds the pre-image of a GeomA tile for this theta (decided from the
@@ -1191,23 +1208,32 @@ __device__ __forceinline__ bool dual_fits_geomA(const float *__restrict__ th, fl
 template <int MODE, int WHICH = 0>
 __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tgA,
                                                                                    TileGeom tgR, int channels, float *__restrict__ partials,
-                                                                                   int zero_surplus = 1)
+                                                                                   int zero_surplus = 1, TileGeom tgD = TileGeom{})
 {
-    static_assert(GeomA::Threads == 512 && GeomR::Threads == 512, "both geometries run 512-thread blocks");
-    constexpr int kAlloc = WHICH == 1 ? GeomA::BoxAlloc : (WHICH == 2 ? GeomR::BoxAlloc : (GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc));
+    static_assert(GeomA::Threads == 512 && GeomR::Threads == 512 && GeomD::Threads == 512, "every geometry runs 512-thread blocks");
+    // the step kernels (MODE 0 / 4) of the one-launch form also carry the deep tile for transforms next to the identity
+    constexpr bool kDeep = (WHICH == 0) && (MODE == 0 || MODE == 4) && (TRX_TILE_CFG == 0) && (TRX_DEEP_TILE != 0);
+    constexpr int kAllocAR = GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc;
+    constexpr int kAlloc = WHICH == 1 ? GeomA::BoxAlloc : (WHICH == 2 ? GeomR::BoxAlloc : ((kDeep && GeomD::BoxAlloc > kAllocAR) ? GeomD::BoxAlloc : kAllocAR));
     __shared__ __attribute__((aligned(16))) float box[kAlloc];
     constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : (MODE == 4 ? kNpMse : 5));
     const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
     const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
-    const bool fitsA = dual_fits_geomA(th, (float)vol.D, (float)vol.H, (float)vol.W);
-    const bool useA = __builtin_amdgcn_readfirstlane(fitsA ? 1 : 0) != 0;
+    const int choice = __builtin_amdgcn_readfirstlane(dual_choice(th, (float)vol.D, (float)vol.H, (float)vol.W, kDeep && tgD.blocks_per_pair > 0));
+    const bool useA = choice == 1;
     if ((WHICH == 1 && !useA) || (WHICH == 2 && useA)) return;   // the other launch owns this pair (and its surplus rows)
-    const int mine = useA ? tgA.blocks_per_pair : tgR.blocks_per_pair;
+    const int mine = choice == 0 ? tgD.blocks_per_pair : (useA ? tgA.blocks_per_pair : tgR.blocks_per_pair);
     if ((int)blockIdx.x >= mine) {
         // (zero_surplus = 0: the reader knows from theta which geometry ran and stops at its row count - the step's finalise kernel)
         if (MODE != 3 && zero_surplus && threadIdx.x < NP) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + threadIdx.x] = 0.f;
         return;
+    }
+    if constexpr (kDeep) {
+        if (choice == 0) {
+            tile_body<MODE, GeomD>(vol, theta, tgD, channels, partials, box, blockIdx.x, blockIdx.y);
+            return;
+        }
     }
     if constexpr (WHICH != 1) {
         if (!useA) {
@@ -1221,10 +1247,10 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
 // GeomA / GeomR per pair: one two-body launch or the pair of single-body launches (TRX_AFFINE_DUAL = 1 / 2, default 1: the pair costs one more launch and gains nothing).
 template <int MODE>
 static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const float *theta, const TileGeom &ta, const TileGeom &tr, int channels, float *out, int how,
-                        int zero_surplus = 1)
+                        int zero_surplus = 1, TileGeom td = TileGeom{})
 {
     if (how == 1) {
-        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus);
+        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td);
     } else {
         hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 1>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
         hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 2>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
@@ -1365,7 +1391,8 @@ template <int ND>
 __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const float *__restrict__ partials, int nblk,
                                                                           double nvox, int D, int H, int W,
                                                                           trx_loss_cfg lc, trx_opt_cfg oc,
-                                                                          trx_affine_state st, int nblk_geomA = 0, int nblk_geomR = 0, int mse_rows = 0)
+                                                                          trx_affine_state st, int nblk_geomA = 0, int nblk_geomR = 0, int mse_rows = 0,
+                                                                          int nblk_geomD = 0)
 {
     constexpr int NP = np_full(ND);
     constexpr int NT = ND * (ND + 1);
@@ -1408,7 +1435,10 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
         // first blocks_per_pair of the geometry it chose from this theta - the same test here (theta is still the one of that forward)
         int rows = nblk;
         if constexpr (ND == 3) {
-            if (nblk_geomA != 0) rows = dual_fits_geomA(theta, (float)D, (float)H, (float)W) ? nblk_geomA : nblk_geomR;
+            if (nblk_geomA != 0) {
+                const int choice = dual_choice(theta, (float)D, (float)H, (float)W, nblk_geomD > 0);
+                rows = choice == 0 ? nblk_geomD : (choice == 1 ? nblk_geomA : nblk_geomR);
+            }
         }
         if (ND == 3 && mse_rows) reduce_partials<kNpMse>(partials + (size_t)b * nblk * kNpMse, rows, S);   // rows of the MSE / SSD-only step kernel
         else reduce_partials<NP>(partials + (size_t)b * nblk * NP, rows, S);
@@ -1639,7 +1669,8 @@ static bool use_tile_path(const trx_volumes *vol)
 // MODE 0 / 1 dispatch: LDS-tiled kernel for 3-D, row-walking gather kernel otherwise.
 // Returns the number of partial rows per pair through *nblk.
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a = nullptr, int *nblk_r = nullptr);
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a = nullptr, int *nblk_r = nullptr,
+                     int *nblk_d = nullptr);
 
 template <int MODE>
 static int launch_accum(const trx_volumes *vol, const float *theta, const AffineGeom &g, int channels, size_t chan_stride,
@@ -1657,9 +1688,10 @@ static int launch_accum(const trx_volumes *vol, const float *theta, const Affine
 // nblk_a / nblk_r != nullptr: the caller's reduction knows the per-pair geometry (see affine_finalize_kernel): surplus blocks of the
 // dual grid then write nothing.
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a, int *nblk_r)
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a, int *nblk_r, int *nblk_d)
 {
     if (nblk_a) *nblk_a = *nblk_r = 0;
+    if (nblk_d) *nblk_d = 0;
     if (use_tile_path(vol)) {
         TileGeom t = tile_geom(*vol);
         trx_volumes v = *vol;
@@ -1679,10 +1711,18 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             const TileGeom ta = tile_geom<GeomA>(*vol), tr = tile_geom<GeomR>(*vol);
             const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
             const bool aware = nblk_a != nullptr && use_dual(vol) == 1;
-            launch_dual<MODE>(dim3(gx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1);
+            // the deep tile joins the choice only where the reader of the partial rows repeats it (the step's finalise kernel) and where
+            // its 128-row slabs still fill the chip (8192 voxels per tile: big batches)
+            TileGeom td = TileGeom{};
+            if (aware && nblk_d != nullptr && (MODE == 0 || MODE == 4)) {
+                const TileGeom cand = tile_geom<GeomD>(*vol);
+                if (TRX_DEEP_TILE && (long)cand.blocks_per_pair * vol->B >= 1024) td = cand;
+            }
+            launch_dual<MODE>(dim3(gx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td);
             TRX_CHECK_LAUNCH();
             *nblk = gx;
             if (aware) { *nblk_a = ta.blocks_per_pair; *nblk_r = tr.blocks_per_pair; }
+            if (nblk_d) *nblk_d = td.blocks_per_pair;
             return TRX_OK;
         }
         hipLaunchKernelGGL((affine_tile_kernel<MODE>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
@@ -1716,16 +1756,16 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     // Every step picks GeomA / GeomR per pair in the kernel (TRX_FLAG_SINGLE_GEOM: the primary geometry only).  Rigid runs start from a
     // random pose (reference: torch.rand, up to 1 rad) and live at large rotations; affine runs start at the identity, where the
     // GeomA body is all that runs, but may rotate away from it: the single-geometry kernel then gathers from L2 at 3.2x the cost.
-    int nblk_a = 0, nblk_r = 0;
+    int nblk_a = 0, nblk_r = 0, nblk_d = 0;
     // without an NCC term only d = warped - target matters: the step kernel then keeps 13 sums instead of 41 (3-D tile path)
     const bool mse_only = (loss->w_ncc == 0.f) && use_tile_path(vol);
-    rc = mse_only ? launch_f1<4>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r)
-                  : launch_f1<0>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r);
+    rc = mse_only ? launch_f1<4>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r, &nblk_d)
+                  : launch_f1<0>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r, &nblk_d);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
     if (vol->ndim == 3)
         hipLaunchKernelGGL((affine_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
-                           vol->D, vol->H, vol->W, *loss, *opt, *st, nblk_a, nblk_r, mse_only ? 1 : 0);
+                           vol->D, vol->H, vol->W, *loss, *opt, *st, nblk_a, nblk_r, mse_only ? 1 : 0, nblk_d);
     else
         hipLaunchKernelGGL((affine_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
                            vol->D, vol->H, vol->W, *loss, *opt, *st);
@@ -1739,8 +1779,8 @@ extern "C" int trx_affine_accumulate(const trx_volumes *vol, const float *theta,
     if (rc) return rc;
     if (!theta || !workspace) return TRX_ERR_ARG;
     if (workspace_bytes < trx_affine_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
-    int nblk = 0;
-    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream, true);   // the kernel of a step (profiling aid)
+    int nblk = 0, na = 0, nr = 0, nd = 0;
+    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream, true, &na, &nr, &nd);   // exactly the launch of a step (profiling aid)
 }
 
 extern "C" int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
