@@ -245,3 +245,40 @@ def test_identity_gradient_same_on_every_path(eng, shape):
     for g, l in zip(grads[:2], losses[:2]):
         assert abs(l - losses[2]) <= 2e-6 * max(1.0, abs(losses[2]))
         assert np.max(np.abs(g - grads[2])) <= 2e-5 * gmax, (g, grads[2])
+
+
+DEEP_THETAS = {
+    "identity": np.eye(3, 4),
+    "near": np.eye(3, 4) + 0.02 * np.sin(1.3 * np.arange(12) + 0.4).reshape(3, 4),
+    "rot_z": rot_theta(0.0, 0.0, 0.12, (1.01, 0.99, 1.0), (0.03, -0.02, 0.01)),          # about z: the deep box holds what GeomA holds
+    "shift_out": rot_theta(0.01, 0.005, -0.02, (1.0, 1.0, 1.0), (0.45, -0.4, 0.3)),      # large out-of-volume region, still the deep tile
+    "tilt": rot_theta(0.06, 0.05, 0.02, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0)),               # about x / y beyond the box's one plane of slack: GeomA takes it
+}
+
+
+@pytest.mark.parametrize("loss", ["ncc_mse", "mse"])
+@pytest.mark.parametrize("shape", [(40, 36, 44), (16, 48, 64), (33, 20, 68), (64, 64, 64), (23, 37, 46)])
+@pytest.mark.parametrize("tname", list(DEEP_THETAS))
+def test_deep_tile_vs_oracle(eng, shape, tname, loss):
+    """GeomD (32 x 16 x 16 tile, sixteen rows per thread; by default only for big batches) forced on small ragged volumes through
+    TRX_FLAG_DEEP_TILE, both step kernels (41 sums with the NCC term, 13 without), against the C oracle in fp64."""
+    from torchregister_amd import _lib
+    tgt = ph.blobs(shape, 77)
+    mov = ph.blobs(shape, 78) + 0.1 * ph.vol(shape, 0.013, "sin")
+    th64 = DEEP_THETAS[tname] if tname == "identity" else generic(DEEP_THETAS[tname])
+    th = torch.tensor(th64, dtype=torch.float32)[None]
+    kw = dict(w_ncc=1.0, w_mse=0.5) if loss == "ncc_mse" else dict(w_mse=1.0, w_ssd=0.01)
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=_lib.FLAG_DEEP_TILE)
+    ref = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
+    s.run(1)
+    ref.run(1)
+    torch.cuda.synchronize()
+    total, _, dth, _ = oracle.c_affine_loss_grad(mov[0, 0].double().numpy(), tgt[0, 0].double().numpy(), th[0].double().numpy(), oracle.wts(**kw),
+                                                 oracle.base_tables(shape, np.float64))
+    loss_v = s.losses[0, 0].item()
+    grad = s.grad[0, :12].cpu().numpy().reshape(3, 4)
+    assert abs(loss_v - total) <= 2e-5 * max(1.0, abs(total)), (loss_v, total)
+    gref = ref.grad[0, :12].cpu().numpy().reshape(3, 4)
+    assert np.max(np.abs(grad - gref)) <= 2e-5 * np.max(np.abs(gref))            # the default geometry choice gives the same numbers
+    if tname != "identity":
+        assert np.max(np.abs(grad - dth)) <= 2e-4 * np.max(np.abs(dth)), (grad, dth)

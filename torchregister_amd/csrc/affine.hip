@@ -1716,7 +1716,7 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             TileGeom td = TileGeom{};
             if (aware && nblk_d != nullptr && (MODE == 0 || MODE == 4)) {
                 const TileGeom cand = tile_geom<GeomD>(*vol);
-                if (TRX_DEEP_TILE && (long)cand.blocks_per_pair * vol->B >= 1024) td = cand;
+                if (TRX_DEEP_TILE && ((long)cand.blocks_per_pair * vol->B >= 1024 || (vol->flags & TRX_FLAG_DEEP_TILE))) td = cand;
             }
             launch_dual<MODE>(dim3(gx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td);
             TRX_CHECK_LAUNCH();
