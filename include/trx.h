@@ -137,6 +137,17 @@ int trx_affine_warp(const trx_volumes *vol, const float *theta, int channels, fl
 int trx_affine_warp_backward(const trx_volumes *vol, const float *theta, int channels, const float *grad_out,
                              float *dtheta, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The warp and its theta-backward on a sub-lattice of the output grid: out[B][nz][ny][nx] = warp(moving, theta) at the output voxels
+ * (iz[kz], iy[ky], ix[kx]) (device int32 tables; 2-D: nz = 1, iz ignored) - what the NMI loss's
+ * F.interpolate(warped, size, mode="nearest") keeps of a full-volume warp (ref:utils.py:236-252: 100^3 of a 256^3 volume) when the
+ * tables hold that call's source indices - and dtheta[B][TRX_PSTRIDE] = sum_k grad_out[B][k] * d out_k / d theta (replaces the
+ * nearest-interpolate backward + grid_sampler backward + affine_grid backward of the same chain).  Single channel.
+ * workspace (backward): at least max(trx_affine_workspace_bytes(vol), B * 2048 * 12 * sizeof(float)) bytes. */
+int trx_affine_warp_lattice(const trx_volumes *vol, const float *theta, const int *iz, int nz, const int *iy, int ny, const int *ix, int nx,
+                            float *out, void *stream);
+int trx_affine_warp_lattice_backward(const trx_volumes *vol, const float *theta, const int *iz, int nz, const int *iy, int ny, const int *ix,
+                                     int nx, const float *grad_out, float *dtheta, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Theta (ref:utils.py:287-310: pose vector -> affine matrix, 6 floats in 3-D / 3 in 2-D) and its vector-Jacobian product, for
  * callers that assemble dL/dtheta themselves: theta_out[B][TRX_PSTRIDE] = Theta(pose[B][TRX_PSTRIDE]) and / or
  * dpose_out[B][TRX_PSTRIDE] = J(pose)^T dtheta[B][TRX_PSTRIDE] (fp64 inside, as in trx_affine_step's rigid branch). */

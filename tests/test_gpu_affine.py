@@ -285,3 +285,84 @@ def test_graph_capture_and_side_stream(eng):
     side.synchronize()
     assert torch.equal(s.step.cpu(), torch.tensor([12], dtype=torch.int32))
     assert torch.equal(s.losses, ref.losses) and torch.equal(s.theta, ref.theta)
+
+
+LATTICE_CASES = [  # spatial, lattice size, theta (row-major nd x (nd+1))
+    ((40, 36, 52), (20, 20, 20), [[1.02, 0.03, -0.02, 0.05], [-0.03, 0.98, 0.02, -0.04], [0.01, -0.02, 1.03, 0.02]]),
+    ((23, 31, 37), (10, 12, 14), [[0.9, 0.3, 0.1, 0.4], [-0.3, 0.9, 0.05, -0.3], [0.1, -0.1, 1.1, 0.2]]),         # samples leave the volume (zero padding)
+    ((16, 18, 20), (24, 20, 40), [[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0]]),             # up-sampling: lattice points repeat
+    ((48, 40), (20, 20), [[1.01, 0.04, 0.03], [-0.05, 0.97, -0.02]]),
+    ((33, 57), (50, 16), [[0.8, 0.5, 0.3], [-0.5, 0.8, -0.2]]),
+]
+
+
+@pytest.mark.parametrize("spatial,size,theta", LATTICE_CASES)
+def test_warp_lattice_equals_warp_then_nearest(eng, spatial, size, theta):
+    """trx_affine_warp_lattice[_backward] (the NMI loss's view of the warp, ref:utils.py:236-252) against the chain it replaces:
+    full-volume HIP warp (golden / oracle-checked above) -> F.interpolate(nearest) and, backward, the adjoint of that gather ->
+    trx_affine_warp_backward.  Backward: 1e-4 of max|dtheta| (fp32 partial sums in a different order)."""
+    import ctypes
+    import torch.nn.functional as F
+    nd = len(spatial)
+    B = 2
+    mov = torch.stack([ph.vol(spatial, 0.37 + 0.11 * b, "sin")[0] for b in range(B)]).cuda()
+    th = torch.tensor(theta, dtype=torch.float32)[None].repeat(B, 1, 1)
+    th[1, 0, -1] += 0.07
+    th = th.cuda()
+    batch = eng._Batch(mov, mov)
+    vol = batch.vol()
+    lat = eng.LatticeWarp(vol, spatial, size, mov.device)
+    thp = eng.pad_theta(th.reshape(B, -1), nd)
+    got = lat.forward(thp)
+    full = eng.affine_warp(th, mov)
+    ref = F.interpolate(full, size=size, mode="nearest")
+    assert got.shape == (B, int(np.prod(size)))
+    # the phantom changes by O(1) between neighbouring voxels and the LDS-tiled warp kernel forms its coordinates as corner + slope
+    # (1e-5 voxels from the plain fma chain): 2e-5 abs against it, and EXACT equality with the un-tiled kernel (same arithmetic)
+    assert torch.max(torch.abs(got - ref.detach().reshape(B, -1))).item() <= 2e-5
+    import ctypes as ct
+    from torchregister_amd import _lib
+    gb = eng._Batch(mov, mov, flags=_lib.FLAG_GATHER_PATH)
+    gvol, plain = gb.vol(), torch.empty_like(mov)
+    _lib.check(_lib.load().trx_affine_warp(ct.byref(gvol), _lib.ptr(thp), 1, _lib.ptr(plain), _lib.current_stream(mov.device)), "trx_affine_warp")
+    assert torch.equal(got, F.interpolate(plain, size=size, mode="nearest").reshape(B, -1))
+    g = torch.Generator().manual_seed(sum(spatial))
+    go = (torch.rand(B, int(np.prod(size)), generator=g) - 0.4).cuda()
+    dth = lat.backward(thp, go)[:, : nd * (nd + 1)].reshape(B, nd, nd + 1).cpu().numpy()
+    # adjoint of the nearest gather, built from the lattice tables.  (NOT torch.autograd through F.interpolate on the GPU: ATen's
+    # device kernel for the nearest BACKWARD inverts the index map with its own float arithmetic - ceil(d * (out / in)) - and for
+    # non-integer ratios sends some gradients to a neighbouring voxel, e.g. 52 -> 20: output 5 reads input 13, its gradient lands on
+    # input 12.  ATen's CPU kernel, which the reference runs on, uses the forward index function in both directions.)
+    gw = torch.zeros_like(full)
+    idx = torch.meshgrid(*[t.long() for t in ((lat.iz, lat.iy, lat.ix) if nd == 3 else (lat.iy, lat.ix))], indexing="ij")
+    for b in range(B):
+        gw[b, 0].index_put_(idx, go[b].view(size), accumulate=True)
+    # through the un-tiled kernel (same coordinate arithmetic as the lattice kernel): the derivative of trilinear interpolation jumps at
+    # cell faces, and a sample within 1e-5 voxels of one may fall on different sides in the tiled kernel (one such sample moves an entry
+    # by ~1 %; seen in the first case) - the tiled path gets the looser bar
+    want = torch.zeros(B, eng.PSTRIDE, device=mov.device)
+    ws = torch.empty(int(_lib.load().trx_affine_workspace_bytes(ct.byref(gvol))), dtype=torch.uint8, device=mov.device)
+    gvol.target = gw.data_ptr()
+    _lib.check(_lib.load().trx_affine_warp_backward(ct.byref(gvol), _lib.ptr(thp), 1, _lib.ptr(gw), _lib.ptr(want), _lib.ptr(ws), ws.numel(),
+                                                    _lib.current_stream(mov.device)), "trx_affine_warp_backward")
+    want = want[:, : nd * (nd + 1)].reshape(B, nd, nd + 1).cpu().numpy()
+    assert np.max(np.abs(dth - want)) <= 1e-4 * np.max(np.abs(want))
+    tiled = eng.affine_warp_backward(th, mov, gw.contiguous()).cpu().numpy()
+    assert np.max(np.abs(dth - tiled)) <= 2e-2 * np.max(np.abs(tiled))
+    assert ctypes.sizeof(vol) > 0   # (vol must stay alive while lat is used)
+
+
+def test_warp_lattice_argument_checks(eng):
+    import ctypes
+    from torchregister_amd import _lib
+    mov = ph.vol((8, 9, 10), 0.3, "sin").cuda()
+    vol = eng._Batch(mov, mov).vol()
+    lat = eng.LatticeWarp(vol, (8, 9, 10), (4, 4, 4), mov.device)
+    th = eng.pad_theta(torch.eye(3, 4).reshape(1, -1).cuda(), 3)
+    out = torch.empty(1, 64, device="cuda")
+    lib = _lib.load()
+    rc = lib.trx_affine_warp_lattice(ctypes.byref(vol), _lib.ptr(th), None, 4, _lib.ptr(lat.iy), 4, _lib.ptr(lat.ix), 4, _lib.ptr(out), None)
+    assert rc != 0   # 3-D without a z table
+    rc = lib.trx_affine_warp_lattice_backward(ctypes.byref(vol), _lib.ptr(th), _lib.ptr(lat.iz), 4, _lib.ptr(lat.iy), 4, _lib.ptr(lat.ix), 4,
+                                              _lib.ptr(out), _lib.ptr(lat.dtheta), _lib.ptr(lat.ws), 16, None)
+    assert rc != 0   # workspace too small

@@ -110,3 +110,24 @@ def test_nmi_loss_caches_the_target_side_only_while_it_is_unchanged():
     y.mul_(1.5)                                  # in-place change of the target: the cache must not be used
     c = crit(y, yp).item()
     assert c == U.NMILoss()(y, yp).item() and c != a
+
+
+def test_nmi_patches_gradient_is_the_gather_adjoint():
+    """NMILoss's nearest down-sampling (ref:utils.py:236-252) on the GPU: values = F.interpolate(nearest), gradient = the exact adjoint
+    of that gather (what ATen's CPU kernel - the reference's platform - computes; the device kernel's own backward misplaces some
+    gradients for non-integer ratios, which this test also demonstrates so that the work-around can be dropped when that changes)."""
+    import torch.nn.functional as F
+    import torchregister_amd.utils as U
+    nmi = U.NMILoss(patch_size=10)
+    x = torch.rand(1, 1, 40, 36, 52, device="cuda").requires_grad_()
+    p = nmi._patches(x)
+    assert torch.equal(p.reshape(-1), F.interpolate(x.detach(), size=(20, 20, 20), mode="nearest").reshape(-1))
+    w = torch.rand_like(p)
+    (p * w).sum().backward()
+    xc = x.detach().cpu().requires_grad_()
+    (F.interpolate(xc, size=(20, 20, 20), mode="nearest").reshape(p.shape) * w.cpu()).sum().backward()
+    assert torch.equal(x.grad.cpu(), xc.grad)
+    xd = x.detach().clone().requires_grad_()
+    (F.interpolate(xd, size=(20, 20, 20), mode="nearest").reshape(p.shape) * w).sum().backward()
+    if torch.equal(xd.grad.cpu(), xc.grad):
+        pytest.skip("this ATen build's device nearest-backward agrees with the CPU kernel: the gather work-around is no longer needed")

@@ -6,6 +6,7 @@ libtrx.so.  Tensors must be fp32 CUDA(HIP) tensors; anything else raises.
 import ctypes
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 from ._lib import PSTRIDE
@@ -615,6 +616,56 @@ def kde_pdf_backward(signals, xis, grad_pdf, h, center=None):
     _lib.check(rc, "trx_kde_pdf_backward")
     return out
 
+
+
+def nearest_lattice(spatial, size, device):
+    """Source indices of F.interpolate(x[..., *spatial], size=size, mode="nearest") per axis, as int32 device tables.  Taken from
+    ATen itself (an index ramp pushed through the same call), so the lattice is exactly the one the torch composition samples."""
+    tabs = []
+    for n_in, n_out in zip(spatial, size):
+        ramp = torch.arange(int(n_in), device=device, dtype=torch.float32).view(1, 1, -1)
+        tabs.append(F.interpolate(ramp, size=int(n_out), mode="nearest").view(-1).to(torch.int32).contiguous())
+    return tabs
+
+
+class LatticeWarp:
+    """warp(moving, theta) evaluated only on a sub-lattice of the output grid and its theta-backward (include/trx.h:
+    trx_affine_warp_lattice[_backward]) - what F.interpolate(get_affine_warp(theta, moving), size, mode="nearest") and the backward of
+    that chain compute, without the full-volume warp, the down-sampling and the full-volume gradient."""
+
+    def __init__(self, vol, spatial, size, device):
+        """vol: the _lib.Volumes of the (moving, target) batch (single channel; its tensors must outlive this object)."""
+        self.vol, self.lib = vol, _lib.load()
+        dev = torch.device(device)
+        nd, B = int(vol.ndim), int(vol.B)
+        self.B = B
+        self.size = tuple(int(v) for v in size)
+        tabs = nearest_lattice(spatial, self.size, dev)
+        zero = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.iz, self.iy, self.ix = (tabs if nd == 3 else [zero] + tabs)
+        self.nz = self.size[0] if nd == 3 else 1
+        self.ny, self.nx = self.size[-2], self.size[-1]
+        self.n = self.nz * self.ny * self.nx
+        self.ws_bytes = max(int(self.lib.trx_affine_workspace_bytes(ctypes.byref(vol))), B * 2048 * 12 * 4)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.dtheta = torch.zeros(B, PSTRIDE, device=dev)
+
+    def forward(self, theta):
+        out = torch.empty(self.B, self.n, device=theta.device)
+        with torch.cuda.device(theta.device):
+            rc = self.lib.trx_affine_warp_lattice(ctypes.byref(self.vol), _lib.ptr(theta), _lib.ptr(self.iz), self.nz, _lib.ptr(self.iy), self.ny,
+                                                  _lib.ptr(self.ix), self.nx, _lib.ptr(out), _lib.current_stream(theta.device))
+        _lib.check(rc, "trx_affine_warp_lattice")
+        return out
+
+    def backward(self, theta, grad_out):
+        """grad_out [B, n] (contiguous fp32) -> dL/dtheta [B, PSTRIDE] (a buffer owned by this object, overwritten by the next call)."""
+        with torch.cuda.device(theta.device):
+            rc = self.lib.trx_affine_warp_lattice_backward(ctypes.byref(self.vol), _lib.ptr(theta), _lib.ptr(self.iz), self.nz, _lib.ptr(self.iy),
+                                                           self.ny, _lib.ptr(self.ix), self.nx, _lib.ptr(grad_out), _lib.ptr(self.dtheta),
+                                                           _lib.ptr(self.ws), self.ws_bytes, _lib.current_stream(theta.device))
+        _lib.check(rc, "trx_affine_warp_lattice_backward")
+        return self.dtheta
 
 
 def nmi_from_pdfs(h1, h2, hj, alpha, need_grad=True):

@@ -73,6 +73,9 @@ SIGNATURES = {
     "trx_affine_warp": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, ctypes.c_int, _P, _P]),
     "trx_affine_warp_backward": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, ctypes.c_int, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_theta_chain": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, _P, _P, _P]),
+    "trx_affine_warp_lattice": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, _P, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P, _P]),
+    "trx_affine_warp_lattice_backward": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, _P, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P,
+                                                        ctypes.c_size_t, _P]),
     "trx_flow_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Volumes)]),
     "trx_flow_warp": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, ctypes.c_int, _P, _P]),
     "trx_flow_step": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.POINTER(LossCfg), ctypes.POINTER(OptCfg),

@@ -1580,6 +1580,114 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_warp_kernel(trx_volumes vol,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward warp and its theta-backward on a SUB-LATTICE of the output grid: the NMI loss (ref:utils.py:236-252) only ever looks at
+// F.interpolate(warped, size, mode="nearest"), i.e. at the output voxels (iz[kz], iy[ky], ix[kx]) - 10^6 of the 1.7e7 voxels of a
+// 256^3 volume.  Evaluating the warp there directly replaces a full-volume warp, the nearest down-sampling, its autograd backward
+// (a scatter into a full-volume gradient) and a full-volume warp backward.  Same coordinate arithmetic as affine_warp_kernel.
+// ------------------------------------------------------------------------------------------
+struct LatticeIdx {
+    const int *iz, *iy, *ix;
+    int nz, ny, nx;
+};
+
+template <int ND>
+__device__ __forceinline__ void lattice_coords(const trx_volumes &vol, const float *__restrict__ th, int x, int y, int z, float &xn, float &yn,
+                                               float &zn, float &ix, float &iy, float &iz)
+{
+    xn = base_coord(vol.xn, x, vol.W); yn = base_coord(vol.yn, y, vol.H); zn = 0.f; iz = 0.f;
+    if constexpr (ND == 3) {
+        zn = base_coord(vol.zn, z, vol.D);
+        ix = unnorm<3>(fmaf(th[1], yn, fmaf(th[0], xn, fmaf(th[2], zn, th[3]))), (float)vol.W);
+        iy = unnorm<3>(fmaf(th[5], yn, fmaf(th[4], xn, fmaf(th[6], zn, th[7]))), (float)vol.H);
+        iz = unnorm<3>(fmaf(th[9], yn, fmaf(th[8], xn, fmaf(th[10], zn, th[11]))), (float)vol.D);
+    } else {
+        ix = unnorm<2>(fmaf(th[1], yn, fmaf(th[0], xn, th[2])), (float)vol.W);
+        iy = unnorm<2>(fmaf(th[4], yn, fmaf(th[3], xn, th[5])), (float)vol.H);
+    }
+}
+
+// One pass over the lattice, four points per thread and trip: the three dependent memory round trips of a point (index tables ->
+// coordinate tables -> the eight corners) are each issued for all four points before the first is used (branch-free sampler), so a
+// thread pays ~3 latencies per four points instead of twelve.  BWD = false: out[b][k] = warped value; BWD = true: acc += go[k] * J_k.
+template <int ND, bool BWD>
+__device__ __forceinline__ void lattice_pass(const trx_volumes &vol, const float *__restrict__ th, const float *__restrict__ mov, const LatticeIdx &L,
+                                             const float *__restrict__ go, float *__restrict__ out, float (&acc)[ND * (ND + 1)])
+{
+    constexpr int U = 4;
+    const unsigned n = (unsigned)L.nz * L.ny * L.nx;   // < 2^31 (checked by the caller): 32-bit index arithmetic
+    const unsigned stride = gridDim.x * TRX_BLOCK;
+    for (unsigned i0 = blockIdx.x * TRX_BLOCK + threadIdx.x; i0 < n; i0 += U * stride) {
+        unsigned idx[U];
+        bool ok[U];
+        int x[U], y[U], z[U];
+        float g[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned i = i0 + u * stride;
+            ok[u] = i < n;
+            idx[u] = ok[u] ? i : i0;                   // a thread past the end repeats its first point (discarded below)
+            const unsigned r = idx[u] / (unsigned)L.nx, kx = idx[u] - r * L.nx, kz = r / (unsigned)L.ny, ky = r - kz * L.ny;
+            x[u] = L.ix[kx]; y[u] = L.iy[ky]; z[u] = (ND == 3) ? L.iz[kz] : 0;
+            g[u] = BWD ? go[idx[u]] : 0.f;
+        }
+        float xn[U], yn[U], zn[U], ix[U], iy[U], iz[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) lattice_coords<ND>(vol, th, x[u], y[u], z[u], xn[u], yn[u], zn[u], ix[u], iy[u], iz[u]);
+        float v[U], gq[U][ND];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if constexpr (ND == 3) {
+                const Samp3 sm = sample3_padded(mov, vol.D, vol.H, vol.W, ix[u], iy[u], iz[u]);
+                v[u] = sm.v; gq[u][0] = sm.dx; gq[u][1] = sm.dy; gq[u][2] = sm.dz;
+            } else {
+                const Samp2 sm = sample2(mov, vol.H, vol.W, ix[u], iy[u]);
+                v[u] = sm.v; gq[u][0] = sm.dx; gq[u][1] = sm.dy;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if constexpr (!BWD) {
+                if (ok[u]) out[idx[u]] = v[u];
+            } else {
+                const float w = ok[u] ? g[u] : 0.f;
+#pragma unroll
+                for (int c = 0; c < ND; c++) {   // the partial-row layout of affine_bwd_finalize_kernel: per component (xn, yn[, zn], 1)
+                    const float q = w * gq[u][c];
+                    acc[c * (ND + 1) + 0] = fmaf(q, xn[u], acc[c * (ND + 1) + 0]);
+                    acc[c * (ND + 1) + 1] = fmaf(q, yn[u], acc[c * (ND + 1) + 1]);
+                    if constexpr (ND == 3) acc[c * (ND + 1) + 2] = fmaf(q, zn[u], acc[c * (ND + 1) + 2]);
+                    acc[c * (ND + 1) + ND] += q;
+                }
+            }
+        }
+    }
+}
+
+template <int ND>
+__global__ __launch_bounds__(TRX_BLOCK) void affine_warp_lattice_kernel(trx_volumes vol, const float *__restrict__ theta, LatticeIdx L,
+                                                                        float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const size_t n = (size_t)L.nz * L.ny * L.nx;
+    float acc[ND * (ND + 1)];
+    lattice_pass<ND, false>(vol, theta + (size_t)b * TRX_PSTRIDE, vol.moving + (size_t)b * vol.moving_stride, L, nullptr, out + (size_t)b * n, acc);
+}
+
+template <int ND>
+__global__ __launch_bounds__(TRX_BLOCK) void affine_lattice_bwd_kernel(trx_volumes vol, const float *__restrict__ theta, LatticeIdx L,
+                                                                       const float *__restrict__ grad_out, float *__restrict__ partials)
+{
+    constexpr int NT = ND * (ND + 1);
+    const int b = blockIdx.y;
+    const size_t n = (size_t)L.nz * L.ny * L.nx;
+    float acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = 0.f;
+    lattice_pass<ND, true>(vol, theta + (size_t)b * TRX_PSTRIDE, vol.moving + (size_t)b * vol.moving_stride, L, grad_out + (size_t)b * n, nullptr, acc);
+    block_reduce_store<NT>(acc, partials + ((size_t)b * gridDim.x + blockIdx.x) * NT);
+}
+
 // Theta (ref:utils.py:287-310) and its vector-Jacobian product for callers that assemble dL/dtheta themselves (the default-criterion
 // loop: NMI's gradient arrives outside the fused step): one wave per pair, fp64 like the finalise kernel.
 template <int ND>
@@ -1888,6 +1996,66 @@ extern "C" int trx_affine_warp_backward(const trx_volumes *vol, const float *the
         hipLaunchKernelGGL((affine_bwd_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, g.nblk, vol->D, vol->H, vol->W, dtheta);
     else
         hipLaunchKernelGGL((affine_bwd_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, g.nblk, vol->D, vol->H, vol->W, dtheta);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+static int check_lattice(const trx_volumes *vol, const int *iz, int nz, const int *iy, int ny, const int *ix, int nx)
+{
+    if (!iy || !ix || ny < 1 || nx < 1) return TRX_ERR_ARG;
+    if (vol->ndim == 3 ? (!iz || nz < 1) : (nz != 1)) return TRX_ERR_ARG;
+    if ((double)nz * ny * nx >= 2147483648.0) return TRX_ERR_ARG;
+    return TRX_OK;
+}
+
+static int lattice_blocks(size_t n)   // 4 lattice points per thread (gather latency is hidden by occupancy), at most 2048 blocks per pair (one partial row each)
+{
+    size_t nb = (n + (size_t)TRX_BLOCK * 4 - 1) / ((size_t)TRX_BLOCK * 4);
+    return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+}
+
+extern "C" int trx_affine_warp_lattice(const trx_volumes *vol, const float *theta, const int *iz, int nz, const int *iy, int ny, const int *ix,
+                                       int nx, float *out, void *stream)
+{
+    int rc = check_vol(vol, false);
+    if (rc) return rc;
+    if (!theta || !out) return TRX_ERR_ARG;
+    if ((rc = check_lattice(vol, iz, nz, iy, ny, ix, nx)) != TRX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)nz * ny * nx;
+    size_t nb = (n + (size_t)TRX_BLOCK * 4 - 1) / ((size_t)TRX_BLOCK * 4);
+    if (nb > 8192) nb = 8192;
+    const LatticeIdx L = {iz, iy, ix, nz, ny, nx};
+    dim3 grid((unsigned)nb, vol->B), block(TRX_BLOCK);
+    if (vol->ndim == 3) hipLaunchKernelGGL((affine_warp_lattice_kernel<3>), grid, block, 0, s, *vol, theta, L, out);
+    else hipLaunchKernelGGL((affine_warp_lattice_kernel<2>), grid, block, 0, s, *vol, theta, L, out);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+extern "C" int trx_affine_warp_lattice_backward(const trx_volumes *vol, const float *theta, const int *iz, int nz, const int *iy, int ny,
+                                                const int *ix, int nx, const float *grad_out, float *dtheta, void *workspace,
+                                                size_t workspace_bytes, void *stream)
+{
+    int rc = check_vol(vol, false);
+    if (rc) return rc;
+    if (!theta || !grad_out || !dtheta || !workspace) return TRX_ERR_ARG;
+    if ((rc = check_lattice(vol, iz, nz, iy, ny, ix, nx)) != TRX_OK) return rc;
+    const int nblk = lattice_blocks((size_t)nz * ny * nx);
+    if (workspace_bytes < trx_affine_workspace_bytes(vol) || workspace_bytes < (size_t)vol->B * nblk * 12 * sizeof(float)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float *partials = (float *)workspace;
+    const LatticeIdx L = {iz, iy, ix, nz, ny, nx};
+    dim3 grid((unsigned)nblk, vol->B), block(TRX_BLOCK);
+    if (vol->ndim == 3) {
+        hipLaunchKernelGGL((affine_lattice_bwd_kernel<3>), grid, block, 0, s, *vol, theta, L, grad_out, partials);
+        TRX_CHECK_LAUNCH();
+        hipLaunchKernelGGL((affine_bwd_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, vol->D, vol->H, vol->W, dtheta);
+    } else {
+        hipLaunchKernelGGL((affine_lattice_bwd_kernel<2>), grid, block, 0, s, *vol, theta, L, grad_out, partials);
+        TRX_CHECK_LAUNCH();
+        hipLaunchKernelGGL((affine_bwd_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, vol->D, vol->H, vol->W, dtheta);
+    }
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }

@@ -111,6 +111,29 @@ __device__ __forceinline__ Samp3 lerp3(float v000, float v001, float v010, float
     return s;
 }
 
+// zero-padded trilinear sample, branch-free form (every corner clamped + predicated): the general path of sample3, and the one to call
+// where several independent samples should have their loads in flight together (no wave-level branch between them)
+__device__ __forceinline__ Samp3 sample3_padded(const float *__restrict__ mov, int D, int H, int W, float ix, float iy, float iz)
+{
+    float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    bool bx0 = (unsigned)x0 < (unsigned)W, bx1 = (unsigned)x1 < (unsigned)W;
+    bool by0 = (unsigned)y0 < (unsigned)H, by1 = (unsigned)y1 < (unsigned)H;
+    bool bz0 = (unsigned)z0 < (unsigned)D, bz1 = (unsigned)z1 < (unsigned)D;
+    int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    int cz0 = min(max(z0, 0), D - 1), cz1 = min(max(z1, 0), D - 1);
+    const float *r00 = mov + ((size_t)cz0 * H + cy0) * W, *r01 = mov + ((size_t)cz0 * H + cy1) * W;
+    const float *r10 = mov + ((size_t)cz1 * H + cy0) * W, *r11 = mov + ((size_t)cz1 * H + cy1) * W;
+    float v000 = (bz0 & by0 & bx0) ? r00[cx0] : 0.f, v001 = (bz0 & by0 & bx1) ? r00[cx1] : 0.f;
+    float v010 = (bz0 & by1 & bx0) ? r01[cx0] : 0.f, v011 = (bz0 & by1 & bx1) ? r01[cx1] : 0.f;
+    float v100 = (bz1 & by0 & bx0) ? r10[cx0] : 0.f, v101 = (bz1 & by0 & bx1) ? r10[cx1] : 0.f;
+    float v110 = (bz1 & by1 & bx0) ? r11[cx0] : 0.f, v111 = (bz1 & by1 & bx1) ? r11[cx1] : 0.f;
+    return lerp3(v000, v001, v010, v011, v100, v101, v110, v111, tx, ty, tz);
+}
+
 __device__ __forceinline__ Samp3 sample3(const float *__restrict__ mov, int D, int H, int W, float ix, float iy,
                                          float iz)
 {
@@ -127,20 +150,7 @@ __device__ __forceinline__ Samp3 sample3(const float *__restrict__ mov, int D, i
         float v100 = q[0], v101 = q[1], v110 = q[W], v111 = q[W + 1];
         return lerp3(v000, v001, v010, v011, v100, v101, v110, v111, tx, ty, tz);
     }
-    int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
-    bool bx0 = (unsigned)x0 < (unsigned)W, bx1 = (unsigned)x1 < (unsigned)W;
-    bool by0 = (unsigned)y0 < (unsigned)H, by1 = (unsigned)y1 < (unsigned)H;
-    bool bz0 = (unsigned)z0 < (unsigned)D, bz1 = (unsigned)z1 < (unsigned)D;
-    int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
-    int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
-    int cz0 = min(max(z0, 0), D - 1), cz1 = min(max(z1, 0), D - 1);
-    const float *r00 = mov + ((size_t)cz0 * H + cy0) * W, *r01 = mov + ((size_t)cz0 * H + cy1) * W;
-    const float *r10 = mov + ((size_t)cz1 * H + cy0) * W, *r11 = mov + ((size_t)cz1 * H + cy1) * W;
-    float v000 = (bz0 & by0 & bx0) ? r00[cx0] : 0.f, v001 = (bz0 & by0 & bx1) ? r00[cx1] : 0.f;
-    float v010 = (bz0 & by1 & bx0) ? r01[cx0] : 0.f, v011 = (bz0 & by1 & bx1) ? r01[cx1] : 0.f;
-    float v100 = (bz1 & by0 & bx0) ? r10[cx0] : 0.f, v101 = (bz1 & by0 & bx1) ? r10[cx1] : 0.f;
-    float v110 = (bz1 & by1 & bx0) ? r11[cx0] : 0.f, v111 = (bz1 & by1 & bx1) ? r11[cx1] : 0.f;
-    return lerp3(v000, v001, v010, v011, v100, v101, v110, v111, tx, ty, tz);
+    return sample3_padded(mov, D, H, W, ix, iy, iz);
 }
 
 __device__ __forceinline__ Samp2 sample2(const float *__restrict__ mov, int H, int W, float ix, float iy)

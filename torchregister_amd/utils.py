@@ -213,11 +213,26 @@ class NMILoss(nn.Module):
         super().__init__()
         self.bins, self.alpha, self.patch, self.bandwidth = bins, alpha, patch_size, bandwidth
         self._cache = {}
+        self._lattice = {}
 
     def _patches(self, t):
         r = self.patch * 2
         nd = t.dim() - 2
-        t = F.interpolate(t, size=(r,) * nd, mode="nearest")
+        if t.is_cuda and t.requires_grad:
+            # Same values as F.interpolate(nearest) (the index tables come from that very call), but differentiated as a gather.
+            # ATen's DEVICE kernel for the nearest backward inverts the index map with its own float arithmetic and, for non-integer
+            # size ratios, hands some gradients to a neighbouring voxel (52 -> 20: output 5 reads input 13, its gradient lands on 12);
+            # the CPU kernel the reference runs on uses the forward index function both ways, as index_select's backward does.
+            from ._engine import nearest_lattice
+            key = (tuple(t.shape[2:]), r, t.device)
+            tabs = self._lattice.get(key)
+            if tabs is None:
+                tabs = self._lattice[key] = [i.long() for i in nearest_lattice(t.shape[2:], (r,) * nd, t.device)]
+            for d, tab in enumerate(tabs):
+                t = t.index_select(2 + d, tab)
+            t = t.contiguous()
+        else:
+            t = F.interpolate(t, size=(r,) * nd, mode="nearest")
         return t.view((2 ** nd) * t.shape[0] * t.shape[1], *([self.patch] * nd))
 
     def forward(self, y, yp):

@@ -175,10 +175,10 @@ def _nmi_fast_path(moving, target, criterions, weights, optimizer):
 
 def _nmi_affine_loop(moving, target, mode, spec, nmi, w_nmi, lr, epochs, init):
     """The loop of ref:warpings.py:67-93 / :138-159 for `fused terms + NMI` without autograd and without a host sync per iteration:
-      F1 step (lr = 0) -> loss and d/dtheta of the MSE / NCC / SSD terms;  HIP warp -> the NMI loss's 2^d patches -> Parzen PDFs (one
-      launch for the warped image's PDF and its half of the pooled one: both sample lines as 2 x bins "bins") -> trx_nmi_from_pdfs (loss
-      and d/dPDF) -> one PDF backward -> nearest-upsample backward -> HIP warp backward -> d/dtheta;  SGD on theta (rigid: Theta's
-      vector-Jacobian product, trx_theta_chain).
+      F1 step (lr = 0) -> loss and d/dtheta of the MSE / NCC / SSD terms;  the warp on the NMI loss's nearest-neighbour lattice only
+      (trx_affine_warp_lattice: the 2^d patches are 100^3 of e.g. 256^3 voxels) -> Parzen PDFs (one launch for the warped image's PDF
+      and its half of the pooled one: both sample lines as 2 x bins "bins") -> trx_nmi_from_pdfs (loss and d/dPDF) -> one PDF backward
+      -> trx_affine_warp_lattice_backward -> d/dtheta;  SGD on theta (rigid: Theta's vector-Jacobian product, trx_theta_chain).
     The reference builds each sample line from .item() extrema (ref:utils.py:40-48, two host syncs per PDF); here the extrema stay
     on the device (torch.lerp between them, the same line to an ulp).  The series form of the PDF kernels needs the window to be at
     least as wide as the value range: checked ONCE from the extrema of moving and target (a warped value is a convex combination of
@@ -218,30 +218,21 @@ def _nmi_affine_loop(moving, target, mode, spec, nmi, w_nmi, lr, epochs, init):
     h1 = _engine.kde_pdf(yq, torch.lerp(yhi, ylo, ramp), h, center)
     hist_loss = torch.zeros(max(1, epochs), device=dev)
     hist_theta = torch.zeros(max(1, epochs) + 1, _engine.PSTRIDE, device=dev)
-    grad_nmi = torch.zeros(1, _engine.PSTRIDE, device=dev)
     alpha = float(nmi.alpha) * float(w_nmi)
-    vol = fused.vol
-    ws, ws_bytes = fused.workspace, fused.ws_bytes
+    lattice = _engine.LatticeWarp(fused.vol, moving.shape[2:], size, dev)
     stream = _lib.current_stream(dev)
     for t in range(epochs):
         hist_theta[t].copy_(theta[0])
         if have_fused:
             fused.run(1)                                   # loss_f -> fused.losses[0, t], d/dtheta -> fused.grad (theta untouched: lr = 0)
-        warped = torch.empty_like(moving)
-        _lib.check(lib.trx_affine_warp(ctypes.byref(vol), _lib.ptr(theta), 1, _lib.ptr(warped), stream), "trx_affine_warp")
-        warped.requires_grad_()
-        with torch.enable_grad():
-            up = F.interpolate(warped, size=size, mode="nearest")
-        ypq = up.detach().view(npatch, -1)
+        ypq = lattice.forward(theta).view(npatch, -1)       # = F.interpolate(warp(theta, moving), size, "nearest"), evaluated on the lattice only
         plo, phi = torch.aminmax(ypq)
         xis = torch.cat([torch.lerp(phi, plo, ramp), torch.lerp(torch.maximum(phi, yhi), torch.minimum(plo, ylo), ramp)], dim=1)   # [P, 2 bins]
         pdf = _engine.kde_pdf(ypq, xis, h, center)          # warped: its own PDF | its half of the pooled PDF
         hj = 0.5 * (pdf[:, bins:] + _engine.kde_pdf(yq, xis[:, bins:].contiguous(), h, center))
         _, _, terms, (_, g2, gj) = _engine.nmi_from_pdfs(h1, pdf[:, :bins], hj, alpha)
         gs = _engine.kde_pdf_backward(ypq, xis, torch.cat([g2, 0.5 * gj], dim=1), h, center)
-        (gw,) = torch.autograd.grad(up, warped, gs.view_as(up))
-        _lib.check(lib.trx_affine_warp_backward(ctypes.byref(vol), _lib.ptr(theta), 1, _lib.ptr(gw), _lib.ptr(grad_nmi), _lib.ptr(ws), ws_bytes, stream),
-                   "trx_affine_warp_backward")
+        grad_nmi = lattice.backward(theta, gs.contiguous())
         total = terms.sum()
         g = grad_nmi
         if have_fused:
