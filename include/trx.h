@@ -142,7 +142,7 @@ int trx_affine_warp_backward(const trx_volumes *vol, const float *theta, int cha
  * F.interpolate(warped, size, mode="nearest") keeps of a full-volume warp (ref:utils.py:236-252: 100^3 of a 256^3 volume) when the
  * tables hold that call's source indices - and dtheta[B][TRX_PSTRIDE] = sum_k grad_out[B][k] * d out_k / d theta (replaces the
  * nearest-interpolate backward + grid_sampler backward + affine_grid backward of the same chain).  Single channel.
- * workspace (backward): at least max(trx_affine_workspace_bytes(vol), B * 2048 * 12 * sizeof(float)) bytes. */
+ * workspace (backward): at least max(trx_affine_workspace_bytes(vol), B * 1024 * 12 * sizeof(float)) bytes. */
 int trx_affine_warp_lattice(const trx_volumes *vol, const float *theta, const int *iz, int nz, const int *iy, int ny, const int *ix, int nx,
                             float *out, void *stream);
 int trx_affine_warp_lattice_backward(const trx_volumes *vol, const float *theta, const int *iz, int nz, const int *iy, int ny, const int *ix,
@@ -252,6 +252,10 @@ int trx_kde_pdf_series(const float *signals, const float *xis, int N, long S, in
                        void *workspace, size_t workspace_bytes, void *stream);
 int trx_kde_pdf_series_backward(const float *signals, const float *xis, const float *grad_pdf, int N, long S, int bins, float h,
                                 double center, float *grad_signals, void *workspace, size_t workspace_bytes, void *stream);
+/* The PDF of the SAME signals on another sample line without a second pass over them: `sums` = the workspace an earlier
+ * trx_kde_pdf_series(signals, ..., N, S, ..., center, ...) call left behind (the power sums live at its start; same N, S, center).  The NMI
+ * loss's pooled sample line moves with the warped image every iteration while the target's samples do not. */
+int trx_kde_pdf_series_cached(const void *sums, const float *xis, int N, long S, int bins, float h, double center, float *pdf, void *stream);
 
 /* The 256-bin algebra of the NMI loss behind the three PDFs (ref:utils.py:53-79 NMI, :224-259 NMILoss.forward) in one kernel, value and
  * gradient: h1 / h2 / hj [N][bins] = the Parzen "histograms" of target, warped and of the pooled samples (get_pdf, ref:utils.py:40-51).

@@ -578,6 +578,35 @@ def kde_series_center(signals, xis, h):
     return 0.5 * (lo + hi) if (hi - lo) <= float(h) else None
 
 
+class KdeSums:
+    """The power sums of a fixed set of signals [N,S] (series form about `center`), kept on the device: pdf(xis) for any number of sample
+    lines costs one small kernel each instead of a pass over the samples (include/trx.h: trx_kde_pdf_series_cached)."""
+
+    def __init__(self, signals, h, center):
+        self.lib = _lib.load()
+        sig = signals.detach().contiguous().float()
+        self.N, self.S = sig.shape
+        self.h, self.center = float(h), float(center)
+        dev = sig.device
+        ws_bytes = self.lib.trx_kde_series_workspace_bytes(self.N, self.S, 1)
+        self.ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        x0 = torch.full((self.N, 1), self.center, device=dev)
+        scratch = torch.empty(self.N, 1, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.trx_kde_pdf_series(_lib.ptr(sig), _lib.ptr(x0), self.N, self.S, 1, self.h, self.center, _lib.ptr(scratch), _lib.ptr(self.ws),
+                                             ws_bytes, _lib.current_stream(dev))
+        _lib.check(rc, "trx_kde_pdf_series")
+
+    def pdf(self, xis):
+        x = xis.detach().contiguous().float()
+        out = torch.empty(self.N, x.shape[1], device=x.device)
+        with torch.cuda.device(x.device):
+            rc = self.lib.trx_kde_pdf_series_cached(_lib.ptr(self.ws), _lib.ptr(x), self.N, self.S, x.shape[1], self.h, self.center, _lib.ptr(out),
+                                                    _lib.current_stream(x.device))
+        _lib.check(rc, "trx_kde_pdf_series_cached")
+        return out
+
+
 def kde_pdf(signals, xis, h, center=None):
     """Parzen-window PDF (include/trx.h: trx_kde_pdf / trx_kde_pdf_series): signals [N,S], xis [N,bins] fp32 on the GPU -> pdf [N,bins].
     center: None = one exponential per (sample, bin) pair; a float = the series form about that value (see kde_series_center)."""
@@ -646,7 +675,7 @@ class LatticeWarp:
         self.nz = self.size[0] if nd == 3 else 1
         self.ny, self.nx = self.size[-2], self.size[-1]
         self.n = self.nz * self.ny * self.nx
-        self.ws_bytes = max(int(self.lib.trx_affine_workspace_bytes(ctypes.byref(vol))), B * 2048 * 12 * 4)
+        self.ws_bytes = max(int(self.lib.trx_affine_workspace_bytes(ctypes.byref(vol))), B * 1024 * 12 * 4)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.dtheta = torch.zeros(B, PSTRIDE, device=dev)
 

@@ -2008,10 +2008,10 @@ static int check_lattice(const trx_volumes *vol, const int *iz, int nz, const in
     return TRX_OK;
 }
 
-static int lattice_blocks(size_t n)   // 4 lattice points per thread (gather latency is hidden by occupancy), at most 2048 blocks per pair (one partial row each)
+static int lattice_blocks(size_t n)   // 4 lattice points per thread and trip, at most 1024 blocks per pair (one partial row each: the finalise reads them all)
 {
     size_t nb = (n + (size_t)TRX_BLOCK * 4 - 1) / ((size_t)TRX_BLOCK * 4);
-    return (int)(nb < 1 ? 1 : (nb > 2048 ? 2048 : nb));
+    return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
 }
 
 extern "C" int trx_affine_warp_lattice(const trx_volumes *vol, const float *theta, const int *iz, int nz, const int *iy, int ny, const int *ix,

@@ -133,10 +133,24 @@ static int kde_ser_nchunk(long S);
 // which itself weighs < 1e-12 of the sum.  The backward is the same algebra: a degree-25 polynomial in t_i whose coefficients
 // come from the moments sum_k g_k (-y_k)^r of the incoming gradient.
 // ------------------------------------------------------------------------------------------------------------------------------
-constexpr int kSerChunk = 16384;        // samples per block of the power-sum pass (64 per thread: the 25 wave reductions are amortised)
+constexpr int kSerChunk = 8192;         // samples per block of the power-sum pass (32 per thread: the 25 wave reductions are amortised; 8 x 10^6 samples = 984 blocks)
 constexpr int kSerN = 12;               // highest series term
 constexpr int kSerP = 2 * kSerN + 1;    // power sums p_0 .. p_24
 constexpr int kSerQ = 2 * kSerN + 2;    // backward polynomial coefficients q_0 .. q_25
+
+// C(n, k) for n <= 25, exact in fp64 (Pascal's triangle at compile time: the kernels used to rebuild the coefficients with an fp64
+// division per term, which was most of their run time)
+struct BinomTable {
+    double v[kSerQ][kSerQ];
+    constexpr BinomTable() : v{}
+    {
+        for (int n = 0; n < kSerQ; n++) {
+            v[n][0] = 1.0;
+            for (int k = 1; k <= n; k++) v[n][k] = v[n - 1][k - 1] + (k <= n - 1 ? v[n - 1][k] : 0.0);
+        }
+    }
+};
+__device__ const BinomTable kBinom = BinomTable();
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -157,11 +171,16 @@ __global__ __launch_bounds__(256) void kde_powsum_kernel(const float *__restrict
 #pragma unroll
     for (int m = 0; m < kSerP; m++) acc[m] = 0.0;
     for (int i = tid; i < cnt; i += 256) {
-        const double t = (double)src[i] - center;
-        double pw = 1.0;
+        const double t = (double)src[i] - center, t2 = t * t;
+        double pe = 1.0, po = t;     // even and odd powers as two independent chains (half the dependent multiplies)
         acc[0] += 1.0;
 #pragma unroll
-        for (int m = 1; m < kSerP; m++) { pw *= t; acc[m] += pw; }
+        for (int m = 1; m < kSerP; m += 2) {
+            acc[m] += po;
+            pe *= t2;
+            acc[m + 1] += pe;
+            po *= t2;
+        }
     }
 #pragma unroll
     for (int m = 0; m < kSerP; m++) {
@@ -197,12 +216,11 @@ __global__ __launch_bounds__(1024) void kde_series_pdf_kernel(const double *__re
 #pragma unroll
         for (int r = 1; r < kSerP; r++) npw[r] = npw[r - 1] * ny;
         double res = 0.0, aj = 1.0;
-        for (int j = 0; j <= kSerN; j++) {
-            double sj = 0.0, coef = 1.0;   // C(2j, m), exact in fp64
-            for (int mm = 0; mm <= 2 * j; mm++) {
-                sj += coef * npw[2 * j - mm] * p[mm];
-                coef = coef * (double)(2 * j - mm) / (double)(mm + 1);
-            }
+#pragma unroll
+        for (int j = 0; j <= kSerN; j++) {   // fully unrolled: npw[] stays in registers, the binomials are constant-memory operands
+            double sj = 0.0;
+#pragma unroll
+            for (int mm = 0; mm <= 2 * j; mm++) sj += (kBinom.v[2 * j][mm] * npw[2 * j - mm]) * p[mm];
             res += aj * sj;
             aj *= -inv_2h2 / (double)(j + 1);
         }
@@ -239,11 +257,7 @@ __global__ __launch_bounds__(256) void kde_series_coef_kernel(const float *__res
         double qm = 0.0, aj = 1.0;
         for (int j = 0; j <= kSerN; j++) {
             const int nn = 2 * j + 1;
-            if (nn >= m) {
-                double coef = 1.0;   // C(nn, m)
-                for (int i = 0; i < m; i++) coef = coef * (double)(nn - i) / (double)(i + 1);
-                qm += aj * coef * G[nn - m];
-            }
+            if (nn >= m) qm += aj * kBinom.v[nn][m] * G[nn - m];
             aj *= -inv_2h2 / (double)(j + 1);
         }
         q[(long)n * kSerQ + m] = qm;
@@ -326,6 +340,17 @@ extern "C" int trx_kde_pdf_series(const float *signals, const float *xis, int N,
     const double scale = 1.0 / ((double)h * (double)S * 6.283185307179586);
     hipLaunchKernelGGL(kde_series_pdf_kernel, dim3(N), dim3(1024), 0, s, (const double *)workspace, nchunk, xis, bins, center, 0.5 / ((double)h * (double)h),
                        scale, pdf);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+extern "C" int trx_kde_pdf_series_cached(const void *sums, const float *xis, int N, long S, int bins, float h, double center, float *pdf, void *stream)
+{
+    if (!sums || !xis || !pdf) return TRX_ERR_ARG;
+    if (N < 1 || N > 65535 || S < 1 || bins < 1 || bins > 1024 || !(h > 0.f)) return TRX_ERR_ARG;
+    const double scale = 1.0 / ((double)h * (double)S * 6.283185307179586);
+    hipLaunchKernelGGL(kde_series_pdf_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const double *)sums, kde_ser_nchunk(S), xis, bins, center,
+                       0.5 / ((double)h * (double)h), scale, pdf);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }

@@ -215,7 +215,8 @@ def _nmi_affine_loop(moving, target, mode, spec, nmi, w_nmi, lr, epochs, init):
     yq = patches(target)                                   # fixed target: patches, extrema and PDF once
     ylo, yhi = torch.aminmax(yq)
     ramp = (torch.arange(bins, device=dev, dtype=torch.float32) / (bins - 1)).expand(npatch, bins).contiguous()
-    h1 = _engine.kde_pdf(yq, torch.lerp(yhi, ylo, ramp), h, center)
+    ysums = _engine.KdeSums(yq, h, center)
+    h1 = ysums.pdf(torch.lerp(yhi, ylo, ramp))
     hist_loss = torch.zeros(max(1, epochs), device=dev)
     hist_theta = torch.zeros(max(1, epochs) + 1, _engine.PSTRIDE, device=dev)
     alpha = float(nmi.alpha) * float(w_nmi)
@@ -229,7 +230,7 @@ def _nmi_affine_loop(moving, target, mode, spec, nmi, w_nmi, lr, epochs, init):
         plo, phi = torch.aminmax(ypq)
         xis = torch.cat([torch.lerp(phi, plo, ramp), torch.lerp(torch.maximum(phi, yhi), torch.minimum(plo, ylo), ramp)], dim=1)   # [P, 2 bins]
         pdf = _engine.kde_pdf(ypq, xis, h, center)          # warped: its own PDF | its half of the pooled PDF
-        hj = 0.5 * (pdf[:, bins:] + _engine.kde_pdf(yq, xis[:, bins:].contiguous(), h, center))
+        hj = 0.5 * (pdf[:, bins:] + ysums.pdf(xis[:, bins:]))   # the target's power sums are computed once: only its polynomial moves with the line
         _, _, terms, (_, g2, gj) = _engine.nmi_from_pdfs(h1, pdf[:, :bins], hj, alpha)
         gs = _engine.kde_pdf_backward(ypq, xis, torch.cat([g2, 0.5 * gj], dim=1), h, center)
         grad_nmi = lattice.backward(theta, gs.contiguous())
