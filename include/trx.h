@@ -255,7 +255,8 @@ int trx_kde_pdf_series_backward(const float *signals, const float *xis, const fl
 /* The PDF of the SAME signals on another sample line without a second pass over them: `sums` = the workspace an earlier
  * trx_kde_pdf_series(signals, ..., N, S, ..., center, ...) call left behind (the power sums live at its start; same N, S, center).  The NMI
  * loss's pooled sample line moves with the warped image every iteration while the target's samples do not. */
-int trx_kde_pdf_series_cached(const void *sums, const float *xis, int N, long S, int bins, float h, double center, float *pdf, void *stream);
+int trx_kde_pdf_series_cached(const void *sums, const float *xis, int xis_stride /* floats between rows of xis, >= bins */, int N, long S, int bins,
+                              float h, double center, float *pdf, void *stream);
 
 /* The 256-bin algebra of the NMI loss behind the three PDFs (ref:utils.py:53-79 NMI, :224-259 NMILoss.forward) in one kernel, value and
  * gradient: h1 / h2 / hj [N][bins] = the Parzen "histograms" of target, warped and of the pooled samples (get_pdf, ref:utils.py:40-51).
@@ -264,6 +265,28 @@ int trx_kde_pdf_series_cached(const void *sums, const float *xis, int N, long S,
  * Outputs (each may be NULL): nmi [N], mi [N], loss_terms [N], grad_h* [N][bins] = d loss / d h*. */
 int trx_nmi_from_pdfs(const float *h1, const float *h2, const float *hj, int N, int bins, float alpha, float *nmi, float *mi,
                       float *loss_terms, float *grad_h1, float *grad_h2, float *grad_hj, void *stream);
+
+/* The same algebra for the loop that evaluates the warped image's PDFs as ONE 2 x bins call (its own line | the pooled line): pdf_w
+ * [N][2 bins], pdf_t [N][bins] = the target's PDF on the pooled line; the pooled histogram is 0.5 (pdf_w[:, bins:] + pdf_t) (fp32, like
+ * the torch composition) and grad_w [N][2 bins] = [d loss / d h2 | 0.5 d loss / d hj] is what trx_kde_pdf_series_backward takes. */
+int trx_nmi_from_pdfs_pooled(const float *h1, const float *pdf_w, const float *pdf_t, int N, int bins, float alpha, float *nmi, float *mi,
+                             float *loss_terms, float *grad_w, void *stream);
+
+/* trx_affine_warp_lattice plus the NMI loss's two sample lines in the same call (ref:utils.py:40-48 get_pdf: linspace(max, min, bins)
+ * of the samples): out as trx_affine_warp_lattice; xis[B * patches][2 bins] = per pair the line between the extrema of ITS lattice
+ * values, then the line between the extrema of those and of minmax_target[B][2] = (min, max) of the target's samples;
+ * minmax_warped[B][2] (nullable) receives the warped extrema.  Replaces torch.aminmax + 2 lerp + maximum + minimum + cat per iteration.
+ * workspace: B * 8192 * 2 * sizeof(float) bytes. */
+int trx_nmi_lattice_lines(const trx_volumes *vol, const float *theta, const int *iz, int nz, const int *iy, int ny, const int *ix, int nx,
+                          float *out, const float *minmax_target, int patches, int bins, float *xis, float *minmax_warped, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* Tail of one iteration of a loop that assembles dL/dtheta itself (ref:warpings.py:80-93 / :146-159 after error.backward()), one pair:
+ * *hist_loss_t = sum(loss_terms[0 .. n_terms)) + *loss_b (nullable); hist_theta_t[TRX_PSTRIDE] = theta (of this forward);
+ * g = grad_a + grad_b (nullable); pose == NULL: theta -= lr g (affine SGD), else pose -= lr J(pose)^T g and theta = Theta(pose)
+ * (rigid, as trx_theta_chain); param_copy[TRX_PSTRIDE] (nullable) = the new theta. */
+int trx_nmi_loop_update(int ndim, float *theta, float *pose, const float *grad_a, const float *grad_b, float lr, const float *loss_terms,
+                        int n_terms, const float *loss_b, float *hist_loss_t, float *hist_theta_t, float *param_copy, void *stream);
 
 #ifdef __cplusplus
 }

@@ -131,3 +131,100 @@ def test_nmi_patches_gradient_is_the_gather_adjoint():
     (F.interpolate(xd, size=(20, 20, 20), mode="nearest").reshape(p.shape) * w).sum().backward()
     if torch.equal(xd.grad.cpu(), xc.grad):
         pytest.skip("this ATen build's device nearest-backward agrees with the CPU kernel: the gather work-around is no longer needed")
+
+
+def test_kde_series_cached_sums_and_strided_lines():
+    """trx_kde_pdf_series_cached: the PDF of the same samples on another (possibly strided) sample line from the power sums an earlier
+    call left behind = a fresh trx_kde_pdf_series call, bit for bit (same kernel, same sums)."""
+    import torchregister_amd._engine as eng
+    g = torch.Generator().manual_seed(5)
+    sig = (torch.rand(4, 20000, generator=g) * 0.9 + 0.05).cuda()
+    h, center = 3.0, 0.5
+    sums = eng.KdeSums(sig, h, center)
+    wide = torch.rand(4, 2 * 64, generator=g).cuda()
+    for xis in (wide[:, :64], wide[:, 64:], wide):
+        want = eng.kde_pdf(sig, xis.contiguous(), h, center)
+        assert torch.equal(sums.pdf(xis), want)
+
+
+def test_nmi_from_pdfs_pooled_equals_manual_pooling():
+    import torchregister_amd._engine as eng
+    g = torch.Generator().manual_seed(6)
+    N, bins = 8, 256
+    h1 = (torch.rand(N, bins, generator=g) + 0.1).cuda()
+    pdf_w = (torch.rand(N, 2 * bins, generator=g) + 0.1).cuda()
+    pdf_t = (torch.rand(N, bins, generator=g) + 0.1).cuda()
+    terms, gw = eng.nmi_from_pdfs_pooled(h1, pdf_w, pdf_t, 0.7)
+    hj = 0.5 * (pdf_w[:, bins:] + pdf_t)
+    _, _, terms2, (_, g2, gj) = eng.nmi_from_pdfs(h1, pdf_w[:, :bins].contiguous(), hj, 0.7)
+    assert torch.equal(terms, terms2)
+    assert torch.equal(gw, torch.cat([g2, 0.5 * gj], dim=1))
+
+
+@pytest.mark.parametrize("spatial,size", [((40, 36, 52), (20, 20, 20)), ((33, 57), (50, 16))])
+def test_nmi_lattice_lines_vs_torch_composition(spatial, size):
+    """trx_nmi_lattice_lines: the lattice values equal trx_affine_warp_lattice's and the two sample lines equal aminmax + lerp +
+    maximum / minimum + cat of the torch composition (to an ulp of the line's span: the device may contract a + w * d)."""
+    import torchregister_amd._engine as eng
+    nd = len(spatial)
+    mov = ph.vol(spatial, 0.37, "sin").cuda() * 0.5 + 0.5
+    th = torch.tensor([[1.02, 0.03, -0.02, 0.05], [-0.03, 0.98, 0.02, -0.04], [0.01, -0.02, 1.03, 0.02]] if nd == 3 else [[1.01, 0.04, 0.03], [-0.05, 0.97, -0.02]])
+    thp = eng.pad_theta(th.reshape(1, -1).cuda(), nd)
+    vol = eng._Batch(mov, mov).vol()
+    lat = eng.LatticeWarp(vol, spatial, size, mov.device)
+    P, bins = 2 ** nd, 256
+    for tlo, thi in ((0.2, 0.7), (-0.5, 1.5)):      # target extrema inside / outside the warped range
+        mm_t = torch.tensor([[tlo, thi]], device="cuda")
+        vals, xis = lat.forward_lines(thp, mm_t, P, bins)
+        assert torch.equal(vals, lat.forward(thp))
+        plo, phi = torch.aminmax(vals)
+        ramp = (torch.arange(bins, device="cuda", dtype=torch.float32) / (bins - 1)).expand(P, bins).contiguous()
+        want = torch.cat([torch.lerp(phi, plo, ramp), torch.lerp(torch.maximum(phi, mm_t[0, 1]), torch.minimum(plo, mm_t[0, 0]), ramp)], dim=1)
+        assert xis.shape == want.shape
+        assert torch.max(torch.abs(xis - want)).item() <= 2.5e-7 * max(1.0, thi - tlo)
+        assert xis[0, 0].item() == phi.item() and xis[0, bins - 1].item() == plo.item()   # the end points are the extrema themselves
+
+
+@pytest.mark.parametrize("nd,rigid", [(3, False), (3, True), (2, False), (2, True)])
+def test_nmi_loop_update_vs_torch_ops(nd, rigid):
+    """trx_nmi_loop_update = hist_theta[t] <- theta; loss <- sum(terms) + fused loss; theta <- theta - lr (g_a + g_b)  (rigid: through
+    trx_theta_chain, as the loop did with separate launches before)."""
+    import ctypes
+    import torchregister_amd._engine as eng
+    from torchregister_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(10 * nd + rigid)
+    PS = eng.PSTRIDE
+    nt, npose = nd * (nd + 1), (6 if nd == 3 else 3)
+    pose = torch.zeros(1, PS, device="cuda"); pose[0, :npose] = (torch.rand(npose, generator=g) * 0.5).cuda()
+    theta = torch.zeros(1, PS, device="cuda")
+    if rigid:
+        _lib.check(lib.trx_theta_chain(_lib.ptr(pose), None, nd, 1, _lib.ptr(theta), None, None), "chain")
+    else:
+        theta[0, :nt] = (torch.eye(nd, nd + 1).reshape(-1) + 0.05 * torch.rand(nt, generator=g)).cuda()
+    ga, gb = torch.zeros(1, PS, device="cuda"), torch.zeros(1, PS, device="cuda")
+    ga[0, :nt] = torch.randn(nt, generator=g).cuda(); gb[0, :nt] = torch.randn(nt, generator=g).cuda()
+    terms = torch.rand(2 ** nd, generator=g).cuda()
+    loss_b = torch.rand(1, generator=g).cuda()
+    lr = 0.013
+    # expected, with the separate launches the loop used before
+    want_loss = terms.sum() + loss_b[0]
+    gsum = ga + gb
+    if rigid:
+        dpose, p2, th2 = torch.zeros_like(pose), pose.clone(), torch.zeros_like(theta)
+        _lib.check(lib.trx_theta_chain(_lib.ptr(pose), _lib.ptr(gsum), nd, 1, None, _lib.ptr(dpose), None), "chain")
+        p2.sub_(dpose, alpha=lr)
+        _lib.check(lib.trx_theta_chain(_lib.ptr(p2), None, nd, 1, _lib.ptr(th2), None, None), "chain")
+    else:
+        th2 = theta - lr * gsum
+    th_before = theta.clone()
+    hist_loss, hist_theta, param = torch.zeros(1, device="cuda"), torch.zeros(PS, device="cuda"), torch.zeros(1, PS, device="cuda")
+    _lib.check(lib.trx_nmi_loop_update(nd, _lib.ptr(theta), _lib.ptr(pose) if rigid else None, _lib.ptr(ga), _lib.ptr(gb), lr, _lib.ptr(terms), 2 ** nd,
+                                       _lib.ptr(loss_b), _lib.ptr(hist_loss), _lib.ptr(hist_theta), _lib.ptr(param), None), "update")
+    torch.cuda.synchronize()
+    assert torch.equal(hist_theta, th_before[0])
+    assert abs(hist_loss.item() - want_loss.item()) <= 1e-6 * abs(want_loss.item())
+    assert torch.max(torch.abs(theta[0, :nt] - th2[0, :nt])).item() <= 2e-7
+    assert torch.equal(param, theta)
+    if rigid:
+        assert torch.max(torch.abs(pose - p2)).item() <= 1e-7

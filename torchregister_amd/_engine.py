@@ -598,11 +598,14 @@ class KdeSums:
         _lib.check(rc, "trx_kde_pdf_series")
 
     def pdf(self, xis):
-        x = xis.detach().contiguous().float()
+        """xis [N, bins] fp32, rows may be strided (a column slice of a wider matrix is read in place)."""
+        x = xis.detach()
+        if x.dtype != torch.float32 or x.stride(1) != 1:
+            x = x.contiguous().float()
         out = torch.empty(self.N, x.shape[1], device=x.device)
         with torch.cuda.device(x.device):
-            rc = self.lib.trx_kde_pdf_series_cached(_lib.ptr(self.ws), _lib.ptr(x), self.N, self.S, x.shape[1], self.h, self.center, _lib.ptr(out),
-                                                    _lib.current_stream(x.device))
+            rc = self.lib.trx_kde_pdf_series_cached(_lib.ptr(self.ws), x.data_ptr(), int(x.stride(0)), self.N, self.S, x.shape[1], self.h, self.center,
+                                                    _lib.ptr(out), _lib.current_stream(x.device))
         _lib.check(rc, "trx_kde_pdf_series_cached")
         return out
 
@@ -675,7 +678,7 @@ class LatticeWarp:
         self.nz = self.size[0] if nd == 3 else 1
         self.ny, self.nx = self.size[-2], self.size[-1]
         self.n = self.nz * self.ny * self.nx
-        self.ws_bytes = max(int(self.lib.trx_affine_workspace_bytes(ctypes.byref(vol))), B * 1024 * 12 * 4)
+        self.ws_bytes = max(int(self.lib.trx_affine_workspace_bytes(ctypes.byref(vol))), B * 1024 * 12 * 4, B * 8192 * 2 * 4)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.dtheta = torch.zeros(B, PSTRIDE, device=dev)
 
@@ -687,6 +690,18 @@ class LatticeWarp:
         _lib.check(rc, "trx_affine_warp_lattice")
         return out
 
+    def forward_lines(self, theta, minmax_target, patches, bins):
+        """forward() plus the NMI loss's two sample lines (include/trx.h: trx_nmi_lattice_lines): returns (values [B, n], xis
+        [B * patches, 2 * bins]); minmax_target [B, 2] = (min, max) of the target's samples."""
+        out = torch.empty(self.B, self.n, device=theta.device)
+        xis = torch.empty(self.B * patches, 2 * bins, device=theta.device)
+        with torch.cuda.device(theta.device):
+            rc = self.lib.trx_nmi_lattice_lines(ctypes.byref(self.vol), _lib.ptr(theta), _lib.ptr(self.iz), self.nz, _lib.ptr(self.iy), self.ny,
+                                                _lib.ptr(self.ix), self.nx, _lib.ptr(out), _lib.ptr(minmax_target), int(patches), int(bins), _lib.ptr(xis),
+                                                None, _lib.ptr(self.ws), self.ws_bytes, _lib.current_stream(theta.device))
+        _lib.check(rc, "trx_nmi_lattice_lines")
+        return out, xis
+
     def backward(self, theta, grad_out):
         """grad_out [B, n] (contiguous fp32) -> dL/dtheta [B, PSTRIDE] (a buffer owned by this object, overwritten by the next call)."""
         with torch.cuda.device(theta.device):
@@ -695,6 +710,20 @@ class LatticeWarp:
                                                            _lib.ptr(self.ws), self.ws_bytes, _lib.current_stream(theta.device))
         _lib.check(rc, "trx_affine_warp_lattice_backward")
         return self.dtheta
+
+
+def nmi_from_pdfs_pooled(h1, pdf_w, pdf_t, alpha):
+    """include/trx.h: trx_nmi_from_pdfs_pooled - h1 [N,bins], pdf_w [N,2 bins] (own line | pooled line), pdf_t [N,bins] (target on the pooled
+    line), all contiguous fp32 on the GPU.  Returns (loss_terms [N], grad_w [N, 2 bins])."""
+    lib = _lib.load()
+    N, bins = h1.shape
+    terms = torch.empty(N, device=h1.device)
+    grad = torch.empty(N, 2 * bins, device=h1.device)
+    with torch.cuda.device(h1.device):
+        rc = lib.trx_nmi_from_pdfs_pooled(_lib.ptr(h1), _lib.ptr(pdf_w), _lib.ptr(pdf_t), N, bins, float(alpha), None, None, _lib.ptr(terms), _lib.ptr(grad),
+                                          _lib.current_stream(h1.device))
+    _lib.check(rc, "trx_nmi_from_pdfs_pooled")
+    return terms, grad
 
 
 def nmi_from_pdfs(h1, h2, hj, alpha, need_grad=True):

@@ -98,7 +98,11 @@ SIGNATURES = {
     "trx_kde_pdf_series": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_double, _P, _P, ctypes.c_size_t, _P]),
     "trx_kde_pdf_series_backward": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_double, _P, _P,
                                                    ctypes.c_size_t, _P]),
-    "trx_kde_pdf_series_cached": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_double, _P, _P]),
+    "trx_kde_pdf_series_cached": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_double, _P, _P]),
+    "trx_nmi_from_pdfs_pooled": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P, _P, _P, _P, _P]),
+    "trx_nmi_lattice_lines": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, _P, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P, _P, ctypes.c_int,
+                                             ctypes.c_int, _P, _P, _P, ctypes.c_size_t, _P]),
+    "trx_nmi_loop_update": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, ctypes.c_float, _P, ctypes.c_int, _P, _P, _P, _P, _P]),
     "trx_nmi_from_pdfs": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "trx_lncc_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "trx_lncc_loss_grad": (ctypes.c_int, [_P, _P] + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_float, _P, _P, _P, ctypes.c_size_t, _P]),

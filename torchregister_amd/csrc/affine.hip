@@ -1612,7 +1612,7 @@ __device__ __forceinline__ void lattice_coords(const trx_volumes &vol, const flo
 // thread pays ~3 latencies per four points instead of twelve.  BWD = false: out[b][k] = warped value; BWD = true: acc += go[k] * J_k.
 template <int ND, bool BWD>
 __device__ __forceinline__ void lattice_pass(const trx_volumes &vol, const float *__restrict__ th, const float *__restrict__ mov, const LatticeIdx &L,
-                                             const float *__restrict__ go, float *__restrict__ out, float (&acc)[ND * (ND + 1)])
+                                             const float *__restrict__ go, float *__restrict__ out, float (&acc)[ND * (ND + 1)], float &vmin, float &vmax)
 {
     constexpr int U = 4;
     const unsigned n = (unsigned)L.nz * L.ny * L.nx;   // < 2^31 (checked by the caller): 32-bit index arithmetic
@@ -1648,7 +1648,7 @@ __device__ __forceinline__ void lattice_pass(const trx_volumes &vol, const float
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if constexpr (!BWD) {
-                if (ok[u]) out[idx[u]] = v[u];
+                if (ok[u]) { out[idx[u]] = v[u]; vmin = fminf(vmin, v[u]); vmax = fmaxf(vmax, v[u]); }
             } else {
                 const float w = ok[u] ? g[u] : 0.f;
 #pragma unroll
@@ -1666,12 +1666,109 @@ __device__ __forceinline__ void lattice_pass(const trx_volumes &vol, const float
 
 template <int ND>
 __global__ __launch_bounds__(TRX_BLOCK) void affine_warp_lattice_kernel(trx_volumes vol, const float *__restrict__ theta, LatticeIdx L,
-                                                                        float *__restrict__ out)
+                                                                        float *__restrict__ out, float *__restrict__ block_minmax)
 {
     const int b = blockIdx.y;
     const size_t n = (size_t)L.nz * L.ny * L.nx;
     float acc[ND * (ND + 1)];
-    lattice_pass<ND, false>(vol, theta + (size_t)b * TRX_PSTRIDE, vol.moving + (size_t)b * vol.moving_stride, L, nullptr, out + (size_t)b * n, acc);
+    float vmin = INFINITY, vmax = -INFINITY;
+    lattice_pass<ND, false>(vol, theta + (size_t)b * TRX_PSTRIDE, vol.moving + (size_t)b * vol.moving_stride, L, nullptr, out + (size_t)b * n, acc, vmin, vmax);
+    if (block_minmax) {   // extrema of this block's values (the NMI sample lines run between the extrema of the warped samples): one pair per block
+        __shared__ float red[2][TRX_WAVES];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, m, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, m, 64)); }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = vmin; red[1][threadIdx.x >> 6] = vmax; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < TRX_WAVES; w++) { vmin = fminf(vmin, red[0][w]); vmax = fmaxf(vmax, red[1][w]); }
+            block_minmax[((size_t)b * gridDim.x + blockIdx.x) * 2 + 0] = vmin;
+            block_minmax[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = vmax;
+        }
+    }
+}
+
+// The two sample lines of the NMI loss for pair b's P patches (ref:utils.py:40-48 get_pdf: linspace(max, min, bins) of the samples the
+// PDF is taken of): line A between the extrema of the warped samples (reduced here from the lattice kernel's per-block pairs), line B
+// between the extrema of warped and target samples pooled; xis[b * P + p][0 .. bins) = A, [bins .. 2 bins) = B.  The points follow
+// torch.lerp's two-sided formula on the ramp k / (bins - 1), like the torch composition this replaces (aminmax, 2 x lerp, maximum,
+// minimum, cat: six launches).  mm_out[b] = (min, max) of the warped samples.
+__global__ __launch_bounds__(1024) void nmi_lines_kernel(const float *__restrict__ block_minmax, int nblk, const float *__restrict__ mm_target, int P, int bins,
+                                                         float *__restrict__ xis, float *__restrict__ mm_out)
+{
+    __shared__ float red[2][16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float vmin = INFINITY, vmax = -INFINITY;
+    for (int i = tid; i < nblk; i += 1024) {
+        vmin = fminf(vmin, block_minmax[((size_t)b * nblk + i) * 2 + 0]);
+        vmax = fmaxf(vmax, block_minmax[((size_t)b * nblk + i) * 2 + 1]);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { vmin = fminf(vmin, __shfl_xor(vmin, m, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, m, 64)); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = vmin; red[1][tid >> 6] = vmax; }
+    __syncthreads();
+    vmin = red[0][0]; vmax = red[1][0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) { vmin = fminf(vmin, red[0][w]); vmax = fmaxf(vmax, red[1][w]); }
+    const float tlo = mm_target[b * 2 + 0], thi = mm_target[b * 2 + 1];
+    const float lo2 = fminf(vmin, tlo), hi2 = fmaxf(vmax, thi);
+    if (tid == 0 && mm_out) { mm_out[b * 2 + 0] = vmin; mm_out[b * 2 + 1] = vmax; }
+    auto lerp = [](float start, float end, float w) { const float d = end - start; return (fabsf(w) < 0.5f) ? start + w * d : end - d * (1.0f - w); };
+    for (int i = tid; i < P * 2 * bins; i += 1024) {
+        const int p = i / (2 * bins), k = i - p * 2 * bins;
+        const bool second = k >= bins;
+        const float w = (float)(second ? k - bins : k) / (float)(bins - 1);
+        xis[((size_t)b * P + p) * 2 * bins + k] = second ? lerp(hi2, lo2, w) : lerp(vmax, vmin, w);
+    }
+}
+
+// The tail of one iteration of the default-criterion loop (ref:warpings.py:80-93 / :146-159 after error.backward()): the loss of this
+// iteration = sum of the NMI terms + the fused terms' loss, the theta of this forward into the history, g = g_a + g_b, SGD on theta -
+// or, rigid, on the pose through Theta's vector-Jacobian product - and theta of the next forward into `param_copy` (the fused solver's
+// parameter).  One wave; replaces ~8 element-wise launches per iteration.
+template <int ND>
+__global__ __launch_bounds__(64) void nmi_loop_update_kernel(float *__restrict__ theta, float *__restrict__ pose, const float *__restrict__ g_a,
+                                                             const float *__restrict__ g_b, float lr, const float *__restrict__ loss_terms, int n_terms,
+                                                             const float *__restrict__ loss_b, float *__restrict__ hist_loss_t,
+                                                             float *__restrict__ hist_theta_t, float *__restrict__ param_copy)
+{
+    constexpr int NT = ND * (ND + 1), NPOSE = (ND == 3) ? 6 : 3;
+    const int i = threadIdx.x;
+    if (i == 0) {
+        float tot = 0.f;
+        for (int k = 0; k < n_terms; k++) tot += loss_terms[k];   // torch's terms.sum() of <= 8 values, then + the fused loss (fp32 like the composition)
+        if (loss_b) tot += *loss_b;
+        *hist_loss_t = tot;
+    }
+    const float th_i = (i < TRX_PSTRIDE) ? theta[i] : 0.f;
+    if (i < TRX_PSTRIDE) hist_theta_t[i] = th_i;
+    float gi = 0.f;
+    if (i < TRX_PSTRIDE) gi = g_a[i] + (g_b ? g_b[i] : 0.f);
+    float th_new = th_i;
+    if (pose) {
+        float p[NPOSE];
+        double g[NT], dx[NPOSE];
+#pragma unroll
+        for (int k = 0; k < NPOSE; k++) p[k] = pose[k];
+#pragma unroll
+        for (int k = 0; k < NT; k++) g[k] = (double)(g_a[k] + (g_b ? g_b[k] : 0.f));
+        pose_vjp<ND>(p, g, dx);
+#pragma unroll
+        for (int k = 0; k < NPOSE; k++) p[k] = p[k] - lr * (float)dx[k];   // pose.sub_(dpose, alpha = lr) on the fp32 dpose
+        double th[NT];
+        theta_from_pose<ND>(p, th);
+        double v = 0.0, pv = 0.0;
+#pragma unroll
+        for (int k = 0; k < NT; k++) v = (k == i) ? th[k] : v;
+#pragma unroll
+        for (int k = 0; k < NPOSE; k++) pv = (k == i) ? (double)p[k] : pv;
+        if (i < NT) th_new = (float)v;
+        __syncthreads();   // every lane has read the old pose
+        if (i < NPOSE) pose[i] = (float)pv;
+    } else if (i < NT) {
+        th_new = th_i - lr * gi;                                   // theta.sub_(g, alpha = lr)
+    }
+    if (i < TRX_PSTRIDE) { theta[i] = th_new; if (param_copy) param_copy[i] = th_new; }
 }
 
 template <int ND>
@@ -1684,7 +1781,8 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_lattice_bwd_kernel(trx_volum
     float acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[t] = 0.f;
-    lattice_pass<ND, true>(vol, theta + (size_t)b * TRX_PSTRIDE, vol.moving + (size_t)b * vol.moving_stride, L, grad_out + (size_t)b * n, nullptr, acc);
+    float vmin = 0.f, vmax = 0.f;
+    lattice_pass<ND, true>(vol, theta + (size_t)b * TRX_PSTRIDE, vol.moving + (size_t)b * vol.moving_stride, L, grad_out + (size_t)b * n, nullptr, acc, vmin, vmax);
     block_reduce_store<NT>(acc, partials + ((size_t)b * gridDim.x + blockIdx.x) * NT);
 }
 
@@ -2014,6 +2112,21 @@ static int lattice_blocks(size_t n)   // 4 lattice points per thread and trip, a
     return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
 }
 
+static unsigned lattice_fwd_blocks(size_t n)
+{
+    size_t nb = (n + (size_t)TRX_BLOCK * 4 - 1) / ((size_t)TRX_BLOCK * 4);
+    return (unsigned)(nb > 8192 ? 8192 : nb);
+}
+
+static int launch_lattice_fwd(const trx_volumes *vol, const float *theta, const LatticeIdx &L, float *out, float *block_minmax, hipStream_t s)
+{
+    dim3 grid(lattice_fwd_blocks((size_t)L.nz * L.ny * L.nx), vol->B), block(TRX_BLOCK);
+    if (vol->ndim == 3) hipLaunchKernelGGL((affine_warp_lattice_kernel<3>), grid, block, 0, s, *vol, theta, L, out, block_minmax);
+    else hipLaunchKernelGGL((affine_warp_lattice_kernel<2>), grid, block, 0, s, *vol, theta, L, out, block_minmax);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
 extern "C" int trx_affine_warp_lattice(const trx_volumes *vol, const float *theta, const int *iz, int nz, const int *iy, int ny, const int *ix,
                                        int nx, float *out, void *stream)
 {
@@ -2021,14 +2134,38 @@ extern "C" int trx_affine_warp_lattice(const trx_volumes *vol, const float *thet
     if (rc) return rc;
     if (!theta || !out) return TRX_ERR_ARG;
     if ((rc = check_lattice(vol, iz, nz, iy, ny, ix, nx)) != TRX_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    const size_t n = (size_t)nz * ny * nx;
-    size_t nb = (n + (size_t)TRX_BLOCK * 4 - 1) / ((size_t)TRX_BLOCK * 4);
-    if (nb > 8192) nb = 8192;
     const LatticeIdx L = {iz, iy, ix, nz, ny, nx};
-    dim3 grid((unsigned)nb, vol->B), block(TRX_BLOCK);
-    if (vol->ndim == 3) hipLaunchKernelGGL((affine_warp_lattice_kernel<3>), grid, block, 0, s, *vol, theta, L, out);
-    else hipLaunchKernelGGL((affine_warp_lattice_kernel<2>), grid, block, 0, s, *vol, theta, L, out);
+    return launch_lattice_fwd(vol, theta, L, out, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int trx_nmi_lattice_lines(const trx_volumes *vol, const float *theta, const int *iz, int nz, const int *iy, int ny, const int *ix, int nx,
+                                     float *out, const float *minmax_target, int patches, int bins, float *xis, float *minmax_warped, void *workspace,
+                                     size_t workspace_bytes, void *stream)
+{
+    int rc = check_vol(vol, false);
+    if (rc) return rc;
+    if (!theta || !out || !minmax_target || !xis || !workspace || patches < 1 || bins < 2 || bins > 1024) return TRX_ERR_ARG;
+    if ((rc = check_lattice(vol, iz, nz, iy, ny, ix, nx)) != TRX_OK) return rc;
+    const LatticeIdx L = {iz, iy, ix, nz, ny, nx};
+    const unsigned nblk = lattice_fwd_blocks((size_t)nz * ny * nx);
+    if (workspace_bytes < (size_t)vol->B * nblk * 2 * sizeof(float)) return TRX_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = launch_lattice_fwd(vol, theta, L, out, (float *)workspace, s)) != TRX_OK) return rc;
+    hipLaunchKernelGGL(nmi_lines_kernel, dim3(vol->B), dim3(1024), 0, s, (const float *)workspace, (int)nblk, minmax_target, patches, bins, xis, minmax_warped);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+extern "C" int trx_nmi_loop_update(int ndim, float *theta, float *pose, const float *grad_a, const float *grad_b, float lr, const float *loss_terms,
+                                   int n_terms, const float *loss_b, float *hist_loss_t, float *hist_theta_t, float *param_copy, void *stream)
+{
+    if ((ndim != 2 && ndim != 3)) return TRX_ERR_NDIM;
+    if (!theta || !grad_a || !loss_terms || n_terms < 1 || !hist_loss_t || !hist_theta_t) return TRX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (ndim == 3) hipLaunchKernelGGL((nmi_loop_update_kernel<3>), dim3(1), dim3(64), 0, s, theta, pose, grad_a, grad_b, lr, loss_terms, n_terms, loss_b,
+                                      hist_loss_t, hist_theta_t, param_copy);
+    else hipLaunchKernelGGL((nmi_loop_update_kernel<2>), dim3(1), dim3(64), 0, s, theta, pose, grad_a, grad_b, lr, loss_terms, n_terms, loss_b, hist_loss_t,
+                            hist_theta_t, param_copy);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }

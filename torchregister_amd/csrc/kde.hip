@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void kde_powsum_kernel(const float *__restrict
 
 // pdf[n][k] = scale * sum_j a_j sum_m C(2j, m) (-y_k)^{2j-m} p_m
 __global__ __launch_bounds__(1024) void kde_series_pdf_kernel(const double *__restrict__ partial, int nchunk, const float *__restrict__ xis, int bins,
-                                                              double center, double inv_2h2, double scale, float *__restrict__ pdf)
+                                                              double center, double inv_2h2, double scale, float *__restrict__ pdf, int xis_stride)
 {
     __shared__ double acc[32][kSerP], p[kSerP];
     const int n = blockIdx.x, tid = threadIdx.x, m = tid & 31, g = tid >> 5;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(1024) void kde_series_pdf_kernel(const double *__re
     }
     __syncthreads();
     for (int k = tid; k < bins; k += 1024) {
-        const double ny = center - (double)xis[(long)n * bins + k];   // -y
+        const double ny = center - (double)xis[(long)n * xis_stride + k];   // -y
         double npw[kSerP];
         npw[0] = 1.0;
 #pragma unroll
@@ -339,18 +339,19 @@ extern "C" int trx_kde_pdf_series(const float *signals, const float *xis, int N,
     TRX_CHECK_LAUNCH();
     const double scale = 1.0 / ((double)h * (double)S * 6.283185307179586);
     hipLaunchKernelGGL(kde_series_pdf_kernel, dim3(N), dim3(1024), 0, s, (const double *)workspace, nchunk, xis, bins, center, 0.5 / ((double)h * (double)h),
-                       scale, pdf);
+                       scale, pdf, bins);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
 
-extern "C" int trx_kde_pdf_series_cached(const void *sums, const float *xis, int N, long S, int bins, float h, double center, float *pdf, void *stream)
+extern "C" int trx_kde_pdf_series_cached(const void *sums, const float *xis, int xis_stride, int N, long S, int bins, float h, double center, float *pdf,
+                                         void *stream)
 {
-    if (!sums || !xis || !pdf) return TRX_ERR_ARG;
+    if (!sums || !xis || !pdf || xis_stride < bins) return TRX_ERR_ARG;
     if (N < 1 || N > 65535 || S < 1 || bins < 1 || bins > 1024 || !(h > 0.f)) return TRX_ERR_ARG;
     const double scale = 1.0 / ((double)h * (double)S * 6.283185307179586);
     hipLaunchKernelGGL(kde_series_pdf_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, (const double *)sums, kde_ser_nchunk(S), xis, bins, center,
-                       0.5 / ((double)h * (double)h), scale, pdf);
+                       0.5 / ((double)h * (double)h), scale, pdf, xis_stride);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
 }
@@ -381,14 +382,27 @@ namespace trx {
 // In torch this is ~25 element-wise / reduction launches forward and ~40 backward on [N, 256] tensors (N = 4 or 8 patches): at 128^3
 // the default criterion was host-bound on them.  One block per patch, thread k owns bin k, fp64 throughout (|NMI - 1| of nearly flat
 // PDFs amplifies relative errors by ~1e4).
+// `hjb` != nullptr: the pooled histogram is 0.5 (hj + hjb) (the NMI loss pools warped and target samples: the warped image's half
+// arrives as the second half of its own 2 x bins evaluation, the target's half from its cached power sums) and d loss / d hj is
+// scaled by `gj_scale` (0.5: the gradient wrt the warped half).  s2 / sj / sg2 / sgj: row strides of h2, hj, g2, gj in floats.
 __global__ __launch_bounds__(256) void nmi_algebra_kernel(const float *__restrict__ h1, const float *__restrict__ h2, const float *__restrict__ hj, int N, int bins,
                                                           double alpha, double eps, float *__restrict__ nmi_out, float *__restrict__ mi_out,
-                                                          float *__restrict__ loss_terms, float *__restrict__ g1, float *__restrict__ g2, float *__restrict__ gj)
+                                                          float *__restrict__ loss_terms, float *__restrict__ g1, float *__restrict__ g2, float *__restrict__ gj,
+                                                          const float *__restrict__ hjb = nullptr, int s2 = 0, int sj = 0, int sg2 = 0, int sgj = 0,
+                                                          double gj_scale = 1.0)
 {
     __shared__ double red[3][4];
     __shared__ double tot[3];
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *hs[3] = {h1 + (size_t)n * bins, h2 + (size_t)n * bins, hj + (size_t)n * bins};
+    if (s2 == 0) s2 = bins;
+    if (sj == 0) sj = bins;
+    if (sg2 == 0) sg2 = bins;
+    if (sgj == 0) sgj = bins;
+    const float *hs[3] = {h1 + (size_t)n * bins, h2 + (size_t)n * s2, hj + (size_t)n * sj};
+    const float *hb = hjb ? hjb + (size_t)n * bins : nullptr;
+    auto hval = [&](int q, int k) -> double {   // fp32 pooling like the torch composition: 0.5 * (a + b)
+        return (q == 2 && hb) ? (double)(0.5f * (hs[2][k] + hb[k])) : (double)hs[q][k];
+    };
     // fixed-order block reduction of three values per thread (bins <= 1024: a thread owns bins tid, tid + 256, ...)
     auto reduce3 = [&](double a, double b, double c, double *out) {
         double v[3] = {a, b, c};
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(256) void nmi_algebra_kernel(const float *__restric
         double a[3] = {0, 0, 0};
         for (int k = tid; k < bins; k += 256)
 #pragma unroll
-            for (int q = 0; q < 3; q++) a[q] += (double)hs[q][k];
+            for (int q = 0; q < 3; q++) a[q] += hval(q, k);
         reduce3(a[0], a[1], a[2], s);
     }
     const double inv_ln2 = 1.4426950408889634;
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(256) void nmi_algebra_kernel(const float *__restric
         for (int k = tid; k < bins; k += 256)
 #pragma unroll
             for (int q = 0; q < 3; q++) {
-                const double p = (double)hs[q][k] / s[q];
+                const double p = hval(q, k) / s[q];
                 const double lg = log2(p + eps);
                 a[q] += p * lg;
                 bsum[q] += p * (lg + p / (p + eps) * inv_ln2);
@@ -431,14 +445,15 @@ __global__ __launch_bounds__(256) void nmi_algebra_kernel(const float *__restric
     const double dl = alpha * ((nmi > 1.0) ? 1.0 : ((nmi < 1.0) ? -1.0 : 0.0)) / (double)N;   // d loss / d NMI_n (torch.abs: 0 at 0)
     const double dn12 = 2.0 * e[2] / (e12 * e12), dnj = -2.0 / e12;
     const double w[3] = {dl * dn12 / s[0], dl * dn12 / s[1], dl * dnj / s[2]};
-    float *gs[3] = {g1 ? g1 + (size_t)n * bins : nullptr, g2 ? g2 + (size_t)n * bins : nullptr, gj ? gj + (size_t)n * bins : nullptr};
+    float *gs[3] = {g1 ? g1 + (size_t)n * bins : nullptr, g2 ? g2 + (size_t)n * sg2 : nullptr, gj ? gj + (size_t)n * sgj : nullptr};
+    const double gsc[3] = {1.0, 1.0, gj_scale};
     for (int k = tid; k < bins; k += 256)
 #pragma unroll
         for (int q = 0; q < 3; q++)
             if (gs[q]) {
-                const double p = (double)hs[q][k] / s[q];
+                const double p = hval(q, k) / s[q];
                 const double L = log2(p + eps) + p / (p + eps) * inv_ln2;
-                gs[q][k] = (float)(w[q] * (L - pl[q]));
+                gs[q][k] = (float)(gsc[q] * (double)(float)(w[q] * (L - pl[q])));
             }
     if (tid == 0) {
         if (nmi_out) nmi_out[n] = (float)nmi;
@@ -448,6 +463,17 @@ __global__ __launch_bounds__(256) void nmi_algebra_kernel(const float *__restric
 }
 
 }  // namespace trx
+
+extern "C" int trx_nmi_from_pdfs_pooled(const float *h1, const float *pdf_w, const float *pdf_t, int N, int bins, float alpha, float *nmi, float *mi,
+                                        float *loss_terms, float *grad_w, void *stream)
+{
+    if (!h1 || !pdf_w || !pdf_t || N < 1 || bins < 1 || bins > 1024) return TRX_ERR_ARG;
+    if (!nmi && !mi && !loss_terms && !grad_w) return TRX_ERR_ARG;
+    hipLaunchKernelGGL(trx::nmi_algebra_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, h1, pdf_w, pdf_w + bins, N, bins, (double)alpha, 1e-10, nmi, mi,
+                       loss_terms, (float *)nullptr, grad_w, grad_w ? grad_w + bins : nullptr, pdf_t, 2 * bins, 2 * bins, 2 * bins, 2 * bins, 0.5);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
 
 extern "C" int trx_nmi_from_pdfs(const float *h1, const float *h2, const float *hj, int N, int bins, float alpha, float *nmi, float *mi,
                                  float *loss_terms, float *grad_h1, float *grad_h2, float *grad_hj, void *stream)

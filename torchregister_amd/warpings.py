@@ -201,7 +201,6 @@ def _nmi_affine_loop(moving, target, mode, spec, nmi, w_nmi, lr, epochs, init):
     if rigid:
         pose = torch.zeros(1, _engine.PSTRIDE, device=dev)
         pose[0, :npose] = init.to(dev).float().reshape(-1)
-        dpose = torch.zeros_like(pose)
         _lib.check(lib.trx_theta_chain(_lib.ptr(pose), None, nd, 1, _lib.ptr(theta), None, _lib.current_stream(dev)), "trx_theta_chain")
     elif init is not None:
         theta.copy_(_engine.pad_theta(init.to(dev).reshape(1, nd, nd + 1), nd))
@@ -212,8 +211,9 @@ def _nmi_affine_loop(moving, target, mode, spec, nmi, w_nmi, lr, epochs, init):
     def patches(t):
         return F.interpolate(t, size=size, mode="nearest").view(npatch, -1)
 
-    yq = patches(target)                                   # fixed target: patches, extrema and PDF once
+    yq = patches(target)                                   # fixed target: patches, extrema, power sums and PDF once
     ylo, yhi = torch.aminmax(yq)
+    mm_target = torch.stack([ylo, yhi]).reshape(1, 2).contiguous()
     ramp = (torch.arange(bins, device=dev, dtype=torch.float32) / (bins - 1)).expand(npatch, bins).contiguous()
     ysums = _engine.KdeSums(yq, h, center)
     h1 = ysums.pdf(torch.lerp(yhi, ylo, ramp))
@@ -223,30 +223,21 @@ def _nmi_affine_loop(moving, target, mode, spec, nmi, w_nmi, lr, epochs, init):
     lattice = _engine.LatticeWarp(fused.vol, moving.shape[2:], size, dev)
     stream = _lib.current_stream(dev)
     for t in range(epochs):
-        hist_theta[t].copy_(theta[0])
         if have_fused:
             fused.run(1)                                   # loss_f -> fused.losses[0, t], d/dtheta -> fused.grad (theta untouched: lr = 0)
-        ypq = lattice.forward(theta).view(npatch, -1)       # = F.interpolate(warp(theta, moving), size, "nearest"), evaluated on the lattice only
-        plo, phi = torch.aminmax(ypq)
-        xis = torch.cat([torch.lerp(phi, plo, ramp), torch.lerp(torch.maximum(phi, yhi), torch.minimum(plo, ylo), ramp)], dim=1)   # [P, 2 bins]
+        # the warp on the NMI lattice (= F.interpolate(warp(theta, moving), size, "nearest")) and both sample lines: the warped image's
+        # own (max -> min of its samples) | the pooled one (extrema of warped and target samples)
+        vals, xis = lattice.forward_lines(theta, mm_target, npatch, bins)
+        ypq = vals.view(npatch, -1)
         pdf = _engine.kde_pdf(ypq, xis, h, center)          # warped: its own PDF | its half of the pooled PDF
-        hj = 0.5 * (pdf[:, bins:] + ysums.pdf(xis[:, bins:]))   # the target's power sums are computed once: only its polynomial moves with the line
-        _, _, terms, (_, g2, gj) = _engine.nmi_from_pdfs(h1, pdf[:, :bins], hj, alpha)
-        gs = _engine.kde_pdf_backward(ypq, xis, torch.cat([g2, 0.5 * gj], dim=1), h, center)
-        grad_nmi = lattice.backward(theta, gs.contiguous())
-        total = terms.sum()
-        g = grad_nmi
-        if have_fused:
-            total = total + fused.losses[0, t]
-            g = g + fused.grad
-        hist_loss[t] = total
-        if rigid:
-            _lib.check(lib.trx_theta_chain(_lib.ptr(pose), _lib.ptr(g), nd, 1, None, _lib.ptr(dpose), stream), "trx_theta_chain")
-            pose.sub_(dpose, alpha=lr)
-            _lib.check(lib.trx_theta_chain(_lib.ptr(pose), None, nd, 1, _lib.ptr(theta), None, stream), "trx_theta_chain")
-        else:
-            theta.sub_(g, alpha=lr)
-        fused.param.copy_(theta)
+        pdf_t = ysums.pdf(xis[:, bins:])                    # the target's half: only its polynomial moves with the line
+        terms, g_w = _engine.nmi_from_pdfs_pooled(h1, pdf, pdf_t, alpha)
+        gs = _engine.kde_pdf_backward(ypq, xis, g_w, h, center)
+        grad_nmi = lattice.backward(theta, gs)
+        _lib.check(lib.trx_nmi_loop_update(nd, _lib.ptr(theta), _lib.ptr(pose) if rigid else None, _lib.ptr(grad_nmi),
+                                           _lib.ptr(fused.grad) if have_fused else None, float(lr), _lib.ptr(terms), npatch,
+                                           _lib.ptr(fused.losses[0, t:]) if have_fused else None, _lib.ptr(hist_loss[t:]), _lib.ptr(hist_theta[t]),
+                                           _lib.ptr(fused.param), stream), "trx_nmi_loop_update")
     hist_theta[epochs].copy_(theta[0])
     unpad = lambda v: v[:nt].reshape(1, nd, nd + 1).clone()  # noqa: E731
     final_theta = unpad(hist_theta[epochs])
