@@ -2,7 +2,8 @@
 """Randomised parity sweep of the paths tests/fuzz_affine.py does not reach (all against the C oracle in fp64):
    2-D affine / rigid steps, forward warp and warp backward; multi-channel forward warps (2-D and 3-D, one launch for all
    channels); loss-only evaluation; short SGD and Adam trajectories (affine and rigid, 2-D and 3-D: loss curve, best index, final theta); dense-flow trajectories
-   (SGD / Adam, with and without the smoothness term, vs the torch composition) and their Z-slab partition (random cuts) vs the whole volume; the Parzen-window PDFs of the NMI loss, forward and backward.
+   (SGD / Adam, with and without the smoothness term, vs the torch composition) and their Z-slab partition (random cuts) vs the whole volume; the Parzen-window PDFs of the NMI loss, forward and backward; the warp on the NMI lattice
+   (trx_affine_warp_lattice and its backward).
    python tests/fuzz_misc.py [cases] [seed]
 Bars: loss 2e-5 relative, gradients 3e-4 of their maximum (random large theta sits a little above the 2e-4 floor of the fixed
 cases: 2 marginal results, 2.7e-4 and a warp at 1.08x a 3x bar, in 900 cases) or twice the oracle's own fp32-vs-fp64 gap, warps 2e-6 or
@@ -289,6 +290,44 @@ def kde_pdf(rng, it, out):
     out.check("kde pdf backward", np.max(np.abs(sc.grad.cpu().double().numpy() - g64)), max(1e-5 * np.max(np.abs(g64)), 2 * np.max(np.abs(g32 - g64)), 1e-12), tag)
 
 
+def lattice_warp(rng, it, out):
+    """trx_affine_warp_lattice[_backward] (the warp on the NMI loss's nearest-neighbour lattice) vs the C oracle: values = the oracle's
+    full warp read at the lattice voxels; backward = the oracle's dMSE/dtheta for a target chosen such that dMSE/dwarped is the
+    scattered grad_out (t = w - g N / 2).  Random down- and up-sampling lattices (repeated voxels), 2-D and 3-D, 1-2 pairs."""
+    nd = 3 if rng.random() < 0.6 else 2
+    shape = tuple(int(v) for v in (rng.integers(3, 60, 3) if nd == 3 else rng.integers(3, 160, 2)))
+    size = tuple(int(max(1, round(n * rng.uniform(0.3, 1.7)))) for n in shape)
+    B = int(rng.integers(1, 3))
+    kind = rng.choice(["tiny", "small", "medium", "large"], p=[0.3, 0.3, 0.2, 0.2])
+    mov = torch.cat([phantom(shape, 7000 + 13 * it + b, 0.23) for b in range(B)])
+    th = torch.tensor(np.stack([(rand_theta if nd == 3 else rand_theta2)(rng, kind) for _ in range(B)]), dtype=torch.float32)
+    mc = mov.cuda()
+    vol = eng._Batch(mc, mc).vol()
+    lat = eng.LatticeWarp(vol, shape, size, mc.device)
+    thp = eng.pad_theta(th.reshape(B, -1).cuda(), nd)
+    vals = lat.forward(thp).cpu().numpy()
+    n = int(np.prod(size))
+    go = rng.uniform(-0.4, 0.6, (B, n)).astype(np.float32)
+    dth = lat.backward(thp, torch.from_numpy(go).cuda())[:, : nd * (nd + 1)].reshape(B, nd, nd + 1).cpu().numpy()
+    tabs = [t.cpu().numpy() for t in ((lat.iz, lat.iy, lat.ix) if nd == 3 else (lat.iy, lat.ix))]
+    sel = np.ix_(*tabs)
+    t64, t32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)
+    nvox = float(np.prod(shape))
+    for b in range(B):
+        m64, m32, tu = mov[b, 0].double().numpy(), mov[b, 0].numpy(), th[b].double().numpy()
+        r64, r32 = oracle.c_affine_warp(m64, tu, t64), oracle.c_affine_warp(m32, th[b].numpy(), t32)
+        tag = (it, b, shape, size, kind)
+        out.check(f"{nd}d lattice warp", np.max(np.abs(vals[b].reshape(size) - r32[sel])), max(2e-6, WARP_GAPS * np.max(np.abs(r32 - r64))), tag)
+        gw = np.zeros(shape, dtype=np.float64)
+        np.add.at(gw, sel, go[b].reshape(size).astype(np.float64))
+        tgt64 = r64 - gw * nvox / 2.0
+        _, _, d64, _ = oracle.c_affine_loss_grad(m64, tgt64, tu, oracle.wts(w_mse=1.0), t64)
+        # (no fp32 run of the oracle here: its target w - g N / 2 cancels in fp32 and would only inflate the bar)
+        gmax = max(np.max(np.abs(d64)), 1e-12)
+        bar = max(GRAD_FLOOR, 1.5 * kink_sens(lambda t: oracle.c_affine_loss_grad(m64, tgt64, t, oracle.wts(w_mse=1.0), t64)[2], tu, d64) / gmax)
+        out.check(f"{nd}d lattice warp backward", np.max(np.abs(dth[b] - d64)) / gmax, bar, tag)
+
+
 class Tally:
     def __init__(self, verbose):
         self.worst, self.fails, self.verbose = {}, 0, verbose
@@ -311,7 +350,7 @@ def run(n, seed, verbose=True, only=None):
         if only is not None and it == only:
             os.environ["FUZZ_DEBUG"] = "1"
         # (every case draws from the shared generator, so earlier cases are re-run to reach case `only`)
-        (steps_2d, multichannel_warp, trajectory, flow_trajectory, kde_pdf)[it % 5](rng, it, out)
+        (steps_2d, multichannel_warp, trajectory, flow_trajectory, kde_pdf, lattice_warp)[it % 6](rng, it, out)
     if verbose:
         print(f"{n} cases, {out.fails} failures; worst error / bar: " + ", ".join(f"{k} {v:.2f}" for k, v in sorted(out.worst.items())))
     return out.fails, out.worst
