@@ -366,3 +366,22 @@ def test_warp_lattice_argument_checks(eng):
     rc = lib.trx_affine_warp_lattice_backward(ctypes.byref(vol), _lib.ptr(th), _lib.ptr(lat.iz), 4, _lib.ptr(lat.iy), 4, _lib.ptr(lat.ix), 4,
                                               _lib.ptr(out), _lib.ptr(lat.dtheta), _lib.ptr(lat.ws), 16, None)
     assert rc != 0   # workspace too small
+
+
+def test_compose_theta_one_warp_equals_the_two_stage_pipeline(eng):
+    """SURVEY 8f.2 (optional extra): rigid -> affine as ONE resampling.  On a smooth phantom the one-warp result and the chain of two warps
+    differ only by the second interpolation (and by what the intermediate image lost at its border): 1 % of the range in the interior."""
+    import torchregister_amd as tr
+    shape = (48, 56, 40)
+    ax = [torch.arange(n, dtype=torch.float32) for n in shape]   # smooth (wavelength >= 40 voxels): the second interpolation costs ~0.3 %
+    x = (torch.sin(0.15 * ax[0])[:, None, None] * torch.cos(0.11 * ax[1])[None, :, None] + torch.sin(0.13 * ax[2] + 0.5)[None, None, :]).view(1, 1, *shape).cuda()
+    first = torch.tensor(oracle.c_theta_fwd(np.array([0.05, -0.04, 0.06, 0.03, -0.02, 0.04])), dtype=torch.float32).reshape(1, 3, 4).cuda()
+    second = torch.tensor([[1.03, 0.02, -0.01, 0.02], [-0.02, 0.97, 0.03, -0.03], [0.01, -0.02, 1.02, 0.01]])[None].cuda()
+    chain = tr.get_affine_warp(second, tr.get_affine_warp(first, x))
+    once = tr.get_affine_warp(tr.compose_theta(first, second), x)
+    inner = (slice(None), slice(None), slice(6, -6), slice(6, -6), slice(6, -6))
+    rng_ = (x.max() - x.min()).item()
+    assert torch.max(torch.abs(chain[inner] - once[inner])).item() <= 1e-2 * rng_
+    # and it is not the other order
+    wrong = tr.get_affine_warp(tr.compose_theta(second, first), x)
+    assert torch.max(torch.abs(chain[inner] - wrong[inner])).item() > torch.max(torch.abs(chain[inner] - once[inner])).item()

@@ -206,3 +206,27 @@ def test_torch_side_helpers_match_golden(single_step):
     b = torch.zeros(1, 2, 8, 8)
     p = tr.padNd(a, b)
     assert p.shape == b.shape
+
+
+def test_compose_theta_is_the_chain_of_the_two_grids():
+    """compose_theta(first, second): sampling coordinates of the one-warp pipeline = first applied to the coordinates
+    second produces, checked with F.affine_grid itself (CPU, fp64), 2-D and 3-D, batched and broadcast."""
+    import torch.nn.functional as F
+    import torchregister_amd as tr
+    g = torch.Generator().manual_seed(3)
+    for nd, shape in ((2, (1, 1, 7, 9)), (3, (1, 1, 5, 6, 7))):
+        a = (torch.eye(nd, nd + 1) + 0.2 * torch.randn(nd, nd + 1, generator=g)).double()[None]
+        b = (torch.eye(nd, nd + 1) + 0.2 * torch.randn(nd, nd + 1, generator=g)).double()[None]
+        c = tr.compose_theta(a, b)
+        assert c.shape == (1, nd, nd + 1) and c.dtype == torch.float64
+        grid_b = F.affine_grid(b, shape, align_corners=False)                 # where the second warp reads the intermediate image
+        ones = torch.ones(*grid_b.shape[:-1], 1, dtype=torch.float64)
+        chained = torch.cat([grid_b, ones], dim=-1) @ a[0].T                 # ... mapped through the first warp's matrix
+        assert torch.allclose(F.affine_grid(c, shape, align_corners=False), chained, atol=1e-12)
+    a2 = torch.eye(3, 4)                                                      # [nd, nd+1] input, batch broadcast, dtype kept
+    b2 = torch.eye(3, 4)[None].repeat(4, 1, 1)
+    b2[:, 0, 3] = torch.arange(4.0)
+    out = tr.compose_theta(a2, b2)
+    assert out.shape == (4, 3, 4) and out.dtype == torch.float32 and torch.equal(out, b2)
+    with pytest.raises(ValueError):
+        tr.compose_theta(torch.eye(2, 3), torch.eye(3, 4))

@@ -11,4 +11,4 @@ from .sharding import register_sharded  # noqa: F401
 from .torchregister import Register  # noqa: F401
 from .utils import (EPSILON, Attention_UNet, K_gauss, LocalNCCLoss, NCCLoss, NMI, NMILoss, PDF, PDF_xis, Regressor, SpatialTransformer, SSDLoss,  # noqa: F401
                     Theta, attention_grid, get_pdf, norm, padNd)
-from .warpings import affine_register, flow_register, get_affine_warp, rigid_register  # noqa: F401
+from .warpings import affine_register, compose_theta, flow_register, get_affine_warp, rigid_register  # noqa: F401

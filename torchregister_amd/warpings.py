@@ -49,6 +49,28 @@ def get_affine_warp(theta, moving):
     return _AffineWarpFn.apply(theta, moving)
 
 
+def compose_theta(first, second):
+    """theta of the two-stage pipeline of ref:README.md:58-83 as ONE warp (optional extra): with
+    y = get_affine_warp(first, x) and z = get_affine_warp(second, y), z(p) = y(A2 p) = x(A1 A2 p) in affine_grid's normalised
+    coordinates, so get_affine_warp(compose_theta(first, second), x) resamples x once where the chain interpolates twice (the two
+    agree up to that second interpolation and to what the intermediate image lost outside its frame).  first, second: [B,nd,nd+1]
+    (or [nd,nd+1]); the product is formed in fp64 and returned in the dtype of `first`."""
+    a, b = first.detach(), second.detach()
+    if a.dim() == 2:
+        a = a[None]
+    if b.dim() == 2:
+        b = b[None]
+    nd = a.shape[-2]
+    if a.shape[-2:] != (nd, nd + 1) or b.shape[-2:] != (nd, nd + 1):
+        raise ValueError(f"expected [B,{nd},{nd + 1}] matrices, got {tuple(first.shape)} and {tuple(second.shape)}")
+    B = max(a.shape[0], b.shape[0])
+    bottom = torch.zeros(B, 1, nd + 1, dtype=torch.float64, device=a.device)
+    bottom[:, 0, nd] = 1.0
+    ha = torch.cat([a.double().expand(B, nd, nd + 1), bottom], dim=1)
+    hb = torch.cat([b.double().to(a.device).expand(B, nd, nd + 1), bottom], dim=1)
+    return (ha @ hb)[:, :nd, :].to(first.dtype)
+
+
 def loss_spec_from(criterions, weights):
     """Map a criterion list onto the fused loss (None if some criterion has no fused form)."""
     spec = LossSpec()
