@@ -48,6 +48,7 @@ typedef enum {
 #define TRX_FLAG_TWO_PASS_FLOW 4u  /* trx_flow_run: keep the moments pass of every iteration (no fusion into the previous update) */
 #define TRX_FLAG_DEEP_TILE 8u      /* affine steps: offer the deep tile (GeomD) to every pair it fits, whatever the batch size (by default only
                                       where its 128-row slabs still fill the chip) */
+#define TRX_FLAG_NO_ROT_DEEP_TILE 16u /* affine steps: never use GeomRD (the 16 x 16 x 16 tile in GeomR's box) - rotated pairs all run GeomR */
 
 /* A batch of B independent (moving, target) pairs. */
 typedef struct {

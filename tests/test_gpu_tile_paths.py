@@ -282,3 +282,69 @@ def test_deep_tile_vs_oracle(eng, shape, tname, loss):
     assert np.max(np.abs(grad - gref)) <= 2e-5 * np.max(np.abs(gref))            # the default geometry choice gives the same numbers
     if tname != "identity":
         assert np.max(np.abs(grad - dth)) <= 2e-4 * np.max(np.abs(dth)), (grad, dth)
+
+
+ROT_DEEP_THETAS = {
+    "rot_z_0.5": rot_theta(0.0, 0.0, 0.5, (1.0, 1.0, 1.0), (0.03, -0.02, 0.01)),
+    "rot_z_1.0": rot_theta(0.0, 0.0, 1.0, (1.02, 0.98, 1.0), (0.0, 0.05, 0.0)),
+    "rot_x_0.6": rot_theta(0.6, 0.0, 0.0, (1.0, 1.0, 1.0), (0.0, 0.0, 0.02)),
+    "rot_y_0.6": rot_theta(0.0, 0.6, 0.0, (1.0, 1.01, 0.97), (0.02, 0.0, 0.0)),
+    "general_0.3": rot_theta(0.3, 0.3, 0.3, (1.0, 1.0, 1.0), (0.01, -0.02, 0.015)),        # fits GeomRD's box
+    "general_0.45": rot_theta(0.45, 0.45, 0.45, (1.0, 1.0, 1.0), (0.01, -0.02, 0.015)),     # does not: GeomR either way
+    "shift_out": rot_theta(0.0, 0.2, 0.5, (1.0, 1.0, 1.0), (0.5, -0.45, 0.3)),             # rotated AND mostly out of the volume
+}
+
+
+@pytest.mark.parametrize("loss", ["ncc_mse", "mse"])
+@pytest.mark.parametrize("shape", [(40, 36, 44), (16, 48, 64), (33, 20, 68), (64, 64, 64), (23, 37, 46)])
+@pytest.mark.parametrize("tname", list(ROT_DEEP_THETAS))
+def test_rotated_deep_tile_vs_oracle(eng, shape, tname, loss):
+    """GeomRD (GeomR's 28 x 27 x 26 box under a 16 x 16 x 16 tile, eight rows per thread: the choice of every step whose rotated
+    pre-image still fits that box) against the C oracle in fp64 and against GeomR on the same inputs (TRX_FLAG_NO_ROT_DEEP_TILE), both
+    step kernels, ragged volumes (partial tiles in every direction)."""
+    from torchregister_amd import _lib
+    tgt = ph.blobs(shape, 77)
+    mov = ph.blobs(shape, 78) + 0.1 * ph.vol(shape, 0.013, "sin")
+    th64 = generic(ROT_DEEP_THETAS[tname])
+    th = torch.tensor(th64, dtype=torch.float32)[None]
+    kw = dict(w_ncc=1.0, w_mse=0.5) if loss == "ncc_mse" else dict(w_mse=1.0, w_ssd=0.01)
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
+    ref = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=_lib.FLAG_NO_ROT_DEEP_TILE)
+    s.run(1)
+    ref.run(1)
+    torch.cuda.synchronize()
+    total, _, dth, _ = oracle.c_affine_loss_grad(mov[0, 0].double().numpy(), tgt[0, 0].double().numpy(), th[0].double().numpy(), oracle.wts(**kw),
+                                                 oracle.base_tables(shape, np.float64))
+    loss_v = s.losses[0, 0].item()
+    grad = s.grad[0, :12].cpu().numpy().reshape(3, 4)
+    assert abs(loss_v - total) <= 2e-5 * max(1.0, abs(total)), (loss_v, total)
+    assert abs(loss_v - ref.losses[0, 0].item()) <= 2e-6 * max(1.0, abs(total))
+    gref = ref.grad[0, :12].cpu().numpy().reshape(3, 4)
+    assert np.max(np.abs(grad - gref)) <= 2e-5 * np.max(np.abs(gref))
+    # large rotations put many samples on the zero-padding border, where fp32 coordinates decide which side of the jump a sample sees:
+    # the bar is the oracle's own fp32-vs-fp64 gap (x2) where that exceeds the 2e-4 floor, as in tests/fuzz_affine.py
+    _, _, dth32, _ = oracle.c_affine_loss_grad(mov[0, 0].numpy(), tgt[0, 0].numpy(), th[0].numpy(), oracle.wts(**kw), oracle.base_tables(shape, np.float32))
+    bar = max(2e-4 * np.max(np.abs(dth)), 2.0 * np.max(np.abs(np.asarray(dth32, dtype=np.float64) - dth)))
+    assert np.max(np.abs(grad - dth)) <= bar, (grad, dth, bar)
+
+
+def test_rotated_deep_tile_mixed_batch(eng):
+    """One batch whose pairs choose four different geometries (GeomA, GeomRD, GeomR, and the deep tile through its flag): the batch
+    launch gives every pair what a single-pair launch gives it, bit for bit (the finalise kernel repeats each pair's choice)."""
+    from torchregister_amd import _lib
+    shape = (48, 40, 56)
+    names = ["near", "rot_z_0.5", "general_0.45", "rot_x_0.6", "identity"]
+    thetas = [DEEP_THETAS.get(n, ROT_DEEP_THETAS.get(n)) for n in names]
+    th = torch.tensor(np.stack([t if n == "identity" else generic(t) for n, t in zip(names, thetas)]), dtype=torch.float32)
+    B = len(names)
+    tgt = torch.cat([ph.blobs(shape, 80 + b) for b in range(B)])
+    mov = torch.cat([ph.blobs(shape, 90 + b) + 0.1 * ph.vol(shape, 0.013, "sin") for b in range(B)])
+    for flags in (0, _lib.FLAG_DEEP_TILE):
+        s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=1e-4, init=th, capacity=3, flags=flags)
+        s.run(3)
+        for b in range(B):
+            one = eng.AffineSolver(mov[b:b + 1].cuda(), tgt[b:b + 1].cuda(), mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=1e-4, init=th[b:b + 1], capacity=3,
+                                   flags=flags)
+            one.run(3)
+            assert torch.equal(one.losses[0, :3], s.losses[b, :3]), (names[b], flags)
+            assert torch.equal(one.current_theta[0], s.current_theta[b]), (names[b], flags)

@@ -188,6 +188,19 @@ int main(int argc, char **argv)
             rep("dual MODE0 rot .8/.6/.7", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 10));
             rep("split MODE0 rot .8/.6/.7", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 1>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 2>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 10));
             rep("tile MODE0 rot .8/.6/.7", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 10));
+            {   // a moderate general rotation (0.4 rad about every axis) and 0.3 rad about z: the single-geometry kernel only (GeomP = GeomR / GeomRD comparisons)
+                for (int which = 0; which < 2; which++) {
+                    const double a2 = which ? 0.0 : 0.4, b2 = which ? 0.3 : 0.4, c2 = which ? 0.0 : 0.4;
+                    const double Ry2[9] = {cos(a2), 0, sin(a2), 0, 1, 0, -sin(a2), 0, cos(a2)}, Rz2[9] = {cos(b2), -sin(b2), 0, sin(b2), cos(b2), 0, 0, 0, 1},
+                                 Rx2[9] = {1, 0, 0, 0, cos(c2), -sin(c2), 0, sin(c2), cos(c2)};
+                    double T2[9], R2[9];
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { T2[i * 3 + j] = 0; for (int k = 0; k < 3; k++) T2[i * 3 + j] += Rz2[i * 3 + k] * Ry2[k * 3 + j]; }
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R2[i * 3 + j] = 0; for (int k = 0; k < 3; k++) R2[i * 3 + j] += T2[i * 3 + k] * Rx2[k * 3 + j]; }
+                    for (int b = 0; b < B; b++) for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) th[b * 12 + i * 4 + j] = (float)R2[i * 3 + j]; th[b * 12 + i * 4 + 3] = 0.01f * (i + 1); }
+                    CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
+                    rep(which ? "tile MODE0 rot z 0.3" : "tile MODE0 rot .4/.4/.4", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 10));
+                }
+            }
             for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = rt[i];
             CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
         }

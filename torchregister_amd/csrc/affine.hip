@@ -241,7 +241,13 @@ using GeomW = TileCfg<64, 8, 512, 76, 13, 14, 2, 1, 8>;
 // barriers are paid once per 8192 voxels instead of 4096 and the z halo is 18 / 16 instead of 10 / 8; the box has one plane of slack, so it
 // serves |theta - I| up to ~0.03 rad about x / y only.
 using GeomD = TileCfg<32, 16, 512, 44, 23, 19, 2, 1>;
-#if TRX_TILE_CFG == 4
+// GeomR's box under a 16 x 16 x 16 tile (eight rows per thread): per-tile work is paid once per 4096 voxels instead of 2048 and the z halo is
+// 18 / 16 instead of 10 / 8; the pre-image fits the 26-plane box for rotations about z of any size GeomR serves and for general rotations up to
+// ~0.4 rad per axis.
+using GeomRD = TileCfg<16, 16, 512, 28, TRX_GEOMR_BH, TRX_GEOMR_BD, 2, 1>;
+#if TRX_TILE_CFG == 5
+using GeomP = GeomRD;
+#elif TRX_TILE_CFG == 4
 using GeomP = GeomD;
 #elif TRX_TILE_CFG == 1
 using GeomP = GeomDeep;   // primary geometry
@@ -333,6 +339,9 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #endif
 #ifndef TRX_DEEP_TILE
 #define TRX_DEEP_TILE 1   // the step kernels carry GeomD (deep tile) as a third per-pair choice (0: GeomA / GeomR only - measured alternative)
+#endif
+#ifndef TRX_ROT_DEEP_TILE
+#define TRX_ROT_DEEP_TILE 1   // the step kernels carry GeomRD as a fourth per-pair choice (0: never - measured alternative)
 #endif
 #ifndef TRX_SWP
 #define TRX_SWP 1   // software pipeline of the gather: LDS reads of row j+1 issued before the arithmetic of row j (0: at use)
@@ -1191,12 +1200,13 @@ __device__ __forceinline__ bool dual_fits(const float *__restrict__ th, float fD
            ((((int)floorf(span[0] + 0.1f) + 5) >> 2) + 1 <= G::BW4) && ((int)floorf(span[1] + 0.1f) + 3 <= G::BH) &&
            ((int)floorf(span[2] + 0.1f) + 3 <= G::BD);
 }
-// The geometry a pair's blocks run (0 = GeomD, the deep tile, step kernels only; 1 = GeomA; 2 = GeomR): evaluated identically by every
+// The geometry a pair's blocks run (0 = GeomD, the deep tile, step kernels only; 1 = GeomA; 2 = GeomR; 3 = GeomRD, step kernels only): evaluated identically by every
 // block of the pair and by the step's finalise kernel.
-__device__ __forceinline__ int dual_choice(const float *__restrict__ th, float fD, float fH, float fW, bool with_deep)
+__device__ __forceinline__ int dual_choice(const float *__restrict__ th, float fD, float fH, float fW, bool with_deep, bool with_rd = false)
 {
     if (with_deep && dual_fits<GeomD>(th, fD, fH, fW)) return 0;
-    return dual_fits<GeomA>(th, fD, fH, fW) ? 1 : 2;
+    if (dual_fits<GeomA>(th, fD, fH, fW)) return 1;
+    return (with_rd && dual_fits<GeomRD>(th, fD, fH, fW)) ? 3 : 2;   // 3 = GeomRD: GeomR's box under a 16 x 16 x 16 tile, where the pre-image still fits it
 }
 
 // The dual kernel: per pair, GeomA where its box holds the pre-image of a GeomA tile for this theta (decided from the
@@ -1208,9 +1218,10 @@ __device__ __forceinline__ int dual_choice(const float *__restrict__ th, float f
 template <int MODE, int WHICH = 0>
 __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tgA,
                                                                                    TileGeom tgR, int channels, float *__restrict__ partials,
-                                                                                   int zero_surplus = 1, TileGeom tgD = TileGeom{})
+                                                                                   int zero_surplus = 1, TileGeom tgD = TileGeom{}, TileGeom tgRD = TileGeom{})
 {
-    static_assert(GeomA::Threads == 512 && GeomR::Threads == 512 && GeomD::Threads == 512, "every geometry runs 512-thread blocks");
+    static_assert(GeomA::Threads == 512 && GeomR::Threads == 512 && GeomD::Threads == 512 && GeomRD::Threads == 512, "every geometry runs 512-thread blocks");
+    static_assert(GeomRD::BoxAlloc <= GeomR::BoxAlloc, "GeomRD lives in GeomR's box");
     // the step kernels (MODE 0 / 4) of the one-launch form also carry the deep tile for transforms next to the identity
     constexpr bool kDeep = (WHICH == 0) && (MODE == 0 || MODE == 4) && (TRX_TILE_CFG == 0) && (TRX_DEEP_TILE != 0);
     constexpr int kAllocAR = GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc;
@@ -1220,10 +1231,11 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : (MODE == 4 ? kNpMse : 5));
     const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
     const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
-    const int choice = __builtin_amdgcn_readfirstlane(dual_choice(th, (float)vol.D, (float)vol.H, (float)vol.W, kDeep && tgD.blocks_per_pair > 0));
+    const int choice = __builtin_amdgcn_readfirstlane(dual_choice(th, (float)vol.D, (float)vol.H, (float)vol.W, kDeep && tgD.blocks_per_pair > 0,
+                                                                  kDeep && tgRD.blocks_per_pair > 0));
     const bool useA = choice == 1;
     if ((WHICH == 1 && !useA) || (WHICH == 2 && useA)) return;   // the other launch owns this pair (and its surplus rows)
-    const int mine = choice == 0 ? tgD.blocks_per_pair : (useA ? tgA.blocks_per_pair : tgR.blocks_per_pair);
+    const int mine = choice == 0 ? tgD.blocks_per_pair : (choice == 3 ? tgRD.blocks_per_pair : (useA ? tgA.blocks_per_pair : tgR.blocks_per_pair));
     if ((int)blockIdx.x >= mine) {
         // (zero_surplus = 0: the reader knows from theta which geometry ran and stops at its row count - the step's finalise kernel)
         if (MODE != 3 && zero_surplus && threadIdx.x < NP) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + threadIdx.x] = 0.f;
@@ -1232,6 +1244,10 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     if constexpr (kDeep) {
         if (choice == 0) {
             tile_body<MODE, GeomD>(vol, theta, tgD, channels, partials, box, blockIdx.x, blockIdx.y);
+            return;
+        }
+        if (choice == 3) {
+            tile_body<MODE, GeomRD>(vol, theta, tgRD, channels, partials, box, blockIdx.x, blockIdx.y);
             return;
         }
     }
@@ -1247,10 +1263,10 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
 // GeomA / GeomR per pair: one two-body launch or the pair of single-body launches (TRX_AFFINE_DUAL = 1 / 2, default 1: the pair costs one more launch and gains nothing).
 template <int MODE>
 static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const float *theta, const TileGeom &ta, const TileGeom &tr, int channels, float *out, int how,
-                        int zero_surplus = 1, TileGeom td = TileGeom{})
+                        int zero_surplus = 1, TileGeom td = TileGeom{}, TileGeom trd = TileGeom{})
 {
     if (how == 1) {
-        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td);
+        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd);
     } else {
         hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 1>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
         hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 2>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
@@ -1392,7 +1408,7 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
                                                                           double nvox, int D, int H, int W,
                                                                           trx_loss_cfg lc, trx_opt_cfg oc,
                                                                           trx_affine_state st, int nblk_geomA = 0, int nblk_geomR = 0, int mse_rows = 0,
-                                                                          int nblk_geomD = 0)
+                                                                          int nblk_geomD = 0, int nblk_geomRD = 0)
 {
     constexpr int NP = np_full(ND);
     constexpr int NT = ND * (ND + 1);
@@ -1436,8 +1452,8 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
         int rows = nblk;
         if constexpr (ND == 3) {
             if (nblk_geomA != 0) {
-                const int choice = dual_choice(theta, (float)D, (float)H, (float)W, nblk_geomD > 0);
-                rows = choice == 0 ? nblk_geomD : (choice == 1 ? nblk_geomA : nblk_geomR);
+                const int choice = dual_choice(theta, (float)D, (float)H, (float)W, nblk_geomD > 0, nblk_geomRD > 0);
+                rows = choice == 0 ? nblk_geomD : (choice == 1 ? nblk_geomA : (choice == 3 ? nblk_geomRD : nblk_geomR));
             }
         }
         if (ND == 3 && mse_rows) reduce_partials<kNpMse>(partials + (size_t)b * nblk * kNpMse, rows, S);   // rows of the MSE / SSD-only step kernel
@@ -1847,8 +1863,11 @@ static size_t tile_rows_per_pair(const trx_volumes &v)
 {
     size_t n = (size_t)tile_geom<GeomP>(v).blocks_per_pair;
     const size_t a = (size_t)tile_geom<GeomA>(v).blocks_per_pair, r = (size_t)tile_geom<GeomR>(v).blocks_per_pair;
+    const size_t d = (size_t)tile_geom<GeomD>(v).blocks_per_pair, rd = (size_t)tile_geom<GeomRD>(v).blocks_per_pair;
     if (a > n) n = a;
     if (r > n) n = r;
+    if (d > n) n = d;
+    if (rd > n) n = rd;
     return n;
 }
 
@@ -1876,7 +1895,7 @@ static bool use_tile_path(const trx_volumes *vol)
 // Returns the number of partial rows per pair through *nblk.
 template <int MODE>
 static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a = nullptr, int *nblk_r = nullptr,
-                     int *nblk_d = nullptr);
+                     int *nblk_d = nullptr, int *nblk_rd = nullptr);
 
 template <int MODE>
 static int launch_accum(const trx_volumes *vol, const float *theta, const AffineGeom &g, int channels, size_t chan_stride,
@@ -1894,10 +1913,12 @@ static int launch_accum(const trx_volumes *vol, const float *theta, const Affine
 // nblk_a / nblk_r != nullptr: the caller's reduction knows the per-pair geometry (see affine_finalize_kernel): surplus blocks of the
 // dual grid then write nothing.
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a, int *nblk_r, int *nblk_d)
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a, int *nblk_r, int *nblk_d,
+                     int *nblk_rd)
 {
     if (nblk_a) *nblk_a = *nblk_r = 0;
     if (nblk_d) *nblk_d = 0;
+    if (nblk_rd) *nblk_rd = 0;
     if (use_tile_path(vol)) {
         TileGeom t = tile_geom(*vol);
         trx_volumes v = *vol;
@@ -1924,11 +1945,18 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
                 const TileGeom cand = tile_geom<GeomD>(*vol);
                 if (TRX_DEEP_TILE && ((long)cand.blocks_per_pair * vol->B >= 1024 || (vol->flags & TRX_FLAG_DEEP_TILE))) td = cand;
             }
-            launch_dual<MODE>(dim3(gx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td);
+            // GeomRD (GeomR's box under a 16 x 16 x 16 tile) joins under the same condition: rotations whose pre-image still fits that box
+            TileGeom trd = TileGeom{};
+            if (aware && nblk_rd != nullptr && (MODE == 0 || MODE == 4) && TRX_ROT_DEEP_TILE && !(vol->flags & TRX_FLAG_NO_ROT_DEEP_TILE)) trd = tile_geom<GeomRD>(*vol);
+            int gxx = gx;
+            if (td.blocks_per_pair > gxx) gxx = td.blocks_per_pair;
+            if (trd.blocks_per_pair > gxx) gxx = trd.blocks_per_pair;
+            launch_dual<MODE>(dim3(gxx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd);
             TRX_CHECK_LAUNCH();
-            *nblk = gx;
+            *nblk = gxx;
             if (aware) { *nblk_a = ta.blocks_per_pair; *nblk_r = tr.blocks_per_pair; }
             if (nblk_d) *nblk_d = td.blocks_per_pair;
+            if (nblk_rd) *nblk_rd = trd.blocks_per_pair;
             return TRX_OK;
         }
         hipLaunchKernelGGL((affine_tile_kernel<MODE>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
@@ -1962,16 +1990,16 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     // Every step picks GeomA / GeomR per pair in the kernel (TRX_FLAG_SINGLE_GEOM: the primary geometry only).  Rigid runs start from a
     // random pose (reference: torch.rand, up to 1 rad) and live at large rotations; affine runs start at the identity, where the
     // GeomA body is all that runs, but may rotate away from it: the single-geometry kernel then gathers from L2 at 3.2x the cost.
-    int nblk_a = 0, nblk_r = 0, nblk_d = 0;
+    int nblk_a = 0, nblk_r = 0, nblk_d = 0, nblk_rd = 0;
     // without an NCC term only d = warped - target matters: the step kernel then keeps 13 sums instead of 41 (3-D tile path)
     const bool mse_only = (loss->w_ncc == 0.f) && use_tile_path(vol);
-    rc = mse_only ? launch_f1<4>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r, &nblk_d)
-                  : launch_f1<0>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r, &nblk_d);
+    rc = mse_only ? launch_f1<4>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r, &nblk_d, &nblk_rd)
+                  : launch_f1<0>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r, &nblk_d, &nblk_rd);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
     if (vol->ndim == 3)
         hipLaunchKernelGGL((affine_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
-                           vol->D, vol->H, vol->W, *loss, *opt, *st, nblk_a, nblk_r, mse_only ? 1 : 0, nblk_d);
+                           vol->D, vol->H, vol->W, *loss, *opt, *st, nblk_a, nblk_r, mse_only ? 1 : 0, nblk_d, nblk_rd);
     else
         hipLaunchKernelGGL((affine_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
                            vol->D, vol->H, vol->W, *loss, *opt, *st);
@@ -1985,8 +2013,8 @@ extern "C" int trx_affine_accumulate(const trx_volumes *vol, const float *theta,
     if (rc) return rc;
     if (!theta || !workspace) return TRX_ERR_ARG;
     if (workspace_bytes < trx_affine_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
-    int nblk = 0, na = 0, nr = 0, nd = 0;
-    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream, true, &na, &nr, &nd);   // exactly the launch of a step (profiling aid)
+    int nblk = 0, na = 0, nr = 0, nd = 0, nrd = 0;
+    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream, true, &na, &nr, &nd, &nrd);   // exactly the launch of a step (profiling aid)
 }
 
 extern "C" int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
