@@ -259,6 +259,9 @@ using GeomP = GeomR;
 using GeomP = GeomA;
 #endif
 
+#ifndef TRX_GEOM_MODEL
+#define TRX_GEOM_MODEL 1   // y-split of the tile columns from the occupancy model in tile_geom (0: the round-1 rules - measured alternative)
+#endif
 struct TileGeom {
     int ntx, nty, ntz, ntiles, blocks_per_pair, ysplit, tiles_per_seg;
 };
@@ -285,7 +288,29 @@ static TileGeom tile_geom(const trx_volumes &v)
     int ys = 1;
     if (target > 0) {
         ys = (int)((target + cols - 1) / cols);
-    } else if (cols <= 512) {
+#if TRX_GEOM_MODEL
+    } else if (cols * t.nty > 1024) {
+        // Occupancy model of one launch, in units of "one tile on a CU that runs a single block": 512 block slots (two per CU); a block
+        // costs its tiles + 1.5 of prologue / epilogue, times 1.6 when it shares its CU (the pair together: 1.25x a lone block); blocks
+        // beyond the slots run in further rounds, a last round of <= 256 blocks has the CUs to itself.  Reproduces the sweeps the
+        // round-1 rules were fitted to by hand (1 x 256^3: 512 blocks 47 us, 256 or 1024 blocks 53 us; 8 x 182^3: split in two 173 us,
+        // unsplit 181) and fixes what they missed - a second round that is nearly empty (1 x 192^3: 576 blocks 39 us, 432 blocks 32 us;
+        // 2 x 182 x 218 x 182: 552 blocks 77 us, 828 blocks 66 us).  Many columns: at most four segments, as before (every segment of
+        // every geometry enlarges the dual kernel's grid, whose surplus blocks cost their dispatch).
+        double best = 1e30;
+        int last_tps = 0;
+        const int cmax = cols > 512 ? (t.nty < 4 ? t.nty : 4) : t.nty;
+        for (int c = 1; c <= cmax; c++) {
+            const int tps = (t.nty + c - 1) / c, segs = (t.nty + tps - 1) / tps;
+            if (tps == last_tps) continue;   // same split as the previous c
+            last_tps = tps;
+            const long blocks = cols * segs, full = blocks / 512, rem = blocks % 512;
+            double cost = (double)full * 1.6 * (tps + 1.5);
+            if (rem > 0) cost += (rem <= 256 ? 1.0 : 1.6) * (tps + 1.5);
+            if (cost < best - 1e-9) { best = cost; ys = c; }
+        }
+#endif
+    } else if (cols <= 512) {   // (with the model: launches of at most two tiles per block slot, where fixed costs decide and the model does not resolve them)
         ys = (int)((512 + cols - 1) / cols);
         const int cap = t.nty / 2 > 1 ? t.nty / 2 : 1;
         if (ys > cap && cols * cap >= 256) ys = cap;   // (tiny volumes: as many blocks as there are tiles - 1 x 64^3: 8.9 vs 12.1 us)
