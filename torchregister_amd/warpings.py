@@ -187,7 +187,7 @@ def _nmi_fast_path(moving, target, criterions, weights, optimizer):
         return None
     nmis = [(c, float(w)) for c, w in zip(criterions, weights) if type(c) is NMILoss and float(w) != 0.0]
     others = [(c, w) for c, w in zip(criterions, weights) if not (type(c) is NMILoss and float(w) != 0.0)]
-    if len(nmis) != 1 or nmis[0][0].bins > 512:
+    if len(nmis) != 1 or not (2 <= nmis[0][0].bins <= 512):   # both sample lines go through one 2 x bins <= 1024 evaluation
         return None
     spec = loss_spec_from([c for c, _ in others], [w for _, w in others]) if others else LossSpec()
     if spec is None:
@@ -197,12 +197,13 @@ def _nmi_fast_path(moving, target, criterions, weights, optimizer):
 
 def _nmi_affine_loop(moving, target, mode, spec, nmi, w_nmi, lr, epochs, init):
     """The loop of ref:warpings.py:67-93 / :138-159 for `fused terms + NMI` without autograd and without a host sync per iteration:
-      F1 step (lr = 0) -> loss and d/dtheta of the MSE / NCC / SSD terms;  the warp on the NMI loss's nearest-neighbour lattice only
-      (trx_affine_warp_lattice: the 2^d patches are 100^3 of e.g. 256^3 voxels) -> Parzen PDFs (one launch for the warped image's PDF
-      and its half of the pooled one: both sample lines as 2 x bins "bins") -> trx_nmi_from_pdfs (loss and d/dPDF) -> one PDF backward
-      -> trx_affine_warp_lattice_backward -> d/dtheta;  SGD on theta (rigid: Theta's vector-Jacobian product, trx_theta_chain).
+      F1 step (lr = 0) -> loss and d/dtheta of the MSE / NCC / SSD terms;  trx_nmi_lattice_lines: the warp on the NMI loss's
+      nearest-neighbour lattice only (the 2^d patches are 200^3 samples of the volume) and both sample lines -> Parzen PDFs (one launch
+      for the warped image's PDF and its half of the pooled one: 2 x bins "bins"; the target's half from its cached power sums) ->
+      trx_nmi_from_pdfs_pooled (loss and d/dPDF) -> one PDF backward -> trx_affine_warp_lattice_backward -> d/dtheta;
+      trx_nmi_loop_update: loss and theta history, SGD on theta (rigid: through Theta's vector-Jacobian product).  13 launches.
     The reference builds each sample line from .item() extrema (ref:utils.py:40-48, two host syncs per PDF); here the extrema stay
-    on the device (torch.lerp between them, the same line to an ulp).  The series form of the PDF kernels needs the window to be at
+    on the device (torch.lerp's formula between them, the same line to an ulp).  The series form of the PDF kernels needs the window to be at
     least as wide as the value range: checked ONCE from the extrema of moving and target (a warped value is a convex combination of
     moving's voxels and the zero padding).  Returns None when that does not hold (the generic loop then runs the exponential kernels)."""
     from . import _lib
