@@ -6,6 +6,7 @@ run (ATen affine_grid_generator / grid_sampler / SGD) act as arbiter:
   affine_warp     <- ref:warpings.py:18-26  (F.affine_grid + F.grid_sample, align_corners=False)
   flow_warp       <- ref:utils.py:350-365   (identity grid + flow, normalise, align_corners=True)
   ncc_loss        <- ref:utils.py:197-205   (global NCC, EPSILON=1e-10, alpha=100)
+  nmi_loss        <- ref:utils.py:18-79, :224-259 (Parzen PDFs, NMI, NMILoss; pinned by trajectories_r2b.npz and the 2-D default-criterion run)
   pose_to_theta   <- ref:utils.py:287-310
   sgd loops       <- ref:warpings.py:67-93, :138-159, :208-233 (best = first strict minimum)
 Validated against tests/golden/ in tests/test_oracle_golden.py.  This is what
@@ -74,6 +75,33 @@ def mse_loss(y, yp):
 
 def ssd_loss(y, yp, alpha=3.0):
     return ((y - yp) ** 2).sum() * alpha
+
+
+def parzen_pdf(data, steps=256, bandwidth=3.0):
+    """ref:utils.py:18-51 (K_gauss, PDF_xis, get_pdf): per row of `data` (flattened) the Parzen estimate at `steps` points running from the
+    largest to the smallest value of ALL rows - the reference calls them (min_val, max_val) = (max, min) - on a float32 sample line whatever
+    the data's dtype; kernel exp(-u^2 / 2) / (2 pi) (the reference's constant), mean over the samples, / h."""
+    signals = torch.flatten(data, start_dim=1)
+    line = torch.linspace(signals.max().item(), signals.min().item(), steps, dtype=torch.float32).expand(signals.shape[0], steps)
+    u = (signals.unsqueeze(-1) - line.unsqueeze(1)) / bandwidth                       # [N, S, steps]
+    return (1.0 / bandwidth) * torch.mean(torch.exp(-(u ** 2) / 2) / (2 * torch.pi), dim=1)
+
+
+def nmi_loss(y, yp, alpha=1000.0, bins=256, patch_size=100, bandwidth=3.0):
+    """ref:utils.py:53-79 (NMI) behind ref:utils.py:224-259 (NMILoss.forward): nearest re-sampling of both images to (2 patch)^nd, viewed
+    as 2^nd "patches" of patch^nd samples (a plain reshape of the re-sampled volume), Parzen PDFs of target, warped and of the two stacked,
+    Shannon terms with the reference's sign convention, NMI = 2 MI / (E1 + E2), loss = mean |NMI - 1| alpha."""
+    nd = y.dim() - 2
+    r = 2 * patch_size
+    q = [F.interpolate(t, size=(r,) * nd, mode="nearest").view((2 ** nd) * t.shape[0] * t.shape[1], *([patch_size] * nd)) for t in (y, yp)]
+    hists = [parzen_pdf(q[0], bins, bandwidth), parzen_pdf(q[1], bins, bandwidth), parzen_pdf(torch.stack((q[0], q[1]), dim=1), bins, bandwidth)]
+    ent = []
+    for hst in hists:
+        p = hst / hst.sum(dim=1, keepdim=True)
+        ent.append(torch.sum(p * torch.log2(p + EPSILON), dim=1))
+    mi = ent[0] + ent[1] - ent[2]
+    nmi = 2 * mi / (ent[0] + ent[1])
+    return torch.mean(torch.abs(nmi - 1.0) * alpha)
 
 
 def weighted_loss(y, yp, w_mse=0.0, w_ncc=0.0, ncc_alpha=100.0, w_ssd=0.0, ssd_alpha=3.0):
