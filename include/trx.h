@@ -44,7 +44,7 @@ typedef enum {
 /* trx_volumes.flags: per-call path selection (0 = the library picks; the others exist so that every path can be tested
  * against the others through the same entry points - results never depend on the path beyond fp32 rounding). */
 #define TRX_FLAG_GATHER_PATH 1u    /* affine entry points: the un-tiled row-walking kernel instead of the LDS-tiled ones */
-#define TRX_FLAG_SINGLE_GEOM 2u    /* affine entry points: one tile geometry for every pair (no per-pair GeomA / GeomR choice) */
+#define TRX_FLAG_SINGLE_GEOM 2u    /* affine entry points: one tile geometry for every pair (no per-pair choice among GeomD / GeomA / GeomRD / GeomR) */
 #define TRX_FLAG_TWO_PASS_FLOW 4u  /* trx_flow_run: keep the moments pass of every iteration (no fusion into the previous update) */
 #define TRX_FLAG_DEEP_TILE 8u      /* affine steps: offer the deep tile (GeomD) to every pair it fits, whatever the batch size (by default only
                                       where its 128-row slabs still fill the chip) */
