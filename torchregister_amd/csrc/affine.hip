@@ -365,6 +365,9 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #ifndef TRX_DEEP_TILE
 #define TRX_DEEP_TILE 1   // the step kernels carry GeomD (deep tile) as a third per-pair choice (0: GeomA / GeomR only - measured alternative)
 #endif
+#ifndef TRX_DEEP_SMALL
+#define TRX_DEEP_SMALL 1   // GeomD also for small batches whose deep tiling fills the block slots (0: only from 1024 blocks - measured alternative)
+#endif
 #ifndef TRX_ROT_DEEP_TILE
 #define TRX_ROT_DEEP_TILE 1   // the step kernels carry GeomRD as a fourth per-pair choice (0: never - measured alternative)
 #endif
@@ -1968,7 +1971,12 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             TileGeom td = TileGeom{};
             if (aware && nblk_d != nullptr && (MODE == 0 || MODE == 4)) {
                 const TileGeom cand = tile_geom<GeomD>(*vol);
-                if (TRX_DEEP_TILE && ((long)cand.blocks_per_pair * vol->B >= 1024 || (vol->flags & TRX_FLAG_DEEP_TILE))) td = cand;
+                // big batches as before; smaller ones where the deep tiling still fills every block slot with blocks of at least four tiles
+                // (1 or 2 pairs of 256^3: -3 %; never where it would leave slots empty - 2 x 128^3 measured +29 % with it)
+                const long blocks_d = (long)cand.blocks_per_pair * vol->B;
+                const long rem_d = blocks_d % 512;      // a last round that is less than ~60 % full costs more than the deeper tile saves (6 x 256^3: +6 %)
+                const bool small_ok = TRX_DEEP_SMALL && blocks_d >= 512 && cand.tiles_per_seg >= 4 && (rem_d == 0 || rem_d >= 320);
+                if (TRX_DEEP_TILE && (blocks_d >= 1024 || small_ok || (vol->flags & TRX_FLAG_DEEP_TILE))) td = cand;
             }
             // GeomRD (GeomR's box under a 16 x 16 x 16 tile) joins under the same condition: rotations whose pre-image still fits that box
             TileGeom trd = TileGeom{};
