@@ -46,8 +46,8 @@ typedef enum {
 #define TRX_FLAG_GATHER_PATH 1u    /* affine entry points: the un-tiled row-walking kernel instead of the LDS-tiled ones */
 #define TRX_FLAG_SINGLE_GEOM 2u    /* affine entry points: one tile geometry for every pair (no per-pair choice among GeomD / GeomA / GeomRD / GeomR) */
 #define TRX_FLAG_TWO_PASS_FLOW 4u  /* trx_flow_run: keep the moments pass of every iteration (no fusion into the previous update) */
-#define TRX_FLAG_DEEP_TILE 8u      /* affine steps: offer the deep tile (GeomD) to every pair it fits, whatever the batch size (by default only
-                                      where its 128-row slabs still fill the chip) */
+#define TRX_FLAG_DEEP_TILE 8u      /* affine steps: offer the deep tiles (GeomD, GeomRD) to every pair they fit, whatever the batch and volume size
+                                      (by default only where their larger tiles still fill the chip) */
 #define TRX_FLAG_NO_ROT_DEEP_TILE 16u /* affine steps: never use GeomRD (the 16 x 16 x 16 tile in GeomR's box) - rotated pairs all run GeomR */
 
 /* A batch of B independent (moving, target) pairs. */

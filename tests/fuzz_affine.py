@@ -73,14 +73,15 @@ def run(n, seed, grad_bar=2e-4, verbose=True, only=None):
         p32 = torch.tensor(poses, dtype=torch.float32)
         if only is not None and it != only:
             continue
-        s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
+        deep = 8 if (it % 2) else 0    # TRX_FLAG_DEEP_TILE on every other case: GeomD / GeomRD wherever they fit, also on these small volumes
+        s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=deep)
         s.run(1)
         wrp_t = eng.affine_warp(th.cuda(), mov.cuda())
         # generic warp backward (tile kernel MODE 2) with grad_out = dMSE/dwarped must reproduce the MSE gradient
         go = 2.0 * (wrp_t - tgt.cuda()) / float(np.prod(shape))
         dth_b = eng.affine_warp_backward(th.cuda(), mov.cuda(), go).cpu().numpy()
         wrp = wrp_t.cpu().numpy()
-        sr = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="rigid", loss=eng.LossSpec(**kw), lr=0.0, init=p32, capacity=1)
+        sr = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="rigid", loss=eng.LossSpec(**kw), lr=0.0, init=p32, capacity=1, flags=deep)
         sr.run(1)
         torch.cuda.synchronize()
         tabs64, tabs32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)

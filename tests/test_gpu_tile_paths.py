@@ -308,7 +308,8 @@ def test_rotated_deep_tile_vs_oracle(eng, shape, tname, loss):
     th64 = generic(ROT_DEEP_THETAS[tname])
     th = torch.tensor(th64, dtype=torch.float32)[None]
     kw = dict(w_ncc=1.0, w_mse=0.5) if loss == "ncc_mse" else dict(w_mse=1.0, w_ssd=0.01)
-    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
+    # (TRX_FLAG_DEEP_TILE: these volumes are below the size from which GeomRD is offered by default)
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=_lib.FLAG_DEEP_TILE)
     ref = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=_lib.FLAG_NO_ROT_DEEP_TILE)
     s.run(1)
     ref.run(1)
@@ -326,6 +327,26 @@ def test_rotated_deep_tile_vs_oracle(eng, shape, tname, loss):
     _, _, dth32, _ = oracle.c_affine_loss_grad(mov[0, 0].numpy(), tgt[0, 0].numpy(), th[0].numpy(), oracle.wts(**kw), oracle.base_tables(shape, np.float32))
     bar = max(2e-4 * np.max(np.abs(dth)), 2.0 * np.max(np.abs(np.asarray(dth32, dtype=np.float64) - dth)))
     assert np.max(np.abs(grad - dth)) <= bar, (grad, dth, bar)
+
+
+def test_rotated_deep_tile_is_the_default_from_96_cubed(eng):
+    """At 96^3 (216 tiles of 16^3 >= 128) GeomRD is offered without any flag: the default run equals the flagged run bit for bit and
+    differs from the GeomR run (fp32 summation order) while agreeing with it to 2e-6."""
+    from torchregister_amd import _lib
+    shape = (96, 96, 96)
+    tgt = ph.blobs(shape, 77).cuda()
+    mov = (ph.blobs(shape, 78) + 0.1 * ph.vol(shape, 0.013, "sin")).cuda()
+    th = torch.tensor(generic(ROT_DEEP_THETAS["rot_z_0.5"]), dtype=torch.float32)[None]
+    runs = {}
+    for flags in (0, _lib.FLAG_DEEP_TILE, _lib.FLAG_NO_ROT_DEEP_TILE):
+        s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=0.0, init=th, capacity=1, flags=flags)
+        s.run(1)
+        torch.cuda.synchronize()
+        runs[flags] = (s.losses[0, 0].item(), s.grad[0, :12].cpu().numpy())
+    assert runs[0][0] == runs[_lib.FLAG_DEEP_TILE][0] and np.array_equal(runs[0][1], runs[_lib.FLAG_DEEP_TILE][1])
+    g_r = runs[_lib.FLAG_NO_ROT_DEEP_TILE][1]
+    assert not np.array_equal(runs[0][1], g_r)
+    assert np.max(np.abs(runs[0][1] - g_r)) <= 2e-5 * np.max(np.abs(g_r)) and abs(runs[0][0] - runs[_lib.FLAG_NO_ROT_DEEP_TILE][0]) <= 2e-6 * abs(runs[0][0])
 
 
 def test_rotated_deep_tile_mixed_batch(eng):

@@ -1980,7 +1980,10 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             }
             // GeomRD (GeomR's box under a 16 x 16 x 16 tile) joins under the same condition: rotations whose pre-image still fits that box
             TileGeom trd = TileGeom{};
-            if (aware && nblk_rd != nullptr && (MODE == 0 || MODE == 4) && TRX_ROT_DEEP_TILE && !(vol->flags & TRX_FLAG_NO_ROT_DEEP_TILE)) trd = tile_geom<GeomRD>(*vol);
+            if (aware && nblk_rd != nullptr && (MODE == 0 || MODE == 4) && TRX_ROT_DEEP_TILE && !(vol->flags & TRX_FLAG_NO_ROT_DEEP_TILE)) {
+                const TileGeom cand = tile_geom<GeomRD>(*vol);
+                if (cand.ntiles >= 128 || (vol->flags & TRX_FLAG_DEEP_TILE)) trd = cand;   // tiny volumes (<= 64^3: at most 64 of these tiles) stay with GeomR's smaller tiles: measured +5 ... +14 % otherwise
+            }
             int gxx = gx;
             if (td.blocks_per_pair > gxx) gxx = td.blocks_per_pair;
             if (trd.blocks_per_pair > gxx) gxx = trd.blocks_per_pair;
