@@ -22,7 +22,11 @@
 
 namespace trx {
 
-constexpr int kLX = 32, kLY = 8;            // output tile of a block in x, y
+#ifndef TRX_LNCC_TWO_ROWS
+#define TRX_LNCC_TWO_ROWS 1   // 1: a thread owns two y-adjacent outputs (32 x 16 tile per plane); 0: one output (32 x 8 tile) - measured alternative
+#endif
+constexpr int kLO = TRX_LNCC_TWO_ROWS ? 2 : 1;      // outputs per thread: rows kLO * (tid >> 5) + o of the tile
+constexpr int kLX = 32, kLY = 8 * kLO;      // output tile of a block in x, y
 constexpr int kLRows = kLY + 8, kLCols = kLX + 8;   // tile + halo 4 (the largest radius)
 
 constexpr int kLCells = (kLRows * kLCols + TRX_BLOCK - 1) / TRX_BLOCK;   // tile cells per thread (3)
@@ -56,7 +60,7 @@ __device__ __forceinline__ void plane_fetch(int zin, int D, int H, int W, int X0
 // All threads of the block must call this together.
 template <int R, int NF, int NL, typename Expand>
 __device__ __forceinline__ void plane_window_sums(const PlaneRegs<NL> &r, Expand expand, float (*raw)[kLRows][kLCols],
-                                                  float (*xs)[kLX][kLRows + 1], float (&P)[NF])
+                                                  float (*xs)[kLX][kLRows + 1], float (&P)[kLO][NF])
 {
     const int tid = threadIdx.x;
     __syncthreads();   // the previous plane's LDS reads are done
@@ -90,13 +94,21 @@ __device__ __forceinline__ void plane_window_sums(const PlaneRegs<NL> &r, Expand
         }
     }
     __syncthreads();
-    const int ox = tid & (kLX - 1), oy = tid >> 5;
+    // y window: the kLO outputs of a thread are adjacent rows, so their windows share 2R of their 2R + 1 rows: 2R + kLO LDS reads for kLO
+    // outputs; every output is still its own (2R + 1)-term sum in a fixed order
+    const int ox = tid & (kLX - 1), oy = kLO * (tid >> 5);
 #pragma unroll
     for (int f = 0; f < NF; f++) {
-        float s = 0.f;
+        float v[2 * R + kLO];
 #pragma unroll
-        for (int k = -R; k <= R; k++) s += xs[f][ox][oy + 4 + k];
-        P[f] = s;
+        for (int k = 0; k < 2 * R + kLO; k++) v[k] = xs[f][ox][oy + 4 - R + k];
+#pragma unroll
+        for (int o = 0; o < kLO; o++) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * R; k++) s += v[o + k];
+            P[o][f] = s;
+        }
     }
 }
 
@@ -108,27 +120,31 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
 {   // output planes [z0, z1) of the column (a z segment: small batches split columns so that the chip is filled)
     PlaneRegs<NL> regs;
     if (nd == 2) {   // images: the window has no z extent
-        float P[NF];
+        float P[kLO][NF];
         plane_fetch<NL>(0, 1, H, W, X0, Y0, fetch, regs);
         plane_window_sums<R, NF, NL>(regs, expand, raw, xs, P);
-        emit(0, P);
+#pragma unroll
+        for (int o = 0; o < kLO; o++) emit(0, P[o], o);
         return;
     }
     constexpr int WN = 2 * R + 1;
-    float ring[WN][NF], Z[NF];
+    float ring[kLO][WN][NF], Z[kLO][NF];
 #pragma unroll
-    for (int k = 0; k < WN; k++)
+    for (int o = 0; o < kLO; o++) {
 #pragma unroll
-        for (int f = 0; f < NF; f++) ring[k][f] = 0.f;
+        for (int k = 0; k < WN; k++)
 #pragma unroll
-    for (int f = 0; f < NF; f++) Z[f] = 0.f;
+            for (int f = 0; f < NF; f++) ring[o][k][f] = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; f++) Z[o][f] = 0.f;
+    }
     plane_fetch<NL>(z0 - R, D, H, W, X0, Y0, fetch, regs);
     for (int base = z0 - R; base < z1 + R; base += WN) {
 #pragma unroll
         for (int k = 0; k < WN; k++) {
             const int zin = base + k;
             if (zin < z1 + R) {
-                float P[NF];
+                float P[kLO][NF];
                 if (zin >= 0 && zin < D) {   // uniform
                     PlaneRegs<NL> cur = regs;
                     plane_fetch<NL>(zin + 1, D, H, W, X0, Y0, fetch, regs);   // next plane in flight during this plane's passes
@@ -136,22 +152,27 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
                 } else {                     // planes outside the volume are zero padding
                     plane_fetch<NL>(zin + 1, D, H, W, X0, Y0, fetch, regs);
 #pragma unroll
-                    for (int f = 0; f < NF; f++) P[f] = 0.f;
+                    for (int o = 0; o < kLO; o++)
+#pragma unroll
+                        for (int f = 0; f < NF; f++) P[o][f] = 0.f;
                 }
 #pragma unroll
-                for (int f = 0; f < NF; f++) {
-                    if (k == 0) {   // once per ring turn: exact re-summation instead of the running update
-                        ring[0][f] = P[f];
-                        float s = 0.f;
+                for (int o = 0; o < kLO; o++) {
 #pragma unroll
-                        for (int j = 0; j < WN; j++) s += ring[j][f];
-                        Z[f] = s;
-                    } else {
-                        Z[f] += P[f] - ring[k][f];
-                        ring[k][f] = P[f];
+                    for (int f = 0; f < NF; f++) {
+                        if (k == 0) {   // once per ring turn: exact re-summation instead of the running update
+                            ring[o][0][f] = P[o][f];
+                            float s = 0.f;
+#pragma unroll
+                            for (int j = 0; j < WN; j++) s += ring[o][j][f];
+                            Z[o][f] = s;
+                        } else {
+                            Z[o][f] += P[o][f] - ring[o][k][f];
+                            ring[o][k][f] = P[o][f];
+                        }
                     }
+                    if (zin - R >= z0) emit(zin - R, Z[o], o);
                 }
-                if (zin - R >= z0) emit(zin - R, Z);
             }
         }
     }
@@ -168,8 +189,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_fields_kernel(const float *__r
     const size_t n = (size_t)D * H * W;
     const float *__restrict__ I = tgt + (size_t)b * n, *__restrict__ J = wrp + (size_t)b * n;
     float *__restrict__ F = fields + (size_t)b * 4 * n;
-    const int tid = threadIdx.x, x = X0 + (tid & (kLX - 1)), y = Y0 + (tid >> 5);
-    const bool live = (x < W) && (y < H);
+    const int tid = threadIdx.x, x = X0 + (tid & (kLX - 1)), y = Y0 + kLO * (tid >> 5);   // this thread's rows: y, ..., y + kLO - 1
     const float wn = (nd == 3) ? (float)((2 * R + 1) * (2 * R + 1) * (2 * R + 1)) : (float)((2 * R + 1) * (2 * R + 1));
     const float inv_n = 1.0f / wn;
     float lsum = 0.f;
@@ -183,15 +203,15 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_fields_kernel(const float *__r
         const float i = in[0], j = in[1];
         cell[0] = i; cell[FS] = j; cell[2 * FS] = i * i; cell[3 * FS] = j * j; cell[4 * FS] = i * j;
     };
-    auto emit = [&](int z, const float (&Z)[5]) {
-        if (!live) return;
+    auto emit = [&](int z, const float (&Z)[5], int o) {
+        if (x >= W || y + o >= H) return;
         const float Is = Z[0], Js = Z[1];
         const float c = Z[4] - Is * Js * inv_n, a = Z[2] - Is * Is * inv_n, bv = Z[3] - Js * Js * inv_n;
         const float den = a * bv + eps, rden = 1.0f / den;
         const float Pq = 2.0f * c * rden, Qq = Pq * c * a * rden;
         lsum += c * c * rden;
-        const size_t o = ((size_t)z * H + y) * W + x;
-        F[o] = Pq; F[n + o] = Pq * (Is * inv_n); F[2 * n + o] = Qq; F[3 * n + o] = Qq * (Js * inv_n);
+        const size_t off = ((size_t)z * H + y + o) * W + x;
+        F[off] = Pq; F[n + off] = Pq * (Is * inv_n); F[2 * n + off] = Qq; F[3 * n + off] = Qq * (Js * inv_n);
     };
     column_walk<R, 5, 2>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, emit, raw, xs);
     // block sum of the cc partials in a fixed order: butterfly inside each wave, then the 4 wave sums through LDS
@@ -217,8 +237,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_grad_kernel(const float *__res
     const float *__restrict__ I = tgt + (size_t)b * n, *__restrict__ J = wrp + (size_t)b * n;
     const float *__restrict__ F = fields + (size_t)b * 4 * n;
     float *__restrict__ G = grad + (size_t)b * n;
-    const int tid = threadIdx.x, x = X0 + (tid & (kLX - 1)), y = Y0 + (tid >> 5);
-    const bool live = (x < W) && (y < H);
+    const int tid = threadIdx.x, x = X0 + (tid & (kLX - 1)), y = Y0 + kLO * (tid >> 5);
     constexpr int FS = kLRows * kLCols;
     auto fetch = [&](int z, int gy, int gx, float (&o)[4]) {
         const size_t off = ((size_t)z * H + gy) * W + gx;
@@ -229,10 +248,10 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_grad_kernel(const float *__res
 #pragma unroll
         for (int f = 0; f < 4; f++) cell[f * FS] = in[f];
     };
-    auto emit = [&](int z, const float (&Z)[4]) {
-        if (!live) return;
-        const size_t o = ((size_t)z * H + y) * W + x;
-        G[o] = scale * (I[o] * Z[0] - Z[1] - J[o] * Z[2] + Z[3]);
+    auto emit = [&](int z, const float (&Z)[4], int o) {
+        if (x >= W || y + o >= H) return;
+        const size_t off = ((size_t)z * H + y + o) * W + x;
+        G[off] = scale * (I[off] * Z[0] - Z[1] - J[off] * Z[2] + Z[3]);
     };
     column_walk<R, 4, 4>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, emit, raw, xs);
 }
@@ -253,12 +272,15 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_finalize_kernel(const float *_
     if (tid == 0) loss[b] = (float)((double)alpha * (1.0 - red[0] / nvox));
 }
 
-// z segments per column: enough blocks for >= ~4 per CU, each segment at least 32 planes deep (it re-reads 2R halo planes)
-static int lncc_zsplit(int nd, int B, int D, int H, int W)
+// z segments per column: enough blocks to fill the block slots the kernels' registers allow (two-row version: 140 VGPRs up to w = 5 ->
+// three 256-thread blocks per CU, 180 for w = 7, 9 -> two), each segment at least 32 planes deep (it re-reads 2R halo planes).
+// R = 0: the largest split of any window (workspace sizing).
+static int lncc_zsplit(int nd, int B, int D, int H, int W, int R)
 {
     if (nd == 2) return 1;
     const long cols = (long)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * B;
-    long z = (1024 + cols - 1) / cols;
+    const long want = TRX_LNCC_TWO_ROWS ? ((R <= 2) ? 768 : 512) : 1024;
+    long z = (want + cols - 1) / cols;
     if (z > D / 32) z = D / 32;
     return (int)(z < 1 ? 1 : z);
 }
@@ -267,7 +289,7 @@ template <int R>
 static int launch_lncc(const float *target, const float *warped, int nd, int B, int D, int H, int W, float alpha, float eps, float *loss, float *grad,
                        float *fields, float *partials, hipStream_t s)
 {
-    const int zsplit = lncc_zsplit(nd, B, D, H, W);
+    const int zsplit = lncc_zsplit(nd, B, D, H, W, R);
     dim3 grid((W + kLX - 1) / kLX, (H + kLY - 1) / kLY, B * zsplit), block(TRX_BLOCK);
     hipLaunchKernelGGL((lncc_fields_kernel<R>), grid, block, 0, s, target, warped, nd, D, H, W, zsplit, eps, fields, partials);
     TRX_CHECK_LAUNCH();
@@ -285,7 +307,7 @@ static int launch_lncc(const float *target, const float *warped, int nd, int B, 
 
 static size_t lncc_partials_bytes(int nd, int B, int D, int H, int W)
 {
-    const size_t nb = (size_t)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * lncc_zsplit(nd, B, D, H, W);
+    const size_t nb = (size_t)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * lncc_zsplit(nd, B, D, H, W, 0);
     return ((size_t)B * nb * sizeof(float) + 255) & ~(size_t)255;
 }
 
