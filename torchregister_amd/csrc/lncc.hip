@@ -25,6 +25,10 @@ namespace trx {
 #ifndef TRX_LNCC_TWO_ROWS
 #define TRX_LNCC_TWO_ROWS 1   // 1: a thread owns two y-adjacent outputs (32 x 16 tile per plane); 0: one output (32 x 8 tile) - measured alternative
 #endif
+// Registers: the two-row version takes 140 VGPRs up to w = 5 and 180 for w = 7, 9 (the z ring: 2 x 9 x 5) = two 256-thread blocks per
+// CU; under __launch_bounds__(256, 3) the same code fits 160 without spilling = three blocks.  Measured on one box (256^3, w = 9, loss +
+// gradient): one pair 371 us with two blocks per CU, 336 us with three (six z segments fill 768 slots); eight pairs 2.62 ms with two,
+// 2.83 ms with three - so the three-wave build runs w = 7, 9 when the batch is small enough to be z-split, the default build otherwise.
 constexpr int kLO = TRX_LNCC_TWO_ROWS ? 2 : 1;      // outputs per thread: rows kLO * (tid >> 5) + o of the tile
 constexpr int kLX = 32, kLY = 8 * kLO;      // output tile of a block in x, y
 constexpr int kLRows = kLY + 8, kLCols = kLX + 8;   // tile + halo 4 (the largest radius)
@@ -178,8 +182,8 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
     }
 }
 
-template <int R>
-__global__ __launch_bounds__(TRX_BLOCK) void lncc_fields_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
+template <int R, int MW>
+__global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_fields_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
                                                                int W, int zsplit, float eps, float *__restrict__ fields, float *__restrict__ partials)
 {
     __shared__ __attribute__((aligned(16))) float raw[5][kLRows][kLCols];   // I, J, I^2, J^2, I J of the tile (+halo)
@@ -225,8 +229,8 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_fields_kernel(const float *__r
     if (tid == 0) partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
-template <int R>
-__global__ __launch_bounds__(TRX_BLOCK) void lncc_grad_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
+template <int R, int MW>
+__global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_grad_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
                                                              int W, int zsplit, float scale, const float *__restrict__ fields, float *__restrict__ grad)
 {
     __shared__ __attribute__((aligned(16))) float raw[4][kLRows][kLCols];
@@ -272,26 +276,23 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_finalize_kernel(const float *_
     if (tid == 0) loss[b] = (float)((double)alpha * (1.0 - red[0] / nvox));
 }
 
-// z segments per column: enough blocks to fill the block slots the kernels' registers allow (two-row version: 140 VGPRs up to w = 5 ->
-// three 256-thread blocks per CU, 180 for w = 7, 9 -> two), each segment at least 32 planes deep (it re-reads 2R halo planes).
-// R = 0: the largest split of any window (workspace sizing).
+// z segments per column: enough blocks to fill the block slots, each segment at least 32 planes deep (it re-reads 2R halo planes).
 static int lncc_zsplit(int nd, int B, int D, int H, int W, int R)
 {
     if (nd == 2) return 1;
     const long cols = (long)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * B;
-    const long want = TRX_LNCC_TWO_ROWS ? ((R <= 2) ? 768 : 512) : 1024;
+    const long want = TRX_LNCC_TWO_ROWS ? 768 : 1024;   // block slots (two-row version: three 256-thread blocks per CU, see above)
     long z = (want + cols - 1) / cols;
     if (z > D / 32) z = D / 32;
     return (int)(z < 1 ? 1 : z);
 }
 
-template <int R>
-static int launch_lncc(const float *target, const float *warped, int nd, int B, int D, int H, int W, float alpha, float eps, float *loss, float *grad,
-                       float *fields, float *partials, hipStream_t s)
+template <int R, int MW>
+static int launch_lncc_mw(const float *target, const float *warped, int nd, int B, int D, int H, int W, float alpha, float eps, float *loss, float *grad,
+                          float *fields, float *partials, int zsplit, hipStream_t s)
 {
-    const int zsplit = lncc_zsplit(nd, B, D, H, W, R);
     dim3 grid((W + kLX - 1) / kLX, (H + kLY - 1) / kLY, B * zsplit), block(TRX_BLOCK);
-    hipLaunchKernelGGL((lncc_fields_kernel<R>), grid, block, 0, s, target, warped, nd, D, H, W, zsplit, eps, fields, partials);
+    hipLaunchKernelGGL((lncc_fields_kernel<R, MW>), grid, block, 0, s, target, warped, nd, D, H, W, zsplit, eps, fields, partials);
     TRX_CHECK_LAUNCH();
     const double nvox = (double)D * H * W;
     if (loss) {
@@ -299,10 +300,20 @@ static int launch_lncc(const float *target, const float *warped, int nd, int B, 
         TRX_CHECK_LAUNCH();
     }
     if (grad) {
-        hipLaunchKernelGGL((lncc_grad_kernel<R>), grid, block, 0, s, target, warped, nd, D, H, W, zsplit, (float)(-(double)alpha / nvox), fields, grad);
+        hipLaunchKernelGGL((lncc_grad_kernel<R, MW>), grid, block, 0, s, target, warped, nd, D, H, W, zsplit, (float)(-(double)alpha / nvox), fields, grad);
         TRX_CHECK_LAUNCH();
     }
     return TRX_OK;
+}
+
+template <int R>
+static int launch_lncc(const float *target, const float *warped, int nd, int B, int D, int H, int W, float alpha, float eps, float *loss, float *grad,
+                       float *fields, float *partials, hipStream_t s)
+{
+    const int zsplit = lncc_zsplit(nd, B, D, H, W, R);
+    if (TRX_LNCC_TWO_ROWS && R >= 3 && zsplit > 1)   // a small batch of a wide window: the three-blocks-per-CU build (see the note on registers above)
+        return launch_lncc_mw<R, 3>(target, warped, nd, B, D, H, W, alpha, eps, loss, grad, fields, partials, zsplit, s);
+    return launch_lncc_mw<R, 1>(target, warped, nd, B, D, H, W, alpha, eps, loss, grad, fields, partials, zsplit, s);
 }
 
 static size_t lncc_partials_bytes(int nd, int B, int D, int H, int W)
