@@ -48,6 +48,8 @@ typedef enum {
 #define TRX_FLAG_TWO_PASS_FLOW 4u  /* trx_flow_run: keep the moments pass of every iteration (no fusion into the previous update) */
 #define TRX_FLAG_DEEP_TILE 8u      /* affine steps: offer the deep tiles (GeomD, GeomRD) to every pair they fit, whatever the batch and volume size
                                       (by default only where their larger tiles still fill the chip) */
+#define TRX_FLAG_NO_ZSTREAM 32u     /* affine steps: never use the z-streaming body (pairs next to the identity run GeomD / GeomA like the others) */
+#define TRX_FLAG_ZSTREAM 64u        /* affine steps: offer the z-streaming body whatever the batch size (by default only to launches that fill the chip) */
 #define TRX_FLAG_NO_ROT_DEEP_TILE 16u /* affine steps: never use GeomRD (the 16 x 16 x 16 tile in GeomR's box) - rotated pairs all run GeomR */
 
 /* A batch of B independent (moving, target) pairs. */
@@ -105,6 +107,11 @@ const char *trx_status_string(int status);
 
 /* Bytes of scratch the affine entry points need for this batch geometry. */
 size_t trx_affine_workspace_bytes(const trx_volumes *vol /*[host]*/);
+
+/* Diagnostics: byte offset, inside the affine workspace, of int rows_used[B] - the number of partial rows the last 3-D step's streaming
+ * launch wrote for each pair.  The step kernels pick a kernel body per pair from theta (tile geometry / z-streaming) and each body has its
+ * own row count, so this tells a test or a profiler which body ran; the step's own reduction reads the same array. */
+size_t trx_affine_workspace_rows_offset(const trx_volumes *vol /*[host]*/);
 
 /* ONE optimiser iteration for all B pairs: fused forward warp + loss + analytic backward
  * (single pass over moving/target), then loss/gradient/optimiser/best-tracking on device.

@@ -1,0 +1,120 @@
+"""GPU parity of the z-streaming F1 body (csrc/affine_zstream.h): the per-pair choice the step kernels make for transforms next
+to the identity.  TRX_FLAG_ZSTREAM offers it whatever the batch size (by default only launches that fill the chip get it), so small
+volumes exercise every part of it: window origin at volume faces (zero padding in x / y / z), several z segments, the ring wrap,
+translations by whole voxels, pairs of one batch choosing different bodies.
+Checker: the C oracle in fp64 (tolerance: loss 2e-5 rel, gradient 2e-4 of max - the fp32 floors of test_gpu_affine.py) and the
+tile kernels on the same inputs (TRX_FLAG_NO_ZSTREAM)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import phantoms as ph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torchregister_amd._engine as e
+    assert torch.cuda.is_available()
+    return e
+
+
+def near_identity(seed, eps, shift=(0.0, 0.0, 0.0)):
+    """identity + eps * (irrational-ish pattern in [-1, 1]) - never puts whole lines of samples on integer coordinates"""
+    k = np.arange(12, dtype=np.float64).reshape(3, 4)
+    th = np.eye(3, 4) + eps * np.sin(1.2345 * (k + 1.0) + 0.77 * seed)
+    th[:, 3] += np.asarray(shift)
+    return th
+
+
+# (D, H, W): W % 64 == 0, H % 32 == 0 - the shapes the body tiles
+SHAPES = [(16, 32, 64), (40, 64, 64), (24, 32, 128), (33, 96, 64), (70, 64, 128)]
+CASES = [("eps3e-3", 3e-3, (0, 0, 0)), ("eps1e-2", 1e-2, (0, 0, 0)), ("shift", 4e-3, (0.11, -0.07, 0.2)), ("eps2e-2", 2e-2, (0.01, 0.02, -0.03))]
+
+
+def ran_zstream(solver, eng):
+    """rows_used[b] (the dual kernel's note to the finalise kernel) == the z-streaming body's block count?"""
+    return solver.rows_used().tolist()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("kw", [dict(w_ncc=1.0, w_mse=0.5), dict(w_mse=1.0, w_ssd=0.3)], ids=["ncc", "mse"])
+def test_zstream_step_vs_oracle(eng, shape, case, kw):
+    from torchregister_amd import _lib
+    _, eps, shift = case
+    tgt = ph.blobs(shape, 31)
+    mov = ph.blobs(shape, 32) + 0.1 * ph.vol(shape, 0.013, "sin")
+    th = torch.tensor(near_identity(sum(shape), eps, shift), dtype=torch.float32)[None]
+    out = {}
+    for name, flags in (("zs", _lib.FLAG_ZSTREAM), ("tile", _lib.FLAG_NO_ZSTREAM)):
+        s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=flags)
+        s.run(1)
+        torch.cuda.synchronize()
+        out[name] = (s.losses[0, 0].item(), s.grad[0, :12].cpu().numpy().reshape(3, 4), s.rows_used().tolist())
+    total, _, dth, _ = oracle.c_affine_loss_grad(mov[0, 0].double().numpy(), tgt[0, 0].double().numpy(), th[0].double().numpy(), oracle.wts(**kw),
+                                                 oracle.base_tables(shape, np.float64))
+    for name in ("zs", "tile"):
+        loss, grad, _ = out[name]
+        assert abs(loss - total) <= 2e-5 * max(1.0, abs(total)), (name, loss, total)
+        assert np.max(np.abs(grad - dth)) <= 2e-4 * np.max(np.abs(dth)), (name, grad, dth)
+    assert out["zs"][2] != out["tile"][2] or eps >= 2e-2, "the z-streaming body did not run (same row count as the tile kernels)"
+
+
+def test_zstream_identity_is_exact(eng):
+    """theta = identity: every sample sits on a voxel, the warp is the identity: fused MSE == mean((moving - target)^2), and the
+    loss is bitwise the tile kernels' (same per-voxel arithmetic; only the order of the block sums differs -> 1e-6)."""
+    from torchregister_amd import _lib
+    shape = (24, 64, 128)
+    tgt, mov = ph.blobs(shape, 5), ph.blobs(shape, 6)
+    th = torch.eye(3, 4)[None]
+    vals = []
+    for flags in (_lib.FLAG_ZSTREAM, _lib.FLAG_NO_ZSTREAM):
+        s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(w_mse=1.0), lr=0.0, init=th, capacity=1, flags=flags)
+        s.run(1)
+        torch.cuda.synchronize()
+        vals.append(s.losses[0, 0].item())
+    ref = ((mov.double() - tgt.double()) ** 2).mean().item()
+    assert abs(vals[0] - ref) <= 2e-6 * ref and abs(vals[0] - vals[1]) <= 2e-6 * ref
+
+
+def test_zstream_mixed_batch_and_trajectory(eng):
+    """One batch whose pairs choose different bodies (z-streaming / GeomA / GeomR) follows the single-geometry launches; ten Adam
+    iterations from the identity stay on the tile kernels' trajectory."""
+    from torchregister_amd import _lib
+    shape = (32, 64, 64)
+    n = 4
+    tgt = torch.cat([ph.blobs(shape, 300 + i) for i in range(n)])
+    mov = torch.cat([ph.blobs(shape, 400 + i) for i in range(n)])
+    ths = [near_identity(1, 4e-3), near_identity(2, 0.08), np.eye(3, 4), near_identity(3, 0.3)]
+    th = torch.stack([torch.tensor(t, dtype=torch.float32) for t in ths])
+    res = []
+    for flags in (_lib.FLAG_ZSTREAM, _lib.FLAG_NO_ZSTREAM):
+        s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(w_ncc=1.0), optimizer="adam", lr=1e-3, init=th, capacity=10, flags=flags)
+        s.run(10)
+        torch.cuda.synchronize()
+        res.append((s.losses.clone(), s.theta.clone(), s.rows_used().tolist()))
+    assert len(set(res[0][2])) > 1, res[0][2]            # pairs of the launch ran different bodies
+    assert torch.allclose(res[0][0], res[1][0], rtol=3e-5, atol=3e-5)
+    assert torch.allclose(res[0][1], res[1][1], rtol=0, atol=3e-5)
+
+
+def test_zstream_default_choice_at_headline_share(eng):
+    """8 x 128 x 128 x 128 ... the default (no flag) offers the body to launches that fill the chip: 8 pairs of 256^3 is the
+    headline; here a smaller launch that still qualifies (B = 16 x 64 x 128 x 128: 16 x 8 columns x 4 segments) against the oracle."""
+    shape = (64, 128, 128)
+    B = 16
+    tgt = torch.cat([ph.blobs(shape, 500 + i) for i in range(2)]).repeat(B // 2, 1, 1, 1, 1)
+    mov = torch.cat([ph.blobs(shape, 600 + i) for i in range(2)]).repeat(B // 2, 1, 1, 1, 1)
+    th = torch.tensor(near_identity(7, 5e-3), dtype=torch.float32)[None].repeat(B, 1, 1)
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=0.0, init=th, capacity=1)
+    s.run(1)
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        total, _, dth, _ = oracle.c_affine_loss_grad(mov[i, 0].double().numpy(), tgt[i, 0].double().numpy(), th[i].double().numpy(), oracle.wts(w_ncc=1.0),
+                                                     oracle.base_tables(shape, np.float64))
+        assert abs(s.losses[i, 0].item() - total) <= 2e-5 * max(1.0, abs(total))
+        assert np.max(np.abs(s.grad[i, :12].cpu().numpy().reshape(3, 4) - dth)) <= 2e-4 * np.max(np.abs(dth))
+    assert torch.equal(s.losses[0], s.losses[2]) and torch.equal(s.grad[1], s.grad[3])   # slot independence, bit for bit

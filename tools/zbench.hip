@@ -1,0 +1,123 @@
+// Development harness for the z-streaming F1 kernel (not shipped): correctness against the tile kernel's 41 sums and hipEvent timing.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize -DTRX_DEV tools/zbench.hip -o build/zbench
+//   build/zbench [B] [S] [eps]      eps: size of the deviation of theta from the identity (0 = identity)
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../torchregister_amd/csrc/affine.hip"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+template <typename F>
+static float time_it(F f, int reps)
+{
+    
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < (reps >= 50 ? 150 : 5); i++) f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; i++) f();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1000.f / reps;
+}
+
+int main(int argc, char **argv)
+{
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const int B = argc > 1 ? atoi(argv[1]) : 8, S = argc > 2 ? atoi(argv[2]) : 256;
+    const float eps = argc > 3 ? (float)atof(argv[3]) : 0.004f;
+    const int reps = argc > 4 ? atoi(argv[4]) : 100;
+    const bool zonly = argc > 5;   // profiling runs: only the first z-streaming kernel
+    const size_t nvox = (size_t)S * S * S, n = nvox * B;
+    std::vector<float> h(n);
+    srand(1);
+    // smooth-ish random volumes: random values low-pass filtered along x so that gradients are not pure noise
+    for (size_t i = 0; i < n; i++) h[i] = (float)rand() / RAND_MAX;
+    float *mov, *tgt, *theta, *partials;
+    CK(hipMalloc(&mov, n * 4)); CK(hipMalloc(&tgt, n * 4));
+    CK(hipMemcpy(mov, h.data(), n * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < n; i++) h[i] = (float)rand() / RAND_MAX;
+    CK(hipMemcpy(tgt, h.data(), n * 4, hipMemcpyHostToDevice));
+    std::vector<float> th(B * 12);
+    const float id[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int b = 0; b < B; b++)
+        for (int i = 0; i < 12; i++) th[b * 12 + i] = id[i] + eps * (2.f * rand() / RAND_MAX - 1.f);
+    CK(hipMalloc(&theta, B * 12 * 4));
+    CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
+    float *tab;
+    CK(hipMalloc(&tab, 3 * S * 4));
+    hipLaunchKernelGGL(trx::fill_tables_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, tab, S, S, S);
+    trx_volumes vol = {mov, tgt, nvox, nvox, 3, B, S, S, S, tab, tab + S, tab + 2 * S, 0};
+    const size_t prow = 8192;
+    CK(hipMalloc(&partials, (size_t)B * prow * 41 * 4));
+    const double alg = 8.0 * nvox;
+    auto rep = [&](const char *name, float us) { printf("%-34s %9.1f us/launch  %7.2f us/pair  %6.2f TB/s alg  frac %.3f\n", name, us, us / B, alg * B / us / 1e6, alg * B / us / 1e6 / 8.0); };
+    auto sums = [&](int rows) {
+        std::vector<float> hp((size_t)B * rows * 41);
+        CK(hipMemcpy(hp.data(), partials, hp.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<double> out((size_t)B * 41, 0.0);
+        for (int b = 0; b < B; b++) for (int r = 0; r < rows; r++) for (int k = 0; k < 41; k++) out[b * 41 + k] += hp[((size_t)b * rows + r) * 41 + k];
+        return out;
+    };
+    const trx::TileGeom tgm = trx::tile_geom(vol);
+    dim3 tgrid(tgm.blocks_per_pair, B);
+    CK(hipMemset(partials, 0, (size_t)B * prow * 41 * 4));
+    hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials);
+    CK(hipDeviceSynchronize());
+    const std::vector<double> ref = sums(tgm.blocks_per_pair);
+    auto check = [&](const char *name, int rows) {
+        const std::vector<double> got = sums(rows);
+        double worst = 0; int wk = -1;
+        bool nan = false;
+        for (int b = 0; b < B; b++) {
+            double scale = 0;
+            for (int k = 5; k < 41; k++) scale = std::max(scale, fabs(ref[b * 41 + k]));
+            for (int k = 0; k < 41; k++) {
+                if (!(got[b * 41 + k] == got[b * 41 + k])) nan = true;
+                const double e = fabs(got[b * 41 + k] - ref[b * 41 + k]) / (k < 5 ? std::max(1.0, fabs(ref[b * 41 + k])) : scale);
+                if (e > worst) { worst = e; wk = k; }
+            }
+        }
+        printf("%s vs tile: worst relative difference of the 41 sums %.3e (sum %d)%s   Sw %.6f / %.6f\n", name, worst, wk, nan ? "  NaN: window does not fit" : "", got[1], ref[1]);
+    };
+    auto run_zs = [&](auto cfg, const char *name) {
+        using C = decltype(cfg);
+        if (!trx::zs_shape_ok<C>(vol)) { printf("%s: shape not supported\n", name); return; }
+        const trx::ZGeom zg = trx::zs_geom<C>(vol);
+        printf("%s geom: %d x %d columns, %d z segments of %d planes, %d blocks/pair, LDS %d B\n", name, zg.ntx, zg.nty, zg.nzseg, zg.planes_per_seg, zg.blocks_per_pair, C::Alloc * 4);
+        CK(hipMemset(partials, 0, (size_t)B * prow * 41 * 4));
+        hipLaunchKernelGGL((trx::affine_zstream_kernel<0, C>), dim3(zg.blocks_per_pair, B), dim3(C::Threads), 0, 0, vol, theta, zg, partials, zg.blocks_per_pair);
+        CK(hipDeviceSynchronize());
+        check(name, zg.blocks_per_pair);
+        rep(name, time_it([&] { hipLaunchKernelGGL((trx::affine_zstream_kernel<0, C>), dim3(zg.blocks_per_pair, B), dim3(C::Threads), 0, 0, vol, theta, zg, partials, zg.blocks_per_pair); }, reps));
+    };
+    printf("B=%d S=%d eps=%g\n", B, S, eps);
+    run_zs(trx::ZS64{}, "zstream 64x32");
+    if (zonly) return 0;
+    rep("tile MODE0 (GeomP)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, reps));
+    {
+        const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol), td = trx::tile_geom<trx::GeomD>(vol), trd = trx::tile_geom<trx::GeomRD>(vol);
+        int gx = std::max(std::max(ta.blocks_per_pair, tr.blocks_per_pair), std::max(td.blocks_per_pair, trd.blocks_per_pair));
+        rep("dual MODE0 (GeomD/A/RD/R per pair)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd); }, reps));
+    }
+    {   // the fused step kernel with the z-streaming body offered (what trx_affine_step launches)
+        const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol), td = trx::tile_geom<trx::GeomD>(vol), trd = trx::tile_geom<trx::GeomRD>(vol);
+        const trx::ZGeom zg = trx::zs_geom<trx::ZS64>(vol);
+        int gx = std::max(std::max(ta.blocks_per_pair, tr.blocks_per_pair), std::max(td.blocks_per_pair, trd.blocks_per_pair));
+        gx = std::max(gx, zg.blocks_per_pair);
+        int *ru; CK(hipMalloc(&ru, B * 4));
+        printf("fused grid: %d blocks/pair (A %d R %d D %d RD %d ZS %d)\n", gx, ta.blocks_per_pair, tr.blocks_per_pair, td.blocks_per_pair, trd.blocks_per_pair, zg.blocks_per_pair);
+        rep("fused dual MODE0, full grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gx); }, reps));
+        rep("fused dual MODE0, looping grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(zg.blocks_per_pair, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gx); }, reps));
+        const trx::ZGeom none = trx::ZGeom{};
+        rep("fused dual, no ZS, full grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, none, ru, gx); }, reps));
+        rep("fused dual, no ZS, looping 64", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(64, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, none, ru, gx); }, reps));
+        rep("fused dual, no ZS, looping 128", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(128, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, none, ru, gx); }, reps));
+    }
+    run_zs(trx::ZS64{}, "zstream 64x32 (again)");
+    return 0;
+}

@@ -196,6 +196,12 @@ class AffineSolver:
                                          _lib.current_stream(self.batch.device))
         _lib.check(rc, "trx_affine_run")
 
+    def rows_used(self):
+        """Partial rows the last 3-D step's streaming launch wrote per pair ([B] int32): identifies the kernel body each pair ran
+        (diagnostics / tests; host sync)."""
+        off = int(self.lib.trx_affine_workspace_rows_offset(ctypes.byref(self.vol)))
+        return self.workspace[off:off + 4 * self.batch.B].view(torch.int32).cpu()
+
     def accumulate_only(self):
         """Launch only the streaming F1 kernel (partials into the workspace); used for kernel timing."""
         with torch.cuda.device(self.batch.device):

@@ -17,7 +17,7 @@ PSTRIDE = 12
 OPT_SGD, OPT_ADAM = 0, 1
 PARAM_AFFINE, PARAM_RIGID = 0, 1
 # trx_volumes.flags (include/trx.h)
-FLAG_GATHER_PATH, FLAG_SINGLE_GEOM, FLAG_TWO_PASS_FLOW, FLAG_DEEP_TILE, FLAG_NO_ROT_DEEP_TILE = 1, 2, 4, 8, 16
+FLAG_GATHER_PATH, FLAG_SINGLE_GEOM, FLAG_TWO_PASS_FLOW, FLAG_DEEP_TILE, FLAG_NO_ROT_DEEP_TILE, FLAG_NO_ZSTREAM, FLAG_ZSTREAM = 1, 2, 4, 8, 16, 32, 64
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int_p = ctypes.POINTER(ctypes.c_int)
@@ -64,6 +64,7 @@ SIGNATURES = {
     "trx_version": (ctypes.c_int, []),
     "trx_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "trx_affine_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Volumes)]),
+    "trx_affine_workspace_rows_offset": (ctypes.c_size_t, [ctypes.POINTER(Volumes)]),
     "trx_affine_step": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.POINTER(LossCfg), ctypes.POINTER(OptCfg),
                                        ctypes.POINTER(AffineState), _P, ctypes.c_size_t, _P]),
     "trx_affine_accumulate": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, _P, ctypes.c_size_t, _P]),

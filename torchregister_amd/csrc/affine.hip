@@ -371,6 +371,12 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #ifndef TRX_ROT_DEEP_TILE
 #define TRX_ROT_DEEP_TILE 1   // the step kernels carry GeomRD as a fourth per-pair choice (0: never - measured alternative)
 #endif
+#ifndef TRX_ZS_MIN_BLOCKS
+#define TRX_ZS_MIN_BLOCKS 512   // the z-streaming body is offered to launches of at least this many of its blocks ...
+#endif
+#ifndef TRX_ZS_MIN_PLANES
+#define TRX_ZS_MIN_PLANES 64    // ... of at least this many planes each (a block pays ~7 planes of pipeline fill)
+#endif
 #ifndef TRX_SWP
 #define TRX_SWP 1   // software pipeline of the gather: LDS reads of row j+1 issued before the arithmetic of row j (0: at use)
 #endif
@@ -493,7 +499,7 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) { return __int_as
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 template <int MODE, class G>
 __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *__restrict__ theta, const TileGeom &tg, int channels,
-                                          float *__restrict__ partials, float *box, const int bx, const int by)
+                                          float *__restrict__ partials, float *box, const int bx, const int by, const int rows_stride)
 {
     // geometry of this instantiation (bx, by: the block's index in the (blocks_per_pair, pairs x channels) grid)
     constexpr int kTX = G::TX, kTY = G::TY, kTZ = G::TZ, kBW = G::BW, kBH = G::BH, kBD = G::BD, kPP = G::PP, kBufs = G::Bufs;
@@ -1198,7 +1204,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
             const float a = acc.AB[q][c].x;
             vals[o++] = xn * a; vals[o++] = acc.AB[q][c].y; vals[o++] = zn * a; vals[o++] = a;
         }
-    block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)by * gridDim.x + bx) * NP, box);
+    block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)by * rows_stride + bx) * NP, box);
 }
 
 // The primary kernel: one geometry (GeomP) for every block.
@@ -1211,8 +1217,14 @@ __global__ __launch_bounds__(GeomP::Threads, TRX_TILE_MIN_WAVES) void affine_til
 #else
     __shared__ __attribute__((aligned(16))) float box[GeomP::BoxAlloc];
 #endif
-    tile_body<MODE, GeomP>(vol, theta, tg, channels, partials, box, blockIdx.x, blockIdx.y);
+    tile_body<MODE, GeomP>(vol, theta, tg, channels, partials, box, blockIdx.x, blockIdx.y, gridDim.x);
 }
+
+#pragma clang diagnostic pop
+#include "affine_zstream.h"   // z-streaming F1 body for transforms near the identity: the fifth per-pair choice of the step kernels
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 
 // Does geometry G's box hold the pre-image of one of its tiles for this theta?  (theta-only: the tile-independent maximum extent, the same
 // bound the fast loop fetches.)  NaN / huge theta compare false: GeomR, whose own per-tile test then sends everything to the fallback.
@@ -1230,8 +1242,9 @@ __device__ __forceinline__ bool dual_fits(const float *__restrict__ th, float fD
 }
 // The geometry a pair's blocks run (0 = GeomD, the deep tile, step kernels only; 1 = GeomA; 2 = GeomR; 3 = GeomRD, step kernels only): evaluated identically by every
 // block of the pair and by the step's finalise kernel.
-__device__ __forceinline__ int dual_choice(const float *__restrict__ th, float fD, float fH, float fW, bool with_deep, bool with_rd = false)
+__device__ __forceinline__ int dual_choice(const float *__restrict__ th, float fD, float fH, float fW, bool with_deep, bool with_rd = false, int zs_planes = 0)
 {
+    if (zs_planes > 0 && zs_nsub<ZS64>(th, fD, fH, fW, zs_planes) > 0) return 4;   // 4 = the z-streaming body (step kernels only, transforms next to the identity)
     if (with_deep && dual_fits<GeomD>(th, fD, fH, fW)) return 0;
     if (dual_fits<GeomA>(th, fD, fH, fW)) return 1;
     return (with_rd && dual_fits<GeomRD>(th, fD, fH, fW)) ? 3 : 2;   // 3 = GeomRD: GeomR's box under a 16 x 16 x 16 tile, where the pre-image still fits it
@@ -1246,55 +1259,73 @@ __device__ __forceinline__ int dual_choice(const float *__restrict__ th, float f
 template <int MODE, int WHICH = 0>
 __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tgA,
                                                                                    TileGeom tgR, int channels, float *__restrict__ partials,
-                                                                                   int zero_surplus = 1, TileGeom tgD = TileGeom{}, TileGeom tgRD = TileGeom{})
+                                                                                   int zero_surplus = 1, TileGeom tgD = TileGeom{}, TileGeom tgRD = TileGeom{},
+                                                                                   ZGeom zg = ZGeom{}, int *__restrict__ rows_used = nullptr, int rows_stride = 0)
 {
     static_assert(GeomA::Threads == 512 && GeomR::Threads == 512 && GeomD::Threads == 512 && GeomRD::Threads == 512, "every geometry runs 512-thread blocks");
     static_assert(GeomRD::BoxAlloc <= GeomR::BoxAlloc, "GeomRD lives in GeomR's box");
     // the step kernels (MODE 0 / 4) of the one-launch form also carry the deep tile for transforms next to the identity
     constexpr bool kDeep = (WHICH == 0) && (MODE == 0 || MODE == 4) && (TRX_TILE_CFG == 0) && (TRX_DEEP_TILE != 0);
     constexpr int kAllocAR = GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc;
-    constexpr int kAlloc = WHICH == 1 ? GeomA::BoxAlloc : (WHICH == 2 ? GeomR::BoxAlloc : ((kDeep && GeomD::BoxAlloc > kAllocAR) ? GeomD::BoxAlloc : kAllocAR));
+    constexpr int kAllocD = WHICH == 1 ? GeomA::BoxAlloc : (WHICH == 2 ? GeomR::BoxAlloc : ((kDeep && GeomD::BoxAlloc > kAllocAR) ? GeomD::BoxAlloc : kAllocAR));
+    constexpr int kAlloc = (kDeep && ZS64::Alloc > kAllocD) ? ZS64::Alloc : kAllocD;
     __shared__ __attribute__((aligned(16))) float box[kAlloc];
     constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : (MODE == 4 ? kNpMse : 5));
     const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
     const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
     const int choice = __builtin_amdgcn_readfirstlane(dual_choice(th, (float)vol.D, (float)vol.H, (float)vol.W, kDeep && tgD.blocks_per_pair > 0,
-                                                                  kDeep && tgRD.blocks_per_pair > 0));
+                                                                  kDeep && tgRD.blocks_per_pair > 0, kDeep && zg.blocks_per_pair > 0 ? zg.planes_per_seg : 0));
     const bool useA = choice == 1;
     if ((WHICH == 1 && !useA) || (WHICH == 2 && useA)) return;   // the other launch owns this pair (and its surplus rows)
-    const int mine = choice == 0 ? tgD.blocks_per_pair : (choice == 3 ? tgRD.blocks_per_pair : (useA ? tgA.blocks_per_pair : tgR.blocks_per_pair));
+    const int mine = choice == 4 ? zg.blocks_per_pair
+                                 : (choice == 0 ? tgD.blocks_per_pair : (choice == 3 ? tgRD.blocks_per_pair : (useA ? tgA.blocks_per_pair : tgR.blocks_per_pair)));
+    // zero_surplus = 0: surplus blocks write nothing; the reader (the step's finalise kernel) learns the pair's row count from rows_used[],
+    // written here by the pair's first block - it does not repeat the choice (two inlined copies of a float test could disagree by an ulp)
+    if (rows_used && blockIdx.x == 0 && threadIdx.x == 0) rows_used[blockIdx.y] = mine;
+    // rows_stride != 0: the grid has FEWER blocks per pair than the geometry with the most (the launcher sized it for the z-streaming
+    // body) and block x runs the pair's blocks x, x + gridDim.x, ... in turn - no surplus blocks.  A grid sized for the largest geometry
+    // makes every pair of a smaller one dispatch hundreds of blocks that exit at once, in front of the next pair's working blocks:
+    // 3584 such blocks cost the 8 x 256^3 launch 33 us (tools/zbench.hip).
+    const int stride = rows_stride > 0 ? rows_stride : (int)gridDim.x;
     if ((int)blockIdx.x >= mine) {
-        // (zero_surplus = 0: the reader knows from theta which geometry ran and stops at its row count - the step's finalise kernel)
-        if (MODE != 3 && zero_surplus && threadIdx.x < NP) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + threadIdx.x] = 0.f;
+        if (MODE != 3 && zero_surplus && threadIdx.x < NP)
+            for (int v = blockIdx.x; v < stride; v += gridDim.x) partials[((size_t)blockIdx.y * stride + v) * NP + threadIdx.x] = 0.f;
         return;
     }
-    if constexpr (kDeep) {
-        if (choice == 0) {
-            tile_body<MODE, GeomD>(vol, theta, tgD, channels, partials, box, blockIdx.x, blockIdx.y);
-            return;
+    for (int v = blockIdx.x; v < mine; v += gridDim.x) {
+        if (v != (int)blockIdx.x) __syncthreads();   // the previous body's reduction scratch aliases the box
+        if constexpr (kDeep) {
+            if (choice == 4) {
+                zstream_body<MODE, ZS64>(vol, theta, zg, partials, box, v, blockIdx.y, stride);
+                continue;
+            }
+            if (choice == 0) {
+                tile_body<MODE, GeomD>(vol, theta, tgD, channels, partials, box, v, blockIdx.y, stride);
+                continue;
+            }
+            if (choice == 3) {
+                tile_body<MODE, GeomRD>(vol, theta, tgRD, channels, partials, box, v, blockIdx.y, stride);
+                continue;
+            }
         }
-        if (choice == 3) {
-            tile_body<MODE, GeomRD>(vol, theta, tgRD, channels, partials, box, blockIdx.x, blockIdx.y);
-            return;
+        if constexpr (WHICH != 1) {
+            if (!useA) {
+                tile_body<MODE, GeomR>(vol, theta, tgR, channels, partials, box, v, blockIdx.y, stride);
+                continue;
+            }
         }
+        if constexpr (WHICH != 2) tile_body<MODE, GeomA>(vol, theta, tgA, channels, partials, box, v, blockIdx.y, stride);
     }
-    if constexpr (WHICH != 1) {
-        if (!useA) {
-            tile_body<MODE, GeomR>(vol, theta, tgR, channels, partials, box, blockIdx.x, blockIdx.y);
-            return;
-        }
-    }
-    if constexpr (WHICH != 2) tile_body<MODE, GeomA>(vol, theta, tgA, channels, partials, box, blockIdx.x, blockIdx.y);
 }
 
 // GeomA / GeomR per pair: one two-body launch or the pair of single-body launches (TRX_AFFINE_DUAL = 1 / 2, default 1: the pair costs one more launch and gains nothing).
 template <int MODE>
 static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const float *theta, const TileGeom &ta, const TileGeom &tr, int channels, float *out, int how,
-                        int zero_surplus = 1, TileGeom td = TileGeom{}, TileGeom trd = TileGeom{})
+                        int zero_surplus = 1, TileGeom td = TileGeom{}, TileGeom trd = TileGeom{}, ZGeom zg = ZGeom{}, int *rows_used = nullptr, int rows_stride = 0)
 {
     if (how == 1) {
-        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd);
+        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride);
     } else {
         hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 1>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
         hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 2>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
@@ -1435,8 +1466,7 @@ template <int ND>
 __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const float *__restrict__ partials, int nblk,
                                                                           double nvox, int D, int H, int W,
                                                                           trx_loss_cfg lc, trx_opt_cfg oc,
-                                                                          trx_affine_state st, int nblk_geomA = 0, int nblk_geomR = 0, int mse_rows = 0,
-                                                                          int nblk_geomD = 0, int nblk_geomRD = 0)
+                                                                          trx_affine_state st, const int *__restrict__ rows_used = nullptr, int mse_rows = 0)
 {
     constexpr int NP = np_full(ND);
     constexpr int NT = ND * (ND + 1);
@@ -1475,15 +1505,10 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
     if (false)
 #endif
     {
-        // rows the F1 pass wrote for this pair: the dual kernel (nblk_geomA != 0) lays a pair's rows out with stride nblk and fills the
-        // first blocks_per_pair of the geometry it chose from this theta - the same test here (theta is still the one of that forward)
+        // rows the F1 pass wrote for this pair: the dual kernel lays a pair's rows out with stride nblk and fills the first
+        // blocks_per_pair of the geometry it chose for the pair - it left that count in rows_used[b]
         int rows = nblk;
-        if constexpr (ND == 3) {
-            if (nblk_geomA != 0) {
-                const int choice = dual_choice(theta, (float)D, (float)H, (float)W, nblk_geomD > 0, nblk_geomRD > 0);
-                rows = choice == 0 ? nblk_geomD : (choice == 1 ? nblk_geomA : (choice == 3 ? nblk_geomRD : nblk_geomR));
-            }
-        }
+        if (rows_used) rows = min(max(rows_used[b], 0), nblk);
         if (ND == 3 && mse_rows) reduce_partials<kNpMse>(partials + (size_t)b * nblk * kNpMse, rows, S);   // rows of the MSE / SSD-only step kernel
         else reduce_partials<NP>(partials + (size_t)b * nblk * NP, rows, S);
     }
@@ -1886,31 +1911,62 @@ static int use_dual(const trx_volumes *vol)
     return TRX_TILE_CFG == 0 ? TRX_DUAL_DEFAULT : 0;
 }
 
+// Does a launch of the step kernels offer the z-streaming body to its pairs?  Sizes only (the theta part is zs_fits on the device):
+// the shape must tile, and the launch must fill the chip with blocks of useful length (small problems stay with the tile kernels).
+static ZGeom zs_launch_geom(const trx_volumes &v)
+{
+    ZGeom none = ZGeom{};
+    if ((v.flags & TRX_FLAG_NO_ZSTREAM) || !zs_shape_ok<ZS64>(v)) return none;
+    const ZGeom g = zs_geom<ZS64>(v);
+    if (v.flags & TRX_FLAG_ZSTREAM) return g;
+    if ((long)g.blocks_per_pair * v.B < TRX_ZS_MIN_BLOCKS || g.planes_per_seg < TRX_ZS_MIN_PLANES) return none;
+    return g;
+}
+
 // partial rows per pair that a tile-path launch may write (the dual grid is sized for the geometry with more blocks)
 static size_t tile_rows_per_pair(const trx_volumes &v)
 {
     size_t n = (size_t)tile_geom<GeomP>(v).blocks_per_pair;
     const size_t a = (size_t)tile_geom<GeomA>(v).blocks_per_pair, r = (size_t)tile_geom<GeomR>(v).blocks_per_pair;
     const size_t d = (size_t)tile_geom<GeomD>(v).blocks_per_pair, rd = (size_t)tile_geom<GeomRD>(v).blocks_per_pair;
+    const size_t z = zs_shape_ok<ZS64>(v) ? (size_t)zs_geom<ZS64>(v).blocks_per_pair : 0;
     if (a > n) n = a;
     if (r > n) n = r;
     if (d > n) n = d;
     if (rd > n) n = rd;
+    if (z > n) n = z;
     return n;
 }
 
+// Workspace of the affine entry points: [B][rows][41] partial sums | coordinate tables (callers that pass none) | rows_used[B]
+struct AffineWs {
+    size_t rows, off_tab, off_rows_used, bytes;
+};
+static AffineWs affine_ws(const trx_volumes &v)
+{
+    AffineWs w;
+    AffineGeom g = affine_geom(v, kTargetBlocks);
+    w.rows = (size_t)g.nblk;
+    if (v.ndim == 3) {
+        const size_t t = tile_rows_per_pair(v);
+        if (t > w.rows) w.rows = t;
+    }
+    w.off_tab = ((size_t)v.B * w.rows * np_full(3) * sizeof(float) + 255) & ~(size_t)255;
+    w.off_rows_used = w.off_tab + (((size_t)(v.W + v.H + v.D) * sizeof(float) + 255) & ~(size_t)255);
+    w.bytes = w.off_rows_used + (((size_t)v.B * sizeof(int) + 255) & ~(size_t)255);
+    return w;
+}
 
 extern "C" size_t trx_affine_workspace_bytes(const trx_volumes *vol)
 {
     if (check_vol(vol, false) != TRX_OK) return 0;
-    AffineGeom g = affine_geom(*vol, kTargetBlocks);
-    size_t nblk = (size_t)g.nblk;
-    if (vol->ndim == 3) {
-        const size_t t = tile_rows_per_pair(*vol);
-        if (t > nblk) nblk = t;
-    }
-    const size_t tab = ((size_t)(vol->W + vol->H + vol->D) * sizeof(float) + 255) & ~(size_t)255;
-    return (size_t)vol->B * nblk * np_full(3) * sizeof(float) + 256 + tab;
+    return affine_ws(*vol).bytes;
+}
+
+extern "C" size_t trx_affine_workspace_rows_offset(const trx_volumes *vol)
+{
+    if (check_vol(vol, false) != TRX_OK) return 0;
+    return affine_ws(*vol).off_rows_used;
 }
 
 static bool use_tile_path(const trx_volumes *vol)
@@ -1922,8 +1978,7 @@ static bool use_tile_path(const trx_volumes *vol)
 // MODE 0 / 1 dispatch: LDS-tiled kernel for 3-D, row-walking gather kernel otherwise.
 // Returns the number of partial rows per pair through *nblk.
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a = nullptr, int *nblk_r = nullptr,
-                     int *nblk_d = nullptr, int *nblk_rd = nullptr);
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, const int **rows_used = nullptr);
 
 template <int MODE>
 static int launch_accum(const trx_volumes *vol, const float *theta, const AffineGeom &g, int channels, size_t chan_stride,
@@ -1938,25 +1993,19 @@ static int launch_accum(const trx_volumes *vol, const float *theta, const Affine
     return TRX_OK;
 }
 
-// nblk_a / nblk_r != nullptr: the caller's reduction knows the per-pair geometry (see affine_finalize_kernel): surplus blocks of the
-// dual grid then write nothing.
+// rows_used != nullptr: the caller's reduction reads the row count of every pair from the device array returned through it (the
+// step's finalise kernel): surplus blocks of the dual grid then write nothing, and the step kernels may offer their extra bodies.
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, int *nblk_a, int *nblk_r, int *nblk_d,
-                     int *nblk_rd)
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, const int **rows_used)
 {
-    if (nblk_a) *nblk_a = *nblk_r = 0;
-    if (nblk_d) *nblk_d = 0;
-    if (nblk_rd) *nblk_rd = 0;
+    if (rows_used) *rows_used = nullptr;
     if (use_tile_path(vol)) {
         TileGeom t = tile_geom(*vol);
         trx_volumes v = *vol;
+        const AffineWs ws = affine_ws(*vol);
         if (!v.xn || !v.yn || !v.zn) {
             // tables live behind the partials (trx_affine_workspace_bytes reserves the room)
-            AffineGeom g = affine_geom(*vol, kTargetBlocks);
-            const size_t tr = tile_rows_per_pair(*vol);
-            size_t nb = (size_t)g.nblk > tr ? (size_t)g.nblk : tr;
-            size_t off = ((size_t)vol->B * nb * np_full(3) * sizeof(float) + 255) & ~(size_t)255;
-            float *tab = (float *)((char *)partials + off);
+            float *tab = (float *)((char *)partials + ws.off_tab);
             const int n = max(v.W, max(v.H, v.D));
             hipLaunchKernelGGL(fill_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tab, v.W, v.H, v.D);
             TRX_CHECK_LAUNCH();
@@ -1965,11 +2014,12 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
         if (dual && use_dual(vol)) {
             const TileGeom ta = tile_geom<GeomA>(*vol), tr = tile_geom<GeomR>(*vol);
             const int gx = ta.blocks_per_pair > tr.blocks_per_pair ? ta.blocks_per_pair : tr.blocks_per_pair;
-            const bool aware = nblk_a != nullptr && use_dual(vol) == 1;
-            // the deep tile joins the choice only where the reader of the partial rows repeats it (the step's finalise kernel) and where
-            // its 128-row slabs still fill the chip (8192 voxels per tile: big batches)
+            const bool aware = rows_used != nullptr && use_dual(vol) == 1;
+            const bool step_kernel = aware && (MODE == 0 || MODE == 4);
+            // the deep tile joins the choice only where the reader of the partial rows knows which rows were written (the step's finalise
+            // kernel) and where its 128-row slabs still fill the chip (8192 voxels per tile: big batches)
             TileGeom td = TileGeom{};
-            if (aware && nblk_d != nullptr && (MODE == 0 || MODE == 4)) {
+            if (step_kernel) {
                 const TileGeom cand = tile_geom<GeomD>(*vol);
                 // big batches as before; smaller ones where the deep tiling still fills every block slot with blocks of at least four tiles
                 // (1 or 2 pairs of 256^3: -3 %; never where it would leave slots empty - 2 x 128^3 measured +29 % with it)
@@ -1980,19 +2030,24 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             }
             // GeomRD (GeomR's box under a 16 x 16 x 16 tile) joins under the same condition: rotations whose pre-image still fits that box
             TileGeom trd = TileGeom{};
-            if (aware && nblk_rd != nullptr && (MODE == 0 || MODE == 4) && TRX_ROT_DEEP_TILE && !(vol->flags & TRX_FLAG_NO_ROT_DEEP_TILE)) {
+            if (step_kernel && TRX_ROT_DEEP_TILE && TRX_DEEP_TILE && !(vol->flags & TRX_FLAG_NO_ROT_DEEP_TILE)) {
                 const TileGeom cand = tile_geom<GeomRD>(*vol);
                 if (cand.ntiles >= 128 || (vol->flags & TRX_FLAG_DEEP_TILE)) trd = cand;   // tiny volumes (<= 64^3: at most 64 of these tiles) stay with GeomR's smaller tiles: measured +5 ... +14 % otherwise
             }
+            // the z-streaming body: pairs next to the identity (zs_fits) in launches that fill the chip
+            ZGeom zg = ZGeom{};
+            if (step_kernel && TRX_DEEP_TILE) zg = zs_launch_geom(*vol);
             int gxx = gx;
             if (td.blocks_per_pair > gxx) gxx = td.blocks_per_pair;
             if (trd.blocks_per_pair > gxx) gxx = trd.blocks_per_pair;
-            launch_dual<MODE>(dim3(gxx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd);
+            if (zg.blocks_per_pair > gxx) gxx = zg.blocks_per_pair;
+            int *ru = aware ? (int *)((char *)partials + ws.off_rows_used) : nullptr;
+            // with the z-streaming body on offer the grid is ITS block count and the blocks of a pair that runs a tile geometry loop
+            const int gdim = zg.blocks_per_pair > 0 ? zg.blocks_per_pair : gxx;
+            launch_dual<MODE>(dim3(gdim, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd, zg, ru, gxx);
             TRX_CHECK_LAUNCH();
             *nblk = gxx;
-            if (aware) { *nblk_a = ta.blocks_per_pair; *nblk_r = tr.blocks_per_pair; }
-            if (nblk_d) *nblk_d = td.blocks_per_pair;
-            if (nblk_rd) *nblk_rd = trd.blocks_per_pair;
+            if (aware) *rows_used = ru;
             return TRX_OK;
         }
         hipLaunchKernelGGL((affine_tile_kernel<MODE>), dim3(t.blocks_per_pair, vol->B), dim3(kTileThreads), 0, s, v, theta, t, 1, partials);
@@ -2026,16 +2081,15 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     // Every step picks GeomA / GeomR per pair in the kernel (TRX_FLAG_SINGLE_GEOM: the primary geometry only).  Rigid runs start from a
     // random pose (reference: torch.rand, up to 1 rad) and live at large rotations; affine runs start at the identity, where the
     // GeomA body is all that runs, but may rotate away from it: the single-geometry kernel then gathers from L2 at 3.2x the cost.
-    int nblk_a = 0, nblk_r = 0, nblk_d = 0, nblk_rd = 0;
+    const int *rows_used = nullptr;
     // without an NCC term only d = warped - target matters: the step kernel then keeps 13 sums instead of 41 (3-D tile path)
     const bool mse_only = (loss->w_ncc == 0.f) && use_tile_path(vol);
-    rc = mse_only ? launch_f1<4>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r, &nblk_d, &nblk_rd)
-                  : launch_f1<0>(vol, st->theta, partials, &nblk, s, true, &nblk_a, &nblk_r, &nblk_d, &nblk_rd);
+    rc = mse_only ? launch_f1<4>(vol, st->theta, partials, &nblk, s, true, &rows_used) : launch_f1<0>(vol, st->theta, partials, &nblk, s, true, &rows_used);
     if (rc) return rc;
     const double nvox = (double)vol->D * vol->H * vol->W;
     if (vol->ndim == 3)
         hipLaunchKernelGGL((affine_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
-                           vol->D, vol->H, vol->W, *loss, *opt, *st, nblk_a, nblk_r, mse_only ? 1 : 0, nblk_d, nblk_rd);
+                           vol->D, vol->H, vol->W, *loss, *opt, *st, rows_used, mse_only ? 1 : 0);
     else
         hipLaunchKernelGGL((affine_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
                            vol->D, vol->H, vol->W, *loss, *opt, *st);
@@ -2049,8 +2103,9 @@ extern "C" int trx_affine_accumulate(const trx_volumes *vol, const float *theta,
     if (rc) return rc;
     if (!theta || !workspace) return TRX_ERR_ARG;
     if (workspace_bytes < trx_affine_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
-    int nblk = 0, na = 0, nr = 0, nd = 0, nrd = 0;
-    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream, true, &na, &nr, &nd, &nrd);   // exactly the launch of a step (profiling aid)
+    int nblk = 0;
+    const int *rows_used = nullptr;
+    return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream, true, &rows_used);   // exactly the launch of a step (profiling aid)
 }
 
 extern "C" int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
