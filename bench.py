@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=SIZE, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pose-legs", action="store_true",
+                    help="skip the config.value_* / flow_value legs (profiling runs: every launch of the step kernel is then a headline-pose launch)")
     ap.add_argument("--optimizer", default="adam", choices=["adam", "sgd"],
                     help="optimiser on theta for the headline number (north_star: Adam; the reference's own loop: SGD)")
     ap.add_argument("--cpu-worker", type=int, default=0, help=argparse.SUPPRESS)
@@ -226,6 +228,52 @@ def main():
     fence()
     elapsed2 = max_over_ranks(time.perf_counter() - t0, device)
 
+    # ---- poses away from the identity (rank-local, same 8 x 256^3 batch): the headline starts at theta = I, where
+    # every affine run starts; a run that converges to theta* ends 0.05-0.1 away from it and a rigid run starts at a random pose.
+    def timed_run(sv, steps):
+        sv.run(40)
+        fence()
+        t = time.perf_counter()
+        sv.run(steps)
+        fence()
+        return time.perf_counter() - t
+
+    import math
+    def rot(ax, ay, az):
+        cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+        rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        return rz @ ry @ rx
+    pose_steps = min(args.steps, 100)
+    extra = {"value_theta_star": None, "value_rot": None, "value_rigid_randinit": None, "flow_value": None}
+    # (a) theta* itself - the pose the headline run converges to; (b) R(0.5, 0.4, 0.3) x anisotropic scale; (c) the rigid mode from the
+    # reference's own initial pose: torch.manual_seed(0); torch.rand(6) radians / tanh-translations (ref:utils.py:316-321)
+    th_star = torch.tensor(THETA_STAR, device=device)[None].expand(PAIRS_PER_GPU, 3, 4).contiguous()
+    th_rot = torch.cat([rot(0.5, 0.4, 0.3).float() @ torch.diag(torch.tensor([1.05, 0.95, 1.02])), torch.tensor([[0.01], [-0.02], [0.015]])], dim=1)
+    th_rot = th_rot.to(device)[None].expand(PAIRS_PER_GPU, 3, 4).contiguous()
+    for key, th0 in (() if args.no_pose_legs else (("value_theta_star", th_star), ("value_rot", th_rot))):
+        sv = tr.AffineSolver(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer=args.optimizer, lr=1e-6, init=th0,
+                             capacity=pose_steps + 40)
+        extra[key] = world * PAIRS_PER_GPU * pose_steps / max_over_ranks(timed_run(sv, pose_steps), device)
+        del sv
+    if not args.no_pose_legs:
+        torch.manual_seed(0)
+        pose0 = torch.rand(6)
+        sv = tr.AffineSolver(mov, tgt, mode="rigid", loss=tr.LossSpec(w_ncc=1.0), optimizer=args.optimizer, lr=1e-6,
+                             init=pose0[None].expand(PAIRS_PER_GPU, 6).contiguous().to(device), capacity=pose_steps + 40)
+        extra["value_rigid_randinit"] = world * PAIRS_PER_GPU * pose_steps / max_over_ranks(timed_run(sv, pose_steps), device)
+        del sv
+        # BASELINE.json configs[2]: one 256^3 pair, direct flow field + NCC + smoothness regulariser, Adam, 100 iterations (iterations / s)
+        fs = tr.FlowSolver(mov[:1], tgt[:1], loss=tr.LossSpec(w_ncc=1.0), optimizer="adam", lr=0.01, smooth_weight=1.0, capacity=160)
+        fs.run(40)
+        fence()
+        t0 = time.perf_counter()
+        fs.run(100)
+        fence()
+        extra["flow_value"] = 100 / max_over_ranks(time.perf_counter() - t0, device)
+        del fs
+
     out = None
     if rank == 0:
         total = world * PAIRS_PER_GPU * args.steps
@@ -240,30 +288,61 @@ def main():
                           "value_cold": world * PAIRS_PER_GPU * args.steps / elapsed_cold,
                           "value_cold_note": f"first {args.steps} iterations of a fresh solver after 2 s of idle GPU, no warm-up",
                           f"{other}_value": world * PAIRS_PER_GPU * args.steps / elapsed2,
+                          "value_theta_star": extra["value_theta_star"], "value_rot": extra["value_rot"],
+                          "value_rigid_randinit": extra["value_rigid_randinit"],
+                          "pose_note": f"pair-iterations/s of {pose_steps} steps at a fixed pose (lr 1e-6), same batch: theta* of the synthetic "
+                                       "pairs (where the headline run converges); theta = R(0.5, 0.4, 0.3) diag(1.05, 0.95, 1.02); rigid mode from "
+                                       "the reference's initial pose torch.manual_seed(0), torch.rand(6).  The headline value itself starts at "
+                                       "theta = identity (where every affine run starts) and moves |theta - I| by at most lr per step",
+                          "flow_value": extra["flow_value"],
+                          "flow_note": "iterations/s of BASELINE configs[2]: one 256^3 pair, direct flow field + NCC + smoothness regulariser, "
+                                       "Adam (extension; parity vs torch autograd, not the reference), 100 iterations in one trx_flow_run call",
                           "parallelism": f"{world} x independent shards, no collective"}}
         if world == 1:
-            # ---- roofline leg: the fused F1 kernel alone, events on the launch stream ----------------
-            reps = 200
-            for _ in range(50):           # the clocks settle ~40 launches after an idle gap (power management transient)
-                solver.accumulate_only()
+            # ---- roofline leg: the fused F1 kernel alone, events on the launch stream, AT THE POSES OF THE TIMED REGION: a replica of
+            # the measured solver (same start, same optimiser, same warm-up) is stepped one iteration at a time and, before each of its K
+            # timed iterations, the F1 launch of that iteration's theta is timed on its own (the kernel picks its body per pair from theta:
+            # the z-streaming body next to the identity, the tile geometries further out)
+            scratch = new_solver(args.optimizer)
+            scratch.run(PRECONDITION)
+            del scratch
+            rep = new_solver(args.optimizer)
+            rep.run(args.warmup)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                solver.accumulate_only()
-            e1.record()
+            for e0, e1 in ev:
+                e0.record()
+                rep.accumulate_only()
+                e1.record()
+                rep.run(1)
             torch.cuda.synchronize()
-            k_s = e0.elapsed_time(e1) * 1e-3 / reps
+            per_it = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in ev]
+            k_s = sum(per_it) / len(per_it)
+            rows = rep.rows_used().tolist()
             alg = ALG_BYTES_PER_VOXEL * args.size ** 3 * PAIRS_PER_GPU
-            traffic, l2req = None, None
+            # HBM-side traffic and L2 requests come from separate PMC passes of this same command (tools/profile_bench.sh ->
+            # tools/summarize_prof.py -> profiles/traffic.json); they are only quoted for the library they were measured on
+            traffic, l2req, traffic_note = None, None, "no profiles/traffic.json"
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
+                import hashlib
                 tj = json.load(open(tf))
-                traffic, l2req = tj.get("hbm_bytes_per_launch"), tj.get("l2_requests_per_launch")
-            out["roofline"] = {"bound": "hbm", "kernel": "affine_tile_dual_kernel<0,0> (fused warp+NCC fwd/bwd, tile geometry per pair)",
+                sha = hashlib.sha256(open(os.path.join(ROOT, "torchregister_amd", "lib", "libtrx.so"), "rb").read()).hexdigest()
+                if tj.get("lib_sha256") == sha and args.size == SIZE:
+                    traffic, l2req = tj.get("hbm_bytes_per_launch"), tj.get("l2_requests_per_launch")
+                    traffic_note = f"PMC passes of this command on this library (tag {tj.get('tag')}, sha256 {sha[:12]})"
+                else:
+                    traffic_note = (f"profiles/traffic.json (tag {tj.get('tag')}) was measured on another build of libtrx.so "
+                                    f"(sha256 {str(tj.get('lib_sha256'))[:12]} != {sha[:12]}): not quoted")
+            out["roofline"] = {"bound": "hbm", "kernel": "affine_tile_dual_kernel<0,0> (fused warp+NCC fwd/bwd; kernel body per pair from theta: "
+                                                         "z-streaming next to the identity, tile geometries further out)",
                                "achieved": alg / k_s / 1e9,
-                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / k_s / HBM_PEAK, "traffic": traffic,
-                               "kernel_ms": k_s * 1e3, "algorithmic_bytes_per_launch": alg,
+                               "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / k_s / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
+                               "kernel_ms": k_s * 1e3, "kernel_ms_first": per_it[0] * 1e3, "kernel_ms_last": per_it[-1] * 1e3,
+                               "kernel_ms_note": f"mean over the F1 launches of the {args.steps} timed iterations' poses (replica run, events around each "
+                                                 "launch); first / last = the first and last of them",
+                               "partial_rows_per_pair_last": rows[0],
+                               "algorithmic_bytes_per_launch": alg,
                                "l2_requests_per_launch": l2req, "l2_request_bytes": 128}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()

@@ -5,7 +5,8 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 P=$R/gpurun_out/prof
 rm -rf $P && mkdir -p $P
-ARGS="$R/bench.py --no-cpu-baseline"   # default --steps / --warmup: the same command the driver runs
+ARGS="$R/bench.py --no-cpu-baseline --no-pose-legs"   # default --steps / --warmup: the command the driver runs, without the legs at other poses
+                                                    # (so that every launch of the step kernel is a headline-pose launch)
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- python3 $ARGS > $P/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch -- python3 $ARGS > $P/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write -- python3 $ARGS > $P/write.log 2>&1

@@ -3,6 +3,7 @@
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -10,7 +11,7 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 note = sys.argv[3] if len(sys.argv) > 3 else ""
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline  (MI355X; {note})",
+out = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-pose-legs  (MI355X; {note})",
        "Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs"]
 rows = list(csv.DictReader(open(sorted(glob.glob(f"{src}/stats/*/*_kernel_stats.csv"), key=os.path.getmtime)[-1])))
 for r in rows:
@@ -44,7 +45,8 @@ if dom:
                                  "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
                    "hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 8 * 256 ** 3 * 8,
                    "l2_requests_per_launch": res.get((k, "TCC_REQ_sum")), "l2_hits_per_launch": res.get((k, "TCC_HIT_sum")),
-                   "l2_misses_per_launch": res.get((k, "TCC_MISS_sum")), "l2_request_bytes": 128, "tag": tag},
+                   "l2_misses_per_launch": res.get((k, "TCC_MISS_sum")), "l2_request_bytes": 128, "tag": tag,
+                   "lib_sha256": hashlib.sha256(open(os.path.join(root, "torchregister_amd", "lib", "libtrx.so"), "rb").read()).hexdigest()},
                   open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
         print("traffic GB/launch", traffic / 1e9)
 print("\n".join(out))

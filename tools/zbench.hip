@@ -31,7 +31,7 @@ int main(int argc, char **argv)
     const int B = argc > 1 ? atoi(argv[1]) : 8, S = argc > 2 ? atoi(argv[2]) : 256;
     const float eps = argc > 3 ? (float)atof(argv[3]) : 0.004f;
     const int reps = argc > 4 ? atoi(argv[4]) : 100;
-    const bool zonly = argc > 5;   // profiling runs: only the first z-streaming kernel
+    const bool zonly = argc == 6;   // profiling runs: only the first z-streaming kernel
     const size_t nvox = (size_t)S * S * S, n = nvox * B;
     std::vector<float> h(n);
     srand(1);
@@ -111,12 +111,37 @@ int main(int argc, char **argv)
         gx = std::max(gx, zg.blocks_per_pair);
         int *ru; CK(hipMalloc(&ru, B * 4));
         printf("fused grid: %d blocks/pair (A %d R %d D %d RD %d ZS %d)\n", gx, ta.blocks_per_pair, tr.blocks_per_pair, td.blocks_per_pair, trd.blocks_per_pair, zg.blocks_per_pair);
-        rep("fused dual MODE0, full grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gx); }, reps));
-        rep("fused dual MODE0, looping grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(zg.blocks_per_pair, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gx); }, reps));
+        rep("fused dual MODE0, classic grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, 0); }, reps));
+        rep("fused dual MODE0, flat grid 512", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(512, 1), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gx); }, reps));
         const trx::ZGeom none = trx::ZGeom{};
-        rep("fused dual, no ZS, full grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, none, ru, gx); }, reps));
-        rep("fused dual, no ZS, looping 64", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(64, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, none, ru, gx); }, reps));
-        rep("fused dual, no ZS, looping 128", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(128, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, none, ru, gx); }, reps));
+        rep("fused dual, no ZS, classic grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, none, ru, 0); }, reps));
+        rep("fused dual, no ZS, flat grid 512", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(512, 1), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, none, ru, gx); }, reps));
+    }
+    if (argc > 6) {   // rotated poses through the fused kernel at several grid sizes (looping): R(0.4,0.4,0.4), Ry(0.3), Rz(0.15)
+        const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol), td = trx::tile_geom<trx::GeomD>(vol), trd = trx::tile_geom<trx::GeomRD>(vol);
+        const trx::ZGeom zg = trx::zs_geom<trx::ZS64>(vol);
+        int gx = std::max(std::max(ta.blocks_per_pair, tr.blocks_per_pair), std::max(td.blocks_per_pair, trd.blocks_per_pair));
+        int *ru; CK(hipMalloc(&ru, B * 4));
+        const double angs[4][3] = {{0.4, 0.4, 0.4}, {0.0, 0.3, 0.0}, {0.0, 0.0, 0.15}, {0.0, 0.0, 0.0}};
+        for (int c = 0; c < 4; c++) {
+            const double ax = angs[c][0], ay = angs[c][1], az = angs[c][2];
+            const double Rx[9] = {1, 0, 0, 0, cos(ax), -sin(ax), 0, sin(ax), cos(ax)}, Ry[9] = {cos(ay), 0, sin(ay), 0, 1, 0, -sin(ay), 0, cos(ay)},
+                         Rz[9] = {cos(az), -sin(az), 0, sin(az), cos(az), 0, 0, 0, 1};
+            double T[9], Rm[9];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { T[i * 3 + j] = 0; for (int k = 0; k < 3; k++) T[i * 3 + j] += Rz[i * 3 + k] * Ry[k * 3 + j]; }
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Rm[i * 3 + j] = 0; for (int k = 0; k < 3; k++) Rm[i * 3 + j] += T[i * 3 + k] * Rx[k * 3 + j]; }
+            for (int b = 0; b < B; b++) for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) th[b * 12 + i * 4 + j] = (float)Rm[i * 3 + j]; th[b * 12 + i * 4 + 3] = 0.01f * (i + 1); }
+            CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
+            printf("-- R(%.2f, %.2f, %.2f)\n", ax, ay, az);
+            rep("fused, classic grid (max x pairs)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, 0); }, reps));
+            for (int g : {256, 512, 768, 1024}) {
+                char nm[64]; snprintf(nm, sizeof nm, "fused, flat grid of %d blocks", g);
+                rep(nm, time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(g, 1), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gx); }, reps));
+            }
+            std::vector<int> hru(B); CK(hipMemcpy(hru.data(), ru, B * 4, hipMemcpyDeviceToHost));
+            printf("   rows used %d\n", hru[0]);
+        }
+        return 0;
     }
     run_zs(trx::ZS64{}, "zstream 64x32 (again)");
     return 0;

@@ -371,6 +371,12 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #ifndef TRX_ROT_DEEP_TILE
 #define TRX_ROT_DEEP_TILE 1   // the step kernels carry GeomRD as a fourth per-pair choice (0: never - measured alternative)
 #endif
+#ifndef TRX_PERSISTENT_BLOCKS
+#define TRX_PERSISTENT_BLOCKS 512   // block slots of one MI355X for the 512-thread step kernels (two per CU): the size of the flat grid
+#endif
+#ifndef TRX_FLAT_GRID
+#define TRX_FLAT_GRID 1             // 0: big batches launch (largest geometry) x (pairs) blocks like the small ones (measured alternative)
+#endif
 #ifndef TRX_ZS_MIN_BLOCKS
 #define TRX_ZS_MIN_BLOCKS 512   // the z-streaming body is offered to launches of at least this many of its blocks ...
 #endif
@@ -1272,50 +1278,96 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     __shared__ __attribute__((aligned(16))) float box[kAlloc];
     constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : (MODE == 4 ? kNpMse : 5));
-    const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
-    const float *__restrict__ th = theta + (size_t)b * TRX_PSTRIDE;
-    const int choice = __builtin_amdgcn_readfirstlane(dual_choice(th, (float)vol.D, (float)vol.H, (float)vol.W, kDeep && tgD.blocks_per_pair > 0,
-                                                                  kDeep && tgRD.blocks_per_pair > 0, kDeep && zg.blocks_per_pair > 0 ? zg.planes_per_seg : 0));
-    const bool useA = choice == 1;
-    if ((WHICH == 1 && !useA) || (WHICH == 2 && useA)) return;   // the other launch owns this pair (and its surplus rows)
-    const int mine = choice == 4 ? zg.blocks_per_pair
-                                 : (choice == 0 ? tgD.blocks_per_pair : (choice == 3 ? tgRD.blocks_per_pair : (useA ? tgA.blocks_per_pair : tgR.blocks_per_pair)));
-    // zero_surplus = 0: surplus blocks write nothing; the reader (the step's finalise kernel) learns the pair's row count from rows_used[],
-    // written here by the pair's first block - it does not repeat the choice (two inlined copies of a float test could disagree by an ulp)
-    if (rows_used && blockIdx.x == 0 && threadIdx.x == 0) rows_used[blockIdx.y] = mine;
-    // rows_stride != 0: the grid has FEWER blocks per pair than the geometry with the most (the launcher sized it for the z-streaming
-    // body) and block x runs the pair's blocks x, x + gridDim.x, ... in turn - no surplus blocks.  A grid sized for the largest geometry
-    // makes every pair of a smaller one dispatch hundreds of blocks that exit at once, in front of the next pair's working blocks:
-    // 3584 such blocks cost the 8 x 256^3 launch 33 us (tools/zbench.hip).
-    const int stride = rows_stride > 0 ? rows_stride : (int)gridDim.x;
-    if ((int)blockIdx.x >= mine) {
-        if (MODE != 3 && zero_surplus && threadIdx.x < NP)
-            for (int v = blockIdx.x; v < stride; v += gridDim.x) partials[((size_t)blockIdx.y * stride + v) * NP + threadIdx.x] = 0.f;
-        return;
+    const float fD = (float)vol.D, fH = (float)vol.H, fW = (float)vol.W;
+    const bool with_d = kDeep && tgD.blocks_per_pair > 0, with_rd = kDeep && tgRD.blocks_per_pair > 0;
+    const int zs_planes = kDeep && zg.blocks_per_pair > 0 ? zg.planes_per_seg : 0;
+    auto blocks_of = [&](int choice) {
+        return choice == 4 ? zg.blocks_per_pair
+                           : (choice == 0 ? tgD.blocks_per_pair : (choice == 3 ? tgRD.blocks_per_pair : (choice == 1 ? tgA.blocks_per_pair : tgR.blocks_per_pair)));
+    };   // (used before the item loop only)
+    // Work items of this block: (pair / slab `by`, block index v of that pair's geometry).  Classic grid: exactly one, from blockIdx.
+    // FLAT grid (rows_stride > 0; the launcher's choice for big batches of the step kernels): gridDim.x persistent blocks share one list
+    // of work items - pair 0's blocks, then pair 1's, ... each pair with the block count of the body ITS theta selects - and block p runs
+    // items p, p + gridDim.x, ...  Why: a (blocks of the largest geometry) x (pairs) grid makes every pair of a smaller geometry dispatch
+    // hundreds of blocks that exit at once, in front of the next pair's working blocks (3584 of them cost the 8 x 256^3 launch 33 us); a
+    // per-pair loop over x removes them but runs all pairs side by side on every XCD, and the halo re-reads of the rotated geometries
+    // then miss the L2 (GeomR: +28 %).  Pair-major items keep the dispatcher's order: all blocks on one pair, each XCD on its slab of
+    // columns (block counts are multiples of 8, so item % 8 is the XCD of v as before).
+    const bool flat = kDeep && rows_stride > 0;
+    const int lane = threadIdx.x & 63;
+    // flat path: per pair (lane) the body its theta selects and the inclusive prefix sum of the block counts - kept in LDS, not in
+    // registers, across the item loop (two more live VGPRs are two spilled ones in the bodies that sit at the register limit)
+    __shared__ int s_choice[64], s_pre[64];
+    int my_choice = 2, total = 1;
+    if (flat) {
+        const int B = vol.B;
+        int cnt = 0, ch = 2;
+        if (lane < B) {
+            ch = dual_choice(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, with_d, with_rd, zs_planes);
+            cnt = blocks_of(ch);
+            if (rows_used && blockIdx.x == 0 && threadIdx.x < 64) rows_used[lane] = cnt;   // for the step's finalise kernel
+        }
+        int pre = cnt;   // inclusive prefix sum over the lanes (pairs)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(pre, d, 64);
+            if (lane >= d) pre += t;
+        }
+        total = __builtin_amdgcn_readlane(pre, 63);
+        if (threadIdx.x < 64) { s_choice[lane] = ch; s_pre[lane] = pre; }
+        __syncthreads();
+    } else {
+        const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
+        my_choice = __builtin_amdgcn_readfirstlane(dual_choice(theta + (size_t)b * TRX_PSTRIDE, fD, fH, fW, with_d, with_rd, zs_planes));
+        const bool useA = my_choice == 1;
+        if ((WHICH == 1 && !useA) || (WHICH == 2 && useA)) return;   // the other launch owns this pair (and its surplus rows)
+        const int mine = blocks_of(my_choice);
+        // zero_surplus = 0: surplus blocks write nothing; the reader (the step's finalise kernel) learns the pair's row count from
+        // rows_used[], written here by the pair's first block - it does not repeat the choice (two inlined copies of a float test could
+        // disagree by an ulp)
+        if (rows_used && blockIdx.x == 0 && threadIdx.x == 0) rows_used[blockIdx.y] = mine;
+        if ((int)blockIdx.x >= mine) {
+            if (MODE != 3 && zero_surplus && threadIdx.x < NP) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + threadIdx.x] = 0.f;
+            return;
+        }
     }
-    for (int v = blockIdx.x; v < mine; v += gridDim.x) {
-        if (v != (int)blockIdx.x) __syncthreads();   // the previous body's reduction scratch aliases the box
+    total = __builtin_amdgcn_readfirstlane(total);
+    const int it0 = flat ? (int)blockIdx.x : 0, it_step = flat ? (int)gridDim.x : 1;
+    for (int item = __builtin_amdgcn_readfirstlane(it0); item < total; item += it_step) {
+        int choice, v, by, stride;
+        if (flat) {
+            const int pre = *(volatile int *)&s_pre[lane];
+            const int pair = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= item)));   // lanes >= B hold the total: never counted
+            const int off = pair > 0 ? __builtin_amdgcn_readlane(pre, pair - 1) : 0;
+            choice = *(volatile int *)&s_choice[pair];
+            v = __builtin_amdgcn_readfirstlane(item - off); by = pair; stride = rows_stride;
+            if (item != it0) __syncthreads();   // the previous body's reduction scratch aliases the box
+        } else {
+            choice = __builtin_amdgcn_readfirstlane(my_choice); v = blockIdx.x; by = blockIdx.y; stride = gridDim.x;   // (my_choice is per-lane on the flat path: keep this one provably uniform)
+        }
+        choice = __builtin_amdgcn_readfirstlane(choice); v = __builtin_amdgcn_readfirstlane(v);   // all four ARE wave-uniform; say so to the
+        by = __builtin_amdgcn_readfirstlane(by); stride = __builtin_amdgcn_readfirstlane(stride);  // compiler (the bodies pin them to SGPRs)
         if constexpr (kDeep) {
             if (choice == 4) {
-                zstream_body<MODE, ZS64>(vol, theta, zg, partials, box, v, blockIdx.y, stride);
+                zstream_body<MODE, ZS64>(vol, theta, zg, partials, box, v, by, stride);
                 continue;
             }
             if (choice == 0) {
-                tile_body<MODE, GeomD>(vol, theta, tgD, channels, partials, box, v, blockIdx.y, stride);
+                tile_body<MODE, GeomD>(vol, theta, tgD, channels, partials, box, v, by, stride);
                 continue;
             }
             if (choice == 3) {
-                tile_body<MODE, GeomRD>(vol, theta, tgRD, channels, partials, box, v, blockIdx.y, stride);
+                tile_body<MODE, GeomRD>(vol, theta, tgRD, channels, partials, box, v, by, stride);
                 continue;
             }
         }
         if constexpr (WHICH != 1) {
-            if (!useA) {
-                tile_body<MODE, GeomR>(vol, theta, tgR, channels, partials, box, v, blockIdx.y, stride);
+            if (choice != 1) {
+                tile_body<MODE, GeomR>(vol, theta, tgR, channels, partials, box, v, by, stride);
                 continue;
             }
         }
-        if constexpr (WHICH != 2) tile_body<MODE, GeomA>(vol, theta, tgA, channels, partials, box, v, blockIdx.y, stride);
+        if constexpr (WHICH != 2) tile_body<MODE, GeomA>(vol, theta, tgA, channels, partials, box, v, by, stride);
     }
 }
 
@@ -2042,9 +2094,10 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             if (trd.blocks_per_pair > gxx) gxx = trd.blocks_per_pair;
             if (zg.blocks_per_pair > gxx) gxx = zg.blocks_per_pair;
             int *ru = aware ? (int *)((char *)partials + ws.off_rows_used) : nullptr;
-            // with the z-streaming body on offer the grid is ITS block count and the blocks of a pair that runs a tile geometry loop
-            const int gdim = zg.blocks_per_pair > 0 ? zg.blocks_per_pair : gxx;
-            launch_dual<MODE>(dim3(gdim, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd, zg, ru, gxx);
+            // big batches of the step kernels: a flat grid of persistent blocks over a pair-major work list (no surplus blocks; see the kernel)
+            const bool flat = step_kernel && TRX_DEEP_TILE && TRX_FLAT_GRID && vol->B <= 64 && (long)gxx * vol->B >= 2 * TRX_PERSISTENT_BLOCKS;
+            if (flat) launch_dual<MODE>(dim3(TRX_PERSISTENT_BLOCKS, 1), s, v, theta, ta, tr, 1, partials, 1, 0, td, trd, zg, ru, gxx);
+            else launch_dual<MODE>(dim3(gxx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd, zg, ru, 0);
             TRX_CHECK_LAUNCH();
             *nblk = gxx;
             if (aware) *rows_used = ru;

@@ -3,20 +3,28 @@
 // Why a second kernel family: the tile kernels (tile_body) stage the whole pre-image box of a tile, wait for it, gather, and start
 // over; requests are in flight only while a block is in its burst phase, and every tile re-fetches its z / y halo.  Here a 512-thread
 // block owns an in-plane tile (TX x TY voxels) and walks it along z, one output plane per step:
-//   * the source planes live in an LDS RING of NZ slots (slot = source plane & (NZ - 1)), filled by LDS-DMA two steps ahead of the
-//     gather: a source plane is fetched once per block (no z halo) and requests are in flight all the time;
-//   * one barrier and one counted s_waitcnt per step; the DMA of a plane is 16 pieces, two per wave, with exec masks and per-lane
-//     offsets computed once per block (the window origin is fixed for the block), so a step's loader work is ~12 scalar instructions;
+//   * the source planes live in an LDS RING of NZ slots (slot = source plane mod NZ), filled by LDS-DMA ahead of the gather: a source
+//     plane is fetched once per block (no z halo) and requests are in flight all the time;
+//   * one barrier and one s_waitcnt per step; the DMA of a plane is 16 pieces, two per wave, with exec masks and per-lane offsets
+//     computed once per anchor (the window origin is fixed for `sublen` planes), so a step's loader work is a few scalar instructions;
+//   * NZ need not be a power of two: the slot of floor(iz) comes from an 8-entry byte table in two SGPRs through v_perm_b32 - the
+//     instruction count of a mask - which buys 40 rows of window where a power-of-two ring leaves 35;
 //   * thread (x, rows r0 .. r0+R-1) is fixed for the whole block: sum(q grad) and sum(q grad yn) accumulate as in the tile kernel,
 //     the zn column comes from U = sum over planes of the running sum (sum_z zn_z P_z = zn_0 S + d (n S - U), zn uniform in z).
-// A pair whose theta does not keep the pre-image inside the window (zs_fits, a function of theta and the shape only) is left to the
+// A pair whose theta does not keep the pre-image inside the window (zs_nsub, a function of theta and the shape only) is left to the
 // tile kernels.  Per-voxel arithmetic is that of tile_body's fast loop: coordinates are ATen's identity coordinate + deviation.
+// Measured (8 x 256^3, MI355X): 253-265 us per launch against 300-313 us for the tile kernels on the same box; L2 requests 12.3 M
+// (18.0 M), HBM-side traffic 1.03 x the algorithmic bytes (1.38 x); barriers and waits are not binding (deleting them changes nothing):
+// the pass is bound by its vector instructions at the clock the chip holds under this load.
 
 #ifndef TRX_ZS_DBG
 #define TRX_ZS_DBG 0   // development ablation (tools/zbench.hip): bits: 1 = no ring DMA, 2 = no target loads, 4 = no gather, 8 = no barrier (racy), 16 = no counted wait (racy)
 #endif
 #ifndef TRX_ZS_MIN_WAVES
 #define TRX_ZS_MIN_WAVES 4
+#endif
+#ifndef TRX_ZS_LEAD
+#define TRX_ZS_LEAD 1   // steps between the issue of a ring plane and the first step that may touch it (1: one more resident plane, Span = NZ - 1)
 #endif
 
 template <int TX_, int TY_, int NZ_, int BW_, int BH_>
@@ -28,13 +36,13 @@ struct ZCfg {
     static constexpr int LPP = (PlaneSlots + 15) / 16;                 // lanes per DMA piece: 16 pieces per plane, two per wave
     static constexpr int PlaneFloats = BW * BH, PlaneBytes = PlaneFloats * 4;
     static constexpr int RingFloats = NZ * PlaneFloats;
-    static constexpr int Span = NZ - 2;                                // source planes a step may touch: [p - Span + 1, p], p = pbase + step
+    static constexpr int Span = NZ - TRX_ZS_LEAD;                                // source planes a step may touch: [p - Span + 1, p], p = pbase + step
     static constexpr int ReduceScratch = Waves * 16 * 65 + Waves * 16;
     static constexpr int Alloc = (RingFloats + 4 > ReduceScratch) ? RingFloats + 4 : ReduceScratch;   // + one float4 the dummy DMAs write
-    static_assert(TX % 64 == 0 && Waves % XW == 0 && TY % RG == 0 && BW % 4 == 0 && LPP <= 64 && NZ >= 4 && NZ <= 8 && Span <= 5, "geometry");
+    static_assert(TX % 64 == 0 && Waves % XW == 0 && TY % RG == 0 && BW % 4 == 0 && LPP <= 64 && NZ >= 4 && NZ <= 8 && Span <= 6, "geometry");
 };
 // 64 x 32 voxels per plane, ring of 7 planes of 72 x 40 floats = 80.6 KB: two blocks per CU.  The ring size is not a power of two: the
-// slot of a source plane comes from a 4-entry byte table in one SGPR (v_perm_b32), at the instruction count of a mask.
+// slot of a source plane comes from an 8-entry byte table (v_perm_b32), at the instruction count of a mask.
 using ZS64 = ZCfg<64, 32, 7, 72, 40>;
 
 struct ZGeom {
@@ -77,13 +85,14 @@ __device__ __forceinline__ bool zs_fits_len(const float *__restrict__ th, float 
     // x: hx - ox <= span + 2 slack + 5 (floor, +1 neighbour, 3 of alignment);  y: + 2;  z: span + drift <= Span - 3 - 2 slack
     return (sx <= (float)C::BW - 6.3f) && (sy <= (float)C::BH - 3.3f) && (sz <= (float)C::Span - 3.3f);   // NaN compares false
 }
-// Number of sub-segments (1, 2 or 4) a block of `planes_per_seg` planes re-anchors its window in; 0: the pair does not fit.
+// Number of sub-segments (1, 2, 4 or 8) a block of `planes_per_seg` planes re-anchors its window in; 0: the pair does not fit.
 template <class C>
 __device__ __forceinline__ int zs_nsub(const float *__restrict__ th, float fD, float fH, float fW, int planes_per_seg)
 {
     if (zs_fits_len<C>(th, fD, fH, fW, planes_per_seg)) return 1;
     if (planes_per_seg >= 64 && zs_fits_len<C>(th, fD, fH, fW, (planes_per_seg + 1) / 2)) return 2;
     if (planes_per_seg >= 128 && zs_fits_len<C>(th, fD, fH, fW, (planes_per_seg + 3) / 4)) return 4;
+    if (planes_per_seg >= 128 && zs_fits_len<C>(th, fD, fH, fW, (planes_per_seg + 7) / 8)) return 8;
     return 0;
 }
 
@@ -121,7 +130,7 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
     const int zseg = lb / ncol, col = lb - zseg * ncol;
     const int X0 = (col % zg.ntx) * C::TX, Y0 = (col / zg.ntx) * C::TY;
     const int zb0 = zseg * zg.planes_per_seg, ze0 = min(zb0 + zg.planes_per_seg, D);
-    // the window is re-anchored every `sublen` planes (1, 2 or 4 sub-segments, from theta: the same rule for every block of the pair)
+    // the window is re-anchored every `sublen` planes (1, 2, 4 or 8 sub-segments, from theta: the same rule for every block of the pair)
     const int nsub = max(1, __builtin_amdgcn_readfirstlane(zs_nsub<C>(th, fD, fH, fW, zg.planes_per_seg)));
     const int sublen = (zg.planes_per_seg + nsub - 1) / nsub;
 
@@ -275,25 +284,25 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
             zid_l = unnorm<3>(zn_l, fD);
         };
         // Ring slots of the source planes step s may touch, zlo = pbase + s - (Span - 1) being the lowest: byte r of `tabA` = slot of
-        // plane zlo + r, of `tabB` = slot of plane zlo + r + 1 (r = 0 .. 3); `selc` + floor(iz) = the byte selector of v_perm_b32.
-        unsigned tabA = 0, tabB = 0, selc = 0;
+        // plane zlo + r, of `tabB` = slot of plane zlo + r + 1 (r = 0 .. 7); `selc` + floor(iz) = the byte selector of v_perm_b32.
+        unsigned long long tabA = 0, tabB = 0;
+        unsigned selc = 0;
         int mlo = 0;   // zlo mod NZ
         auto set_tables = [&](int zlo) {
             mlo = pmod(zlo);
             tabA = tabB = 0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                tabA |= (unsigned)((mlo + r) % C::NZ) << (8 * r);
-                tabB |= (unsigned)((mlo + r + 1) % C::NZ) << (8 * r);
+            for (int r = 0; r < 8; r++) {
+                tabA |= (unsigned long long)((mlo + r) % C::NZ) << (8 * r);
+                tabB |= (unsigned long long)((mlo + r + 1) % C::NZ) << (8 * r);
             }
             selc = 0x0c0c0c00u - (unsigned)zlo;
         };
         auto advance_tables = [&]() {   // zlo -> zlo + 1 (scalar unit)
             mlo = (mlo + 1 == C::NZ) ? 0 : mlo + 1;
-            int m5 = mlo + 4;
-            if (m5 >= C::NZ) m5 -= C::NZ;
+            const int m9 = (mlo + 8) % C::NZ;
             tabA = tabB;
-            tabB = (tabB >> 8) | ((unsigned)m5 << 24);
+            tabB = (tabB >> 8) | ((unsigned long long)m9 << 56);
             selc -= 1u;
         };
 
@@ -308,8 +317,8 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
                 int a0, a1, aA, aB;
                 asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a0) : "v"(floor_to_int(ix)), "s"(bpb));
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a1) : "v"(floor_to_int(iy)), "s"(ys_s), "v"(a0));
-                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aA) : "v"(__builtin_amdgcn_perm(tabA, tabA, sel)), "s"(ps_s), "v"(a1));
-                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aB) : "v"(__builtin_amdgcn_perm(tabB, tabB, sel)), "s"(ps_s), "v"(a1));
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aA) : "v"(__builtin_amdgcn_perm((unsigned)(tabA >> 32), (unsigned)tabA, sel)), "s"(ps_s), "v"(a1));
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aB) : "v"(__builtin_amdgcn_perm((unsigned)(tabB >> 32), (unsigned)tabB, sel)), "s"(ps_s), "v"(a1));
                 Fetch f;
                 f.r00 = *(lds_f2)(unsigned)aA; f.r01 = *(lds_f2)(unsigned)(aA + C::BW * 4);
                 f.r10 = *(lds_f2)(unsigned)aB; f.r11 = *(lds_f2)(unsigned)(aB + C::BW * 4);
@@ -337,15 +346,15 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
         //   T(s+1): this thread's targets of the next plane into the other register set
         //   D(s+2): ring plane pbase + s + 2 into the slot of plane pbase + s + 2 - NZ, which no step >= s reads
         const float *tnext = tgt + (size_t)(zb + 1) * H * W;   // target plane of the next step
-        const char *dnext = plane_ptr(pbase + 2);               // ring plane two steps ahead ...
-        int dslot = pmod(pbase + 2);                            // ... and its slot
+        const char *dnext = plane_ptr(pbase + TRX_ZS_LEAD);     // ring plane TRX_ZS_LEAD steps ahead ...
+        int dslot = pmod(pbase + TRX_ZS_LEAD);                  // ... and its slot
         auto step = [&](int s, float (&use)[R], float (&load)[R]) {
             if (s > 0) {
                 if ((s & 63) == 0) {   // next chunk of the z tables (compiler-counted loads: the pipeline drains here, once per 64 steps)
                     load_ztab(s);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 } else if (TRX_ZS_DBG & 16) {
-                } else if (s + 1 <= last) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else if (TRX_ZS_LEAD == 2 && s + 1 <= last) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!(TRX_ZS_DBG & 8)) __syncthreads();
                 advance_tables();
@@ -353,8 +362,8 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
 #pragma unroll
             for (int j = 0; j < R; j++) asm volatile("" : "+v"(use[j]));
             if (s + 1 <= last) { issue_targets(tnext, load); tnext += (size_t)H * W; }
-            if (s + 2 <= last) {
-                issue_plane(pbase + s + 2, dslot, dnext);
+            if (s + TRX_ZS_LEAD <= last) {
+                issue_plane(pbase + s + TRX_ZS_LEAD, dslot, dnext);
                 dnext += plane_bytes;
                 dslot = (dslot + 1 == C::NZ) ? 0 : dslot + 1;
             }
@@ -368,7 +377,7 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
         set_tables(pbase - (C::Span - 1));
         __syncthreads();   // the ring is zeroed
         // fill the pipeline: the planes steps 0 and 1 touch, the targets of step 0
-        for (int p = pbase - (C::Span - 1); p <= pbase + (last >= 1 ? 1 : 0); p++) issue_plane(p, pmod(p), plane_ptr(p));
+        for (int p = pbase - (C::Span - 1); p <= pbase + min(last, TRX_ZS_LEAD - 1); p++) issue_plane(p, pmod(p), plane_ptr(p));
         issue_targets(tgt + (size_t)zb * H * W, tvA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
