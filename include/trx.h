@@ -48,6 +48,9 @@ typedef enum {
 #define TRX_FLAG_TWO_PASS_FLOW 4u  /* trx_flow_run: keep the moments pass of every iteration (no fusion into the previous update) */
 #define TRX_FLAG_DEEP_TILE 8u      /* affine steps: offer the deep tiles (GeomD, GeomRD) to every pair they fit, whatever the batch and volume size
                                       (by default only where their larger tiles still fill the chip) */
+#define TRX_FLAG_SAVE_LAST 256u      /* trx_flow_slab_update[_fused]: also store the flow this update starts from into st->flow_last (+12 B/voxel written);
+                                      callers set it on the LAST iteration of a run - the iteration that meets stop_crit stores it by itself */
+#define TRX_FLAG_NEAREST 128u        /* trx_flow_warp: nearest-neighbour sampling (SpatialTransformer(mode='nearest'), ref:utils.py:339-365) instead of bi/trilinear */
 #define TRX_FLAG_NO_ZSTREAM 32u     /* affine steps: never use the z-streaming body (pairs next to the identity run GeomD / GeomA like the others) */
 #define TRX_FLAG_ZSTREAM 64u        /* affine steps: offer the z-streaming body whatever the batch size (by default only to launches that fill the chip) */
 #define TRX_FLAG_NO_ROT_DEEP_TILE 16u /* affine steps: never use GeomRD (the 16 x 16 x 16 tile in GeomR's box) - rotated pairs all run GeomR */

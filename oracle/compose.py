@@ -30,7 +30,9 @@ def identity_grid(shape, dtype=torch.float32, device="cpu"):
     return torch.stack(torch.meshgrid(*axes, indexing="ij"))[None]
 
 
-def flow_warp(src, flow, grid=None):
+def flow_warp(src, flow, grid=None, mode="bilinear"):
+    """ref:src/TorchRegister/utils.py:350-365 (SpatialTransformer.forward): identity grid + flow, normalised to [-1, 1] with S - 1,
+    channels flipped to (x, y[, z]), grid_sample(align_corners=True, mode=mode) - `mode` 'bilinear' or 'nearest' as the reference passes it."""
     shape = flow.shape[2:]
     nd = len(shape)
     if grid is None:
@@ -38,7 +40,25 @@ def flow_warp(src, flow, grid=None):
     loc = grid + flow
     loc = torch.stack([2 * (loc[:, i] / (shape[i] - 1) - 0.5) for i in range(nd)], dim=1)
     loc = loc.movedim(1, -1).flip(-1)  # channel-last, (x, y[, z]) order
-    return F.grid_sample(src, loc, mode="bilinear", padding_mode="zeros", align_corners=True)
+    return F.grid_sample(src, loc, mode=mode, padding_mode="zeros", align_corners=True)
+
+
+def flow_warp_nearest_voxel_space(src, flow):
+    """The same nearest warp restated in VOXEL space (what the HIP kernel computes): out = src[rint(voxel + flow)], zeros outside, rint =
+    round half to even.  Differs from flow_warp(mode='nearest') only where voxel + flow is within ~1e-4 of a half-integer (the reference's
+    normalise / un-normalise round trip decides the side there)."""
+    shape = flow.shape[2:]
+    nd = len(shape)
+    pos = identity_grid(shape, flow.dtype, flow.device) + flow
+    idx = torch.round(pos)   # torch.round rounds half to even
+    ok = torch.ones_like(idx[:, 0], dtype=torch.bool)
+    lin = torch.zeros_like(idx[:, 0], dtype=torch.long)
+    for i in range(nd):
+        ok &= (idx[:, i] >= 0) & (idx[:, i] < shape[i])
+        lin = lin * shape[i] + idx[:, i].clamp(0, shape[i] - 1).long()
+    flat = src.reshape(src.shape[0], src.shape[1], -1)
+    out = torch.gather(flat, 2, lin.reshape(lin.shape[0], 1, -1).expand(-1, src.shape[1], -1)).reshape(src.shape)
+    return out * ok[:, None].to(src.dtype)
 
 
 def ncc_loss(y, yp, alpha=100.0):

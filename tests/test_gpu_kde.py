@@ -102,7 +102,7 @@ def test_nmi_loss_caches_the_target_side_only_while_it_is_unchanged():
     y, yp = ph.blobs(shape, 5).cuda(), ph.blobs(shape, 6).cuda()
     crit = U.NMILoss()
     a = crit(y, yp).item()
-    assert crit._cache.get("ykey") is not None and "h1" in crit._cache
+    assert crit._cache.get("yref") is y and "h1" in crit._cache
     b = crit(y, yp).item()                       # second call: the target's patches / extrema / PDF come from the cache
     assert a == b
     fresh = U.NMILoss()(y, yp).item()

@@ -4,6 +4,8 @@ CPU-only.  Golden vectors come from tests/golden/make_golden.py (reference impor
 build container).  Tolerances: fp64 instantiation vs the reference's fp64 run — 1e-9 relative;
 fp32 — max(stated floor, 2x the reference's own fp32-vs-fp64 gap).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -244,3 +246,39 @@ def test_local_ncc_definition_properties():
             c = s[4] - s[0] * s[1] / 9
             cc.append(c * c / ((s[2] - s[0] ** 2 / 9) * (s[3] - s[1] ** 2 / 9) + 1e-5))
     assert abs(compose.local_ncc_loss(y2, p2, 3).item() - (1 - sum(cc) / 30)) < 1e-12
+
+
+# ----------------------------------------------------------------------------- round 3: nearest-mode SpatialTransformer
+def _r3():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixtures_r3.npz"))
+
+
+def _smooth_flow(shape, seed, amp):
+    """tests/golden/make_golden_r3.py::smooth_flow (closed form)"""
+    nd = len(shape)
+    axes = torch.meshgrid(*[torch.arange(s, dtype=torch.float64) for s in shape], indexing="ij")
+    chans = []
+    for c in range(nd):
+        f = torch.zeros(shape, dtype=torch.float64)
+        for k in range(3):
+            arg = sum((0.041 + 0.013 * ((c + k + d) % 3)) * axes[d] for d in range(nd)) + 0.37 * seed + 1.1 * c + 0.7 * k
+            f = f + torch.sin(arg) / (k + 1.0)
+        chans.append(amp * f)
+    return torch.stack(chans)[None].float()
+
+
+@pytest.mark.parametrize("name,shape", [("st_nearest_2d", (48, 64)), ("st_nearest_3d", (20, 36, 28))])
+def test_compose_nearest_warp_matches_reference(name, shape):
+    """oracle/compose.flow_warp(mode='nearest') is the reference's SpatialTransformer(mode='nearest') bit for bit; its voxel-space
+    restatement (the HIP kernel's definition) agrees everywhere except at the listed ties."""
+    from oracle import compose
+    g = _r3()
+    amp, seed = g[f"{name}/meta"]
+    src = ph.blobs(shape, 901) + 0.2 * ph.vol(shape, 0.021, "sin")
+    flow = _smooth_flow(shape, int(seed), float(amp))
+    ref = torch.from_numpy(g[f"{name}/warped"])
+    assert torch.equal(compose.flow_warp(src, flow, mode="nearest"), ref)
+    vox = compose.flow_warp_nearest_voxel_space(src, flow)
+    tie = torch.from_numpy(g[f"{name}/tie"])[:, None]
+    assert torch.equal(vox[~tie], ref[~tie])
+    assert (ref == 0).float().mean() > 0.01   # part of the flow leaves the image: the zero padding is exercised

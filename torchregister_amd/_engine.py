@@ -321,10 +321,10 @@ class FlowSolver:
         _lib.check(rc, "trx_flow_run")
 
 
-def flow_warp(moving, flow):
-    """SpatialTransformer forward: moving [B,C,*sp], flow [B,nd,*sp] -> [B,C,*sp]."""
+def flow_warp(moving, flow, nearest=False):
+    """SpatialTransformer forward: moving [B,C,*sp], flow [B,nd,*sp] -> [B,C,*sp]; nearest: mode='nearest' (round half to even, zeros outside)."""
     lib = _lib.load()
-    batch = _Batch(moving, tables=False)
+    batch = _Batch(moving, tables=False, flags=_lib.FLAG_NEAREST if nearest else 0)
     _require_gpu(flow, "flow")
     fl = flow.detach().contiguous()
     if fl.shape != (batch.B, batch.nd) + batch.spatial:
@@ -534,7 +534,11 @@ class SlabFlowSolver:
             self._side = torch.cuda.Stream(device=self.device)
             self._edge = torch.zeros(1, 8, dtype=torch.float64, device=self.device)
         main = torch.cuda.current_stream(self.device)
-        for _ in range(int(iters)):
+        base_flags = int(self.vol.flags)
+        for it in range(int(iters)):
+            # flow_last (the flow of the last forward) is written by the iteration that meets stop_crit, or by the last one of the run:
+            # only that one pays the extra 12 B/voxel of stores
+            self.vol.flags = base_flags | (_lib.FLAG_SAVE_LAST if (self.flow_last is not None and it == int(iters) - 1) else 0)
             if overlap:
                 self._side.wait_stream(main)                 # the previous update has produced the planes to send
                 with torch.cuda.stream(self._side):
@@ -551,6 +555,7 @@ class SlabFlowSolver:
             if multi:
                 dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.group)   # 64 bytes per iteration
             self.apply(m)
+        self.vol.flags = base_flags
 
 
 def local_ncc_loss_grad(target, warped, window=9, alpha=1.0, eps=1e-5, need_grad=True):

@@ -416,6 +416,32 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_warp_kernel(trx_volumes vol, c
     }
 }
 
+// SpatialTransformer(mode='nearest') (ref:utils.py:339-365 hands `mode` to grid_sample; Attention_UNet's default, ref:utils.py:409-410,520):
+// out = src[rint(voxel + flow)] with zeros outside - grid_sample's nearest mode rounds half to even (std::nearbyint) and tests the
+// rounded index against the volume.  The reference's normalise / un-normalise round trip (ref:utils.py:354-356, align_corners=True) moves
+// a coordinate by ~1e-7 of the axis length, which matters only within that distance of a half-integer; like the bilinear kernels this one
+// works in voxel space.  No gradient wrt the flow exists (ATen returns zeros for it).
+template <int ND>
+__global__ __launch_bounds__(TRX_BLOCK) void flow_warp_nearest_kernel(trx_volumes vol, const float *__restrict__ flow, int channels, float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int D = vol.D, H = vol.H, W = vol.W;
+    const size_t nvox = (size_t)D * H * W;
+    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
+    const float *__restrict__ fl = flow + (size_t)b * ND * nvox;
+    float *__restrict__ o = out + (size_t)b * channels * nvox;
+    for (VoxelWalk vw(blockIdx.x * TRX_BLOCK + threadIdx.x, gridDim.x * TRX_BLOCK, H, W); vw.i < nvox; vw.next(H, W)) {
+        const size_t i = vw.i;
+        float pz = 0.f, py, px;
+        if constexpr (ND == 3) { pz = (float)vw.z + fl[i]; py = (float)vw.y + fl[nvox + i]; px = (float)vw.x + fl[2 * nvox + i]; }
+        else { py = (float)vw.y + fl[i]; px = (float)vw.x + fl[nvox + i]; }
+        const float rz = rintf(pz), ry = rintf(py), rx = rintf(px);
+        const bool in = (rx >= 0.f) && (rx < (float)W) && (ry >= 0.f) && (ry < (float)H) && (rz >= 0.f) && (rz < (float)D);   // NaN compares false: zeros
+        const size_t src = in ? ((size_t)(int)rz * H + (size_t)(int)ry) * W + (size_t)(int)rx : 0;
+        for (int ch = 0; ch < channels; ch++) o[ch * nvox + i] = in ? mov[ch * nvox + src] : 0.f;
+    }
+}
+
 template <int ND>
 __global__ __launch_bounds__(TRX_BLOCK) void flow_warp_bwd_kernel(trx_volumes vol, const float *__restrict__ flow, int channels,
                                                                   const float *__restrict__ grad_out, float *__restrict__ dflow)
@@ -692,7 +718,10 @@ extern "C" int trx_flow_warp(const trx_volumes *vol, const float *flow, int chan
     if (!flow || !out || channels < 1) return TRX_ERR_ARG;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
     hipStream_t s = (hipStream_t)stream;
-    if (vol->ndim == 3) hipLaunchKernelGGL((flow_warp_kernel<3>), grid, block, 0, s, *vol, flow, channels, out);
+    if (vol->flags & TRX_FLAG_NEAREST) {
+        if (vol->ndim == 3) hipLaunchKernelGGL((flow_warp_nearest_kernel<3>), grid, block, 0, s, *vol, flow, channels, out);
+        else hipLaunchKernelGGL((flow_warp_nearest_kernel<2>), grid, block, 0, s, *vol, flow, channels, out);
+    } else if (vol->ndim == 3) hipLaunchKernelGGL((flow_warp_kernel<3>), grid, block, 0, s, *vol, flow, channels, out);
     else hipLaunchKernelGGL((flow_warp_kernel<2>), grid, block, 0, s, *vol, flow, channels, out);
     TRX_CHECK_LAUNCH();
     return TRX_OK;
@@ -764,7 +793,7 @@ extern "C" int trx_flow_slab_update(const trx_volumes *vol, int z_offset, int D_
     TRX_CHECK_LAUNCH();
     // with the regulariser the update reads neighbours of the OLD flow: it is written to flow_tmp (the caller swaps)
     return launch_update<0>(vol, st->flow, smooth ? st->flow_tmp : st->flow, st->adam_m, st->adam_v, coef, *opt, smooth, s,
-                            Slab{z_offset, D_full, halo_lo, halo_hi}, nullptr, st->flow_last, st->flow_last ? 1 : 0);
+                            Slab{z_offset, D_full, halo_lo, halo_hi}, nullptr, st->flow_last, (st->flow_last && (vol->flags & TRX_FLAG_SAVE_LAST)) ? 1 : 0);
 }
 
 // Slab counterpart of the fused step of trx_flow_run (no smoothness term, 3-D): the update also leaves the slab's block partials of
@@ -786,7 +815,7 @@ extern "C" int trx_flow_slab_update_fused(const trx_volumes *vol, int z_offset, 
                        global_moments, D_full, 0, (double *)nullptr, st->stop_crit, st->stopped, 0);
     TRX_CHECK_LAUNCH();
     return launch_update<0>(vol, st->flow, st->flow, st->adam_m, st->adam_v, coef, *opt, false, s, Slab{z_offset, D_full, nullptr, nullptr},
-                            (float *)workspace, st->flow_last, st->flow_last ? 1 : 0);
+                            (float *)workspace, st->flow_last, (st->flow_last && (vol->flags & TRX_FLAG_SAVE_LAST)) ? 1 : 0);
 }
 
 extern "C" int trx_flow_slab_moments_ready(const trx_volumes *vol, int z_offset, int D_full, double *moments, void *workspace,

@@ -33,7 +33,7 @@ constexpr int kLO = TRX_LNCC_TWO_ROWS ? 2 : 1;      // outputs per thread: rows 
 constexpr int kLX = 32, kLY = 8 * kLO;      // output tile of a block in x, y
 constexpr int kLRows = kLY + 8, kLCols = kLX + 8;   // tile + halo 4 (the largest radius)
 
-constexpr int kLCells = (kLRows * kLCols + TRX_BLOCK - 1) / TRX_BLOCK;   // tile cells per thread (3)
+constexpr int kLCells = (kLRows * kLCols + TRX_BLOCK - 1) / TRX_BLOCK;   // tile cells per thread (4: a 40 x 24 tile on 256 threads)
 
 // The raw inputs of one plane of the block's tile (+halo), held in registers between the global loads and the LDS
 // commit: the loads of plane z+1 are issued before the window passes of plane z, so their latency is hidden.
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_finalize_kernel(const float *_
 }
 
 // z segments per column: enough blocks to fill the block slots, each segment at least 32 planes deep (it re-reads 2R halo planes).
-static int lncc_zsplit(int nd, int B, int D, int H, int W, int R)
+static int lncc_zsplit(int nd, int B, int D, int H, int W)
 {
     if (nd == 2) return 1;
     const long cols = (long)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * B;
@@ -310,7 +310,7 @@ template <int R>
 static int launch_lncc(const float *target, const float *warped, int nd, int B, int D, int H, int W, float alpha, float eps, float *loss, float *grad,
                        float *fields, float *partials, hipStream_t s)
 {
-    const int zsplit = lncc_zsplit(nd, B, D, H, W, R);
+    const int zsplit = lncc_zsplit(nd, B, D, H, W);   // the same split for every window: 768 block slots (measured with the three-blocks-per-CU build; the workspace is sized for it)
     if (TRX_LNCC_TWO_ROWS && R >= 3 && zsplit > 1)   // a small batch of a wide window: the three-blocks-per-CU build (see the note on registers above)
         return launch_lncc_mw<R, 3>(target, warped, nd, B, D, H, W, alpha, eps, loss, grad, fields, partials, zsplit, s);
     return launch_lncc_mw<R, 1>(target, warped, nd, B, D, H, W, alpha, eps, loss, grad, fields, partials, zsplit, s);
@@ -318,7 +318,7 @@ static int launch_lncc(const float *target, const float *warped, int nd, int B, 
 
 static size_t lncc_partials_bytes(int nd, int B, int D, int H, int W)
 {
-    const size_t nb = (size_t)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * lncc_zsplit(nd, B, D, H, W, 0);
+    const size_t nb = (size_t)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * lncc_zsplit(nd, B, D, H, W);
     return ((size_t)B * nb * sizeof(float) + 255) & ~(size_t)255;
 }
 

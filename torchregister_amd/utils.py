@@ -158,15 +158,17 @@ def _nmi_pdfs(img1, img2, bins, bandwidth, cache=None):
     unmodified tensor - in a registration loop img1 is the fixed target."""
     key = None
     if cache is not None and not img1.requires_grad:
-        key = (img1.data_ptr(), img1._version, tuple(img1.shape), int(bins), float(bandwidth))
-    if key is not None and cache.get("key") == key:
+        key = (img1._version, int(bins), float(bandwidth))
+    # identity, not address: the cache holds a reference to img1, so `is` cannot be fooled by an allocator that hands a freed
+    # tensor's address (and version 0) to the next one of the same shape
+    if key is not None and cache.get("img1") is img1 and cache.get("key") == key:
         hi1, lo1, h1 = cache["hi1"], cache["lo1"], cache["h1"]
         hi2, lo2 = torch.stack([img2.detach().amax(), img2.detach().amin()]).tolist()
     else:
         hi1, lo1, hi2, lo2 = torch.stack([img1.detach().amax(), img1.detach().amin(), img2.detach().amax(), img2.detach().amin()]).tolist()
         h1 = get_pdf(img1, steps=bins, bandwidth=bandwidth, value_range=(hi1, lo1))
         if key is not None:
-            cache.update(key=key, hi1=hi1, lo1=lo1, h1=h1.detach())
+            cache.update(key=key, img1=img1, hi1=hi1, lo1=lo1, h1=h1.detach())
     h2 = get_pdf(img2, steps=bins, bandwidth=bandwidth, value_range=(hi2, lo2))
     hj = get_pdf(torch.stack((img1, img2), dim=1), steps=bins, bandwidth=bandwidth, value_range=(max(hi1, hi2), min(lo1, lo2)))
     return h1, h2, hj
@@ -238,9 +240,10 @@ class NMILoss(nn.Module):
     def forward(self, y, yp):
         fused = y.is_cuda and yp.is_cuda and y.dtype == torch.float32 and self.bins <= 1024
         if fused and not y.requires_grad:
-            ykey = (y.data_ptr(), y._version, tuple(y.shape))
-            if self._cache.get("ykey") != ykey:
-                self._cache = {"ykey": ykey, "y": self._patches(y)}
+            # the target's patches / extrema / PDF survive while `y` is the SAME tensor object, unmodified: the cache keeps `y` itself
+            # (a strong reference: its storage cannot be recycled under the cache) and compares identity + version counter
+            if self._cache.get("yref") is not y or self._cache.get("yver") != y._version:
+                self._cache = {"yref": y, "yver": y._version, "y": self._patches(y)}
             yq = self._cache["y"]
         else:
             yq = self._patches(y)
@@ -286,6 +289,20 @@ class Regressor(nn.Module):
         return theta.view(1, 3, 4) if theta.shape[-1] == 12 else theta.view(1, 2, 3)
 
 
+class _FlowWarpNearestFn(torch.autograd.Function):
+    """mode='nearest': piecewise constant in the flow - autograd gets the zeros ATen's grid_sampler backward produces for the grid."""
+
+    @staticmethod
+    def forward(ctx, src, flow):
+        ctx.flow_meta = (flow.shape, flow.dtype, flow.device)
+        return _engine.flow_warp(src, flow, nearest=True)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        shape, dtype, device = ctx.flow_meta
+        return None, (torch.zeros(shape, dtype=dtype, device=device) if ctx.needs_input_grad[1] else None)
+
+
 class _FlowWarpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, flow):
@@ -309,8 +326,8 @@ class SpatialTransformer(nn.Module):
 
     def __init__(self, size, mode="bilinear"):
         super().__init__()
-        if mode != "bilinear":
-            raise NotImplementedError("only mode='bilinear' (what Register uses) is implemented on the HIP path")
+        if mode not in ("bilinear", "nearest"):   # the two modes grid_sample has for 5-D inputs (bicubic is 4-D only and unused by the reference)
+            raise NotImplementedError(f"mode={mode!r}: the HIP warp implements 'bilinear' and 'nearest'")
         self.mode = mode
         self.size = tuple(int(s) for s in size)
 
@@ -319,7 +336,7 @@ class SpatialTransformer(nn.Module):
             raise ValueError("flow and src spatial sizes differ")
         if src.shape[0] != flow.shape[0]:
             flow = flow.expand(src.shape[0], *flow.shape[1:])
-        return _FlowWarpFn.apply(src, flow)
+        return (_FlowWarpNearestFn if self.mode == "nearest" else _FlowWarpFn).apply(src, flow)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -346,15 +363,11 @@ class attention_grid(nn.Module):
         self.mode = mode
 
     def forward(self, x, g, device):
-        a = self.input_filter(x)
-        b = self.gate_filter(g)
-        if a.shape[-1] < b.shape[-1]:
-            a = padNd(a, b, device)
-        elif a.shape[-1] > b.shape[-1]:
-            b = padNd(b, a, device)
-        w = torch.sigmoid(self.psi(F.relu(a + b)))
-        w = F.interpolate(w, size=x.shape[2:], mode=self.mode)
-        return self.bnorm(x * w), w
+        feats = [self.input_filter(x), self.gate_filter(g)]   # strided view of the skip tensor, gating signal: sizes differ by a voxel or two
+        big = max(feats, key=lambda t: t.shape[-1])
+        gate = sum(t if t.shape[-1] == big.shape[-1] else padNd(t, big, device) for t in feats)
+        att = F.interpolate(torch.sigmoid(self.psi(F.relu(gate))), size=x.shape[2:], mode=self.mode)
+        return self.bnorm(x * att), att
 
 
 class Attention_UNet(nn.Module):
@@ -390,7 +403,7 @@ class Attention_UNet(nn.Module):
         self.layer9 = nn.Sequential(*double(c[1], c[0]))
         self.out = Conv(in_channels=c[0], out_channels=dims, kernel_size=1)
         self.maxpool = Pool(kernel_size=2, stride=2)
-        self.warp = SpatialTransformer(img_size, 'bilinear' if mode == 'bilinear' else mode)
+        self.warp = SpatialTransformer(img_size, mode)
 
     def features(self, x, device=None):
         """Everything up to the flow head: returns flow [B, nd, *spatial] (no warp)."""

@@ -362,7 +362,10 @@ class flow_register(nn.Module):
     the parameter, optimised entirely by the two-pass HIP kernels with no per-iteration host sync
     (`n` / `in_c` unused; optional Adam and smoothness regulariser).
     Either way `.flow` (voxel units, channel i along spatial dim i; the flow of the LAST FORWARD like the
-    reference's), `.warp` (SpatialTransformer), `.deform(x)` and the stop_crit early stop follow the reference."""
+    reference's), `.warp` (SpatialTransformer), `.deform(x)` and the stop_crit early stop follow the reference.
+    Deviation (flow_model='direct' with a batch): the reference is batch-1 and stops on its one scalar loss
+    (ref:warpings.py:231-233); here a batch is B independent registrations, each pair stops on its OWN loss, and
+    `optimize` reports 'Converged' only when every pair has stopped (`.iterations` holds the per-pair counts)."""
 
     def __init__(self, img_size, mode="bilinear", in_c=1, n=1, criterions=None, weights=[0.33, 0.33, 0.33], lr=1E-3,
                  max_epochs=2000, stop_crit=1E-4, *, flow_model="unet", optimizer="sgd", smooth_weight=0.0):
