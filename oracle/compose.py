@@ -148,15 +148,16 @@ def pose_to_theta(x, max_translate=0.25):
     return torch.stack([torch.cos(a), -torch.sin(a), x[1], torch.sin(a), torch.cos(a), x[2]]).view(1, 2, 3)
 
 
-def affine_loop(moving, target, lr, iters, pose0=None, optimizer="sgd", **loss_kw):
-    """SGD (or Adam, extension) on theta / pose; returns losses, thetas[iters+1], best idx."""
+def affine_loop(moving, target, lr, iters, pose0=None, optimizer="sgd", theta0=None, **loss_kw):
+    """SGD (or Adam, extension) on theta / pose; returns losses, thetas[iters+1], best idx.  theta0: start of the affine mode (default
+    identity, the reference's start: ref:src/TorchRegister/warpings.py:42-55)."""
     nd = moving.dim() - 2
     dt = moving.dtype
     if pose0 is not None:
         p = pose0.clone().to(dt).requires_grad_()
         make = lambda: pose_to_theta(p)  # noqa: E731
     else:
-        p = torch.eye(nd, nd + 1, dtype=dt)[None].clone().requires_grad_()
+        p = (torch.eye(nd, nd + 1, dtype=dt) if theta0 is None else theta0.to(dt).reshape(nd, nd + 1))[None].clone().requires_grad_()
         make = lambda: p  # noqa: E731
     opt = torch.optim.SGD([p], lr) if optimizer == "sgd" else torch.optim.Adam([p], lr)
     losses, thetas, best, best_idx = [], [], None, -1
@@ -175,16 +176,31 @@ def affine_loop(moving, target, lr, iters, pose0=None, optimizer="sgd", **loss_k
     return dict(losses=torch.tensor(losses, dtype=torch.float64), thetas=torch.stack(thetas), best_idx=best_idx)
 
 
-def flow_loop(moving, target, lr, iters, optimizer="sgd", **loss_kw):
+def smooth_regulariser(flow, weight):
+    """Extension (not in the reference): weight / ndim * sum_d mean_{c,p} (forward difference of the flow along d)^2 - the definition
+    of the fused flow kernels' smoothness term (torchregister_amd/csrc/flow.hip, flow_coef_kernel), restated with torch ops."""
+    nd = flow.dim() - 2
+    reg = 0.0
+    for d in range(nd):
+        df = flow.diff(dim=2 + d)
+        reg = reg + (df * df).mean()
+    return weight * reg / nd
+
+
+def flow_loop(moving, target, lr, iters, optimizer="sgd", flow0=None, smooth_weight=0.0, **loss_kw):
+    """ref:src/TorchRegister/warpings.py:208-233 with the flow field itself as the parameter (flow_model='direct'); flow0: its start
+    (default zero); smooth_weight: the smoothness extension above."""
     nd = moving.dim() - 2
     shape = moving.shape[2:]
-    fl = torch.zeros(1, nd, *shape, dtype=moving.dtype, requires_grad=True)
+    fl = (torch.zeros(1, nd, *shape, dtype=moving.dtype) if flow0 is None else flow0.to(moving.dtype).clone()).requires_grad_()
     grid = identity_grid(shape, moving.dtype)
     opt = torch.optim.SGD([fl], lr) if optimizer == "sgd" else torch.optim.Adam([fl], lr)
     losses = []
     for _ in range(iters):
         opt.zero_grad()
         e = weighted_loss(target, flow_warp(moving, fl, grid), **loss_kw)
+        if smooth_weight:
+            e = e + smooth_regulariser(fl, smooth_weight)
         e.backward()
         opt.step()
         losses.append(e.item())
