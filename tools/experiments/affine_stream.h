@@ -12,7 +12,7 @@
 // does not fit two blocks per CU.
 //
 // Y-STREAMING variant of the F1 pass (3-D, MODE 0: moments + sum(qJ)) for transforms near the identity - where every affine run
-// starts and, after a rigid pre-alignment, stays.  Included by affine.hip inside namespace trx.
+// starts and, after a rigid pre-alignment, stays.  Included by tools/kbench.hip inside namespace trx.
 //
 // Why: the tile kernel (tile_body) stages the whole pre-image box of every 32 x 16 x 8 tile, waits for it, gathers, and starts over.
 // Its L2-side request count is 2.24x the algorithmic bytes (x halo: a 32-voxel row + neighbour touches 2-3 lines of 128 B; y halo:

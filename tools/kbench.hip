@@ -6,6 +6,11 @@
 #include <cstdlib>
 #include <vector>
 #include "../torchregister_amd/csrc/affine.hip"
+#ifdef TRX_EXPERIMENT_STREAM
+namespace trx {
+#include "experiments/affine_stream.h"   // the shelved y-streaming F1 kernel (round 2): a measured alternative, never part of the library
+}
+#endif
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 

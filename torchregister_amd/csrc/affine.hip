@@ -15,6 +15,7 @@
 #ifdef TRX_DEV
 #include <cstdlib>   // getenv: development builds only (tools/kbench.hip); the product library reads no environment variable
 #endif
+#include "trx_dev.h"   // development instrumentation (in-kernel stamps, LDS padding): no-ops unless tools/kbench.hip asks for them
 
 #include "trx_common.h"
 
@@ -183,9 +184,6 @@ __global__ __launch_bounds__(TRX_BLOCK) void affine_accum_kernel(trx_volumes vol
 // Thread (x, z) is fixed for the whole column, so only sum(q grad) and sum(q grad yn) live in registers and
 // the xn / zn columns of the 41 sums are one multiply at the very end.
 // ------------------------------------------------------------------------------------------
-#ifndef TRX_TILE_CFG
-#define TRX_TILE_CFG 0
-#endif
 // Two geometries of the tile kernel:
 //  cfg 0: 512-thread blocks, tile 32 x 16 y 8 z, ONE 56.7 KB box, 2 blocks per CU (staging of one block overlaps the gather
 //         of the other), 7 DMA pieces of two box planes each;
@@ -211,17 +209,11 @@ struct TileCfg {
     static constexpr int BoxAlloc = (Bufs * BoxFloats > ReduceScratch) ? Bufs * BoxFloats : ReduceScratch;
     static_assert(BW % 4 == 0 && PP * PlaneSlots <= Threads && (PP == 2 || PP == 4), "one DMA piece: at most one slot per thread");
 };
-#ifndef TRX_GEOMA_BD
-#define TRX_GEOMA_BD 14   // (13 = 52.6 KB: three blocks per CU fit the LDS; measured with TRX_TILE_MIN_WAVES=6)
-#endif
 using GeomA = TileCfg<32, 8, 512, 44, 23, TRX_GEOMA_BD, 2, 1>;      // near-identity transforms: 32 x 16 x 8 tile, 44 x 23 x 14 box (56.7 KB)
 using GeomDeep = TileCfg<32, 16, 1024, 44, 22, 21, 4, 2>;  // cfg 1 (measured alternative): 1024 threads, two 81 KB boxes
 // Rotated transforms: the pre-image of a 32-wide tile grows by 31 sin(angle) rows / planes and stops fitting any box beyond
 // ~0.1 rad.  A more cubic tile (16 x 16 x 8, four y-quarters of 4 rows per thread) with a 28 x 26 x 16 box (46.6 KB) fits
 // every rotation about one axis up to ~0.5 rad at 55 us per 256^3 pair, whatever the angle (the global-gather fallback: 125 us).
-#ifndef TRX_GEOMR_BIG
-#define TRX_GEOMR_BIG 1
-#endif
 #if TRX_GEOMR_BIG
 // 28 x 27 x 26 box (78.6 KB, still two blocks per CU): the pre-image of the 16 x 16 x 8 tile under ANY rotation (span <= |(15,15,7)| = 22.3
 // voxels per axis) fits, i.e. every pose the reference's rigid mode can draw (angles uniform in [0,1) rad, ref:utils.py:316-330);
@@ -259,9 +251,6 @@ using GeomP = GeomR;
 using GeomP = GeomA;
 #endif
 
-#ifndef TRX_GEOM_MODEL
-#define TRX_GEOM_MODEL 1   // y-split of the tile columns from the occupancy model in tile_geom (0: the round-1 rules - measured alternative)
-#endif
 struct TileGeom {
     int ntx, nty, ntz, ntiles, blocks_per_pair, ysplit, tiles_per_seg;
 };
@@ -332,69 +321,6 @@ static TileGeom tile_geom(const trx_volumes &v)
     return t;
 }
 
-#ifndef TRX_DBG_SKIP
-#define TRX_DBG_SKIP 0   // development ablation (tools/kbench.hip): 1 = no gather/compute, 2 = no box staging, 3 = no target loads
-#endif
-#ifndef TRX_TIMING
-#define TRX_TIMING 0      // development (tools/kbench.hip): per-block staging / gather cycle counts into trx_timing[]
-#endif
-#if TRX_TIMING
-__device__ unsigned long long trx_timing[4 * 8192];
-#endif
-#ifndef TRX_SWP_BARRIER
-#define TRX_SWP_BARRIER 0
-#endif
-#ifndef TRX_DMA_SPREAD
-#define TRX_DMA_SPREAD 1   // cfg 1: issue the next tile's DMA pieces between the rows of the gather (0: all at once before it)
-#endif
-#ifndef TRX_TGT_POLICY
-#define TRX_TGT_POLICY ""   // cache policy suffix of the target loads (development)
-#endif
-#ifndef TRX_BOX_POLICY
-#define TRX_BOX_POLICY ""   // cache policy suffix of the box DMA (development: " nt", " sc1")
-#endif
-#ifndef TRX_DUAL_DEFAULT
-#define TRX_DUAL_DEFAULT 1   // rigid steps, loss-only, warp and warp-backward launches pick GeomA / GeomR per pair: 1 in one kernel, 2 as two launches; 0: never
-#endif
-#ifndef TRX_DMA_EXECZ_SKIP
-#define TRX_DMA_EXECZ_SKIP 1   // branch over a DMA piece none of whose lanes fetch (an LDS-DMA with exec = 0 still costs its issue)
-#endif
-#ifndef TRX_FIN_ABLATE
-#define TRX_FIN_ABLATE 0
-#endif
-#ifndef TRX_DEEP_TILE
-#define TRX_DEEP_TILE 1   // the step kernels carry GeomD (deep tile) as a third per-pair choice (0: GeomA / GeomR only - measured alternative)
-#endif
-#ifndef TRX_DEEP_SMALL
-#define TRX_DEEP_SMALL 1   // GeomD also for small batches whose deep tiling fills the block slots (0: only from 1024 blocks - measured alternative)
-#endif
-#ifndef TRX_ROT_DEEP_TILE
-#define TRX_ROT_DEEP_TILE 1   // the step kernels carry GeomRD as a fourth per-pair choice (0: never - measured alternative)
-#endif
-#ifndef TRX_PERSISTENT_BLOCKS
-#define TRX_PERSISTENT_BLOCKS 512   // block slots of one MI355X for the 512-thread step kernels (two per CU): the size of the flat grid
-#endif
-#ifndef TRX_FLAT_GRID
-#define TRX_FLAT_GRID 1             // 0: big batches launch (largest geometry) x (pairs) blocks like the small ones (measured alternative)
-#endif
-#ifndef TRX_ZS_MIN_BLOCKS
-#define TRX_ZS_MIN_BLOCKS 512   // the z-streaming body is offered to launches of at least this many of its blocks ...
-#endif
-#ifndef TRX_ZS_MIN_PLANES
-#define TRX_ZS_MIN_PLANES 64    // ... of at least this many planes each (a block pays ~7 planes of pipeline fill)
-#endif
-#ifndef TRX_SWP
-#define TRX_SWP 1   // software pipeline of the gather: LDS reads of row j+1 issued before the arithmetic of row j (0: at use)
-#endif
-#ifndef TRX_STAGE_PRIO
-#define TRX_STAGE_PRIO 3
-#endif
-#ifndef TRX_TILE_MIN_WAVES
-#define TRX_TILE_MIN_WAVES 4   // waves per SIMD the register allocator must allow (16 waves per CU)
-#endif
-#ifndef TRX_DUAL_MIN_WAVES
-#define TRX_DUAL_MIN_WAVES 4   // the dual kernel's LDS (GeomR's 78.6 KB box) allows two blocks per CU whatever the registers
-#endif
 // packed running sums of the tile kernel: AB[q][c] = (sum q*g_c, sum q*g_c*yn), M01 = (Sy, Sw), M23 = (Syy, Sww)
 struct F1Acc {
     f2 AB[3][3], M01, M23;
@@ -689,9 +615,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
             lim_blk = __builtin_amdgcn_readfirstlane(((min(ezm, kBD) - 1) << 16) | ((min(eym, kBH) - 1) << 8) | (min(ex4m, kBW4) - 1));
         }
         int m_lim = -1, m_lo = -1, m_hi = -1, m_px = -2;
-#if TRX_TIMING
-        unsigned long long tm_acc[4] = {0, 0, 0, 0};   // wave 0: stage-wait, barrier-1 wait, gather, barrier-2 wait
-#endif
+        TRX_TM_INIT();
         typedef const __attribute__((address_space(3))) f2u *lds_f2;
         // Tiles come in chunks of 64 (geometry: one tile per lane); the leading run of fast tiles of a chunk is a plain
         // counted loop - no exit in the middle, so the accumulators stay in one register set.
@@ -926,9 +850,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
           if constexpr (kBufs == 1) {
             // one box, two blocks per CU: burst - wait - barrier - gather - barrier
             for (int gl = 0; gl < nf; gl++) {
-#if TRX_TIMING
-              const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
-#endif
+              TRX_TM_STAMP(tm0);
               // row tables of this wave's 8 rows in lanes 0..7 (broadcast in gather_tile with constant-lane v_readlane)
               float yn_l;
               asm volatile("global_load_dword %0, %1, %2" : "=v"(yn_l) : "v"(lane7b), "s"(ytab + (ty + gl) * kTY + j0) : "memory");
@@ -944,24 +866,13 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
                   asm volatile("" : "+v"(yn_l));
               }
               const float yid_l = unnorm<3>(yn_l, fH);
-#if TRX_TIMING
-              const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
-#endif
+              TRX_TM_STAMP(tm1);
               __syncthreads();
-#if TRX_TIMING
-              const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
-#endif
+              TRX_TM_STAMP(tm2);
               gather_tile(gl, 0, yn_l, yid_l, tv, nullptr, false);
-#if TRX_TIMING
-              const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
-#endif
+              TRX_TM_STAMP(tm3);
               __syncthreads();   // the box is overwritten by the next tile
-#if TRX_TIMING
-              {
-                  const unsigned long long tm4 = __builtin_amdgcn_s_memtime();
-                  tm_acc[0] += tm1 - tm0; tm_acc[1] += tm2 - tm1; tm_acc[2] += tm3 - tm2; tm_acc[3] += tm4 - tm3;
-              }
-#endif
+              TRX_TM_TILE_DONE();
             }
           } else {
             // two boxes, one block per CU: the DMA of tile g+1 (and, row by row, its target column) is in flight while
@@ -971,9 +882,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
                 issue_box(0, 0, false);
             }
             for (int gl = 0; gl < nf; gl++) {
-#if TRX_TIMING
-              const unsigned long long tm0 = __builtin_amdgcn_s_memtime();
-#endif
+              TRX_TM_STAMP(tm0);
               float yn_l;
               asm volatile("global_load_dword %0, %1, %2" : "=v"(yn_l) : "v"(lane7b), "s"(ytab + (ty + gl) * kTY + j0) : "memory");
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's box pieces (issued one tile ago) and target column
@@ -984,25 +893,14 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
                   asm volatile("" : "+v"(yn_l));
               }
               const float yid_l = unnorm<3>(yn_l, fH);
-#if TRX_TIMING
-              const unsigned long long tm1 = __builtin_amdgcn_s_memtime();
-#endif
+              TRX_TM_STAMP(tm1);
               __syncthreads();
-#if TRX_TIMING
-              const unsigned long long tm2 = __builtin_amdgcn_s_memtime();
-#endif
+              TRX_TM_STAMP(tm2);
               const int gn = (gl + 1 < nf) ? gl + 1 : gl;
               if (gl + 1 < nf) issue_box(gl + 1, (gl + 1) & 1, TRX_DMA_SPREAD);
-#if TRX_TIMING
-              const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
-#endif
+              TRX_TM_STAMP(tm3);
               gather_tile(gl, gl & 1, yn_l, yid_l, tv, tgt + (size_t)(ty + gn) * kTY * W, TRX_DMA_SPREAD && gl + 1 < nf);
-#if TRX_TIMING
-              {
-                  const unsigned long long tm4 = __builtin_amdgcn_s_memtime();
-                  tm_acc[0] += tm1 - tm0; tm_acc[1] += tm2 - tm1; tm_acc[2] += tm3 - tm2; tm_acc[3] += tm4 - tm3;
-              }
-#endif
+              TRX_TM_TILE_DONE();
             }
             // the prefetch issued during the last tile is still in flight: its destination registers must not be reused,
             // and the generic loop below must not overwrite box 0 while a slower wave still gathers from it
@@ -1014,12 +912,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
           ty += nf;
           if (nf < chunk) break;   // the generic loop takes over at tile ty (same 64-tile chunking, geometry already in g_*)
         }
-#if TRX_TIMING
-        if (tid == 0) {
-            const size_t bi = (size_t)by * gridDim.x + bx;
-            if (bi < 8192) for (int i = 0; i < 4; i++) trx_timing[bi * 4 + i] = tm_acc[i];
-        }
-#endif
+        TRX_TM_STORE();
         if (!act) {
 #pragma unroll
             for (int q = 0; q < 3; q++)
@@ -1218,11 +1111,7 @@ template <int MODE>
 __global__ __launch_bounds__(GeomP::Threads, TRX_TILE_MIN_WAVES) void affine_tile_kernel(trx_volumes vol, const float *__restrict__ theta,
                                                                                           TileGeom tg, int channels, float *__restrict__ partials)
 {
-#ifdef TRX_LDS_PAD   // development: inflate the LDS footprint to force one block per CU
-    __shared__ __attribute__((aligned(16))) float box[GeomP::BoxAlloc + TRX_LDS_PAD];
-#else
-    __shared__ __attribute__((aligned(16))) float box[GeomP::BoxAlloc];
-#endif
+    __shared__ __attribute__((aligned(16))) float box[GeomP::BoxAlloc + TRX_DEV_LDS_PAD];
     tile_body<MODE, GeomP>(vol, theta, tg, channels, partials, box, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
@@ -1386,9 +1275,6 @@ static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const fl
 
 #pragma clang diagnostic pop
 
-#ifdef TRX_EXPERIMENT_STREAM
-#include "../../tools/experiments/affine_stream.h"   // y-streaming F1 kernel: a measured alternative, not part of the library
-#endif
 
 // closed-form base coordinates for callers that pass no tables: (2i+1)/S - 1
 __global__ void fill_tables_kernel(float *__restrict__ tab, int W, int H, int D)
@@ -1551,11 +1437,6 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
             for (int k = 0; k < NPOSE; k++) pose_old[k] = param[k];
         }
     }
-#if TRX_FIN_ABLATE == 2   // development: no reduction
-    if (i < 64) S[i] = 1.0 + 0.01 * i;
-    __syncthreads();
-    if (false)
-#endif
     {
         // rows the F1 pass wrote for this pair: the dual kernel lays a pair's rows out with stride nblk and fills the first
         // blocks_per_pair of the geometry it chose for the pair - it left that count in rows_used[b]
@@ -1569,10 +1450,6 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
         rsbc2 = 1.0 / sqrt(1.0 - ipow((double)oc.beta2, t + 1));
     }
     if (i >= 64) return;
-#if TRX_FIN_ABLATE == 1   // development: reduction only
-    if (i == 0) st.step[b] = t + 1 + (int)(S[0] > 1e300) + (int)(bc1 + rsbc2 + theta_old + p_old + m_old + v_old + best_prev > 1e300);
-    return;
-#endif
 
     const double scale[3] = {0.5 * W, 0.5 * H, 0.5 * D};
     double dth_i, total;
