@@ -385,6 +385,293 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
     if constexpr (NEXT) block_reduce_store<kFlowNP, 8>(nv, next_partials + ((size_t)b * gridDim.x + blockIdx.x) * kFlowNP);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// 3-D passes as COLUMN WALKS (round 3).  The grid-stride kernels above (still the 2-D path) spend ~490 vector instructions per
+// voxel-wave, most of them 64-bit index arithmetic and selects for the 18 neighbour loads of the smoothness term, and every XCD
+// re-fetches the z neighbours of its voxels from the fabric (rocprofv3: 128 M VALU instructions and 1.07 GB of L2 read misses per
+// 256^3 Adam + smoothness update against 0.74 GB of unique reads).  Here a 256-thread block owns a (64 x, 4 y) column of one z
+// segment - wave w = row y0 + w, lane = x - and every thread walks its (x, y) along z: the voxel index advances by one plane per trip,
+// the z neighbours of the flow are the previous and the next trip's own loads (kept in registers), the y / x neighbours are the other
+// waves' / lanes' lines (L1), and the XCD-aware block order keeps a column's y neighbours in its L2.  Per-voxel arithmetic, the order
+// of every sum and the partial-row layout are those of the kernels above, so the coefficient kernel and the slab entry points are
+// unchanged and a fused update still leaves the bits a stand-alone moments pass would.
+// ---------------------------------------------------------------------------------------------------
+struct ColGeom {
+    int ntx, nty, nzseg, planes_per_seg, nblk;
+};
+
+// The eight corners of a trilinear sample, fetched now and interpolated later (the column walk requests the corners of trip z + 1 while
+// trip z computes).  Same loads and the same lerp3 as sample3 / sample3_padded (trx_common.h): bit-identical values.
+struct Corners3 {
+    float v[8], tx, ty, tz;
+};
+__device__ __forceinline__ Corners3 load_corners3(const float *__restrict__ mov, int D, int H, int W, float ix, float iy, float iz)
+{
+    Corners3 c;
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    c.tx = ix - fx; c.ty = iy - fy; c.tz = iz - fz;
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const bool interior = ((unsigned)x0 < (unsigned)(W - 1)) & ((unsigned)y0 < (unsigned)(H - 1)) & ((unsigned)z0 < (unsigned)(D - 1));
+    const size_t HW = (size_t)H * W;
+    if (__all(interior)) {
+        const float *p = mov + ((size_t)z0 * H + y0) * W + x0, *q = p + HW;
+        c.v[0] = p[0]; c.v[1] = p[1]; c.v[2] = p[W]; c.v[3] = p[W + 1];
+        c.v[4] = q[0]; c.v[5] = q[1]; c.v[6] = q[W]; c.v[7] = q[W + 1];
+        return c;
+    }
+    const int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    const bool bx0 = (unsigned)x0 < (unsigned)W, bx1 = (unsigned)x1 < (unsigned)W;
+    const bool by0 = (unsigned)y0 < (unsigned)H, by1 = (unsigned)y1 < (unsigned)H;
+    const bool bz0 = (unsigned)z0 < (unsigned)D, bz1 = (unsigned)z1 < (unsigned)D;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    const int cz0 = min(max(z0, 0), D - 1), cz1 = min(max(z1, 0), D - 1);
+    const float *r00 = mov + ((size_t)cz0 * H + cy0) * W, *r01 = mov + ((size_t)cz0 * H + cy1) * W;
+    const float *r10 = mov + ((size_t)cz1 * H + cy0) * W, *r11 = mov + ((size_t)cz1 * H + cy1) * W;
+    c.v[0] = (bz0 & by0 & bx0) ? r00[cx0] : 0.f; c.v[1] = (bz0 & by0 & bx1) ? r00[cx1] : 0.f;
+    c.v[2] = (bz0 & by1 & bx0) ? r01[cx0] : 0.f; c.v[3] = (bz0 & by1 & bx1) ? r01[cx1] : 0.f;
+    c.v[4] = (bz1 & by0 & bx0) ? r10[cx0] : 0.f; c.v[5] = (bz1 & by0 & bx1) ? r10[cx1] : 0.f;
+    c.v[6] = (bz1 & by1 & bx0) ? r11[cx0] : 0.f; c.v[7] = (bz1 & by1 & bx1) ? r11[cx1] : 0.f;
+    return c;
+}
+// value and derivative in flow-channel order (z, y, x) like flow_sample_v<3>
+__device__ __forceinline__ float lerp_corners3(const Corners3 &c, float *d)
+{
+    const Samp3 s = lerp3(c.v[0], c.v[1], c.v[2], c.v[3], c.v[4], c.v[5], c.v[6], c.v[7], c.tx, c.ty, c.tz);
+    d[0] = s.dz; d[1] = s.dy; d[2] = s.dx;
+    return s.v;
+}
+constexpr int kColRows = TRX_BLOCK / 64;
+
+static ColGeom flow_col_geom(const trx_volumes &v)
+{
+    ColGeom g;
+    g.ntx = (v.W + 63) / 64; g.nty = (v.H + kColRows - 1) / kColRows;
+    const long cols = (long)g.ntx * g.nty * v.B;
+    long want = (2048 + cols - 1) / cols;            // ~2048 blocks in flight (8 per CU at the kernels' 7-8 waves per SIMD)
+    if (want > v.D / 8) want = v.D / 8;              // a segment start costs one extra plane of flow loads
+    if (want < 1) want = 1;
+    g.planes_per_seg = (int)((v.D + want - 1) / want);
+    g.nzseg = (v.D + g.planes_per_seg - 1) / g.planes_per_seg;
+    g.nblk = g.ntx * g.nty * g.nzseg;
+    return g;
+}
+
+struct ColWalk {
+    int x, y, z0, z1;
+    bool active;
+    unsigned i;   // voxel index of (z0, y, x)
+    __device__ __forceinline__ ColWalk(const ColGeom &g, int D, int H, int W)
+    {
+        int l = blockIdx.x;
+        if ((g.nblk & 7) == 0) l = (l & 7) * (g.nblk >> 3) + (l >> 3);   // blocks b, b + 8, ... share an XCD: give it a contiguous run of columns
+        const int ncol = g.ntx * g.nty, zs = l / ncol, c = l - zs * ncol, ty = c / g.ntx, tx = c - ty * g.ntx;
+        x = tx * 64 + (threadIdx.x & 63); y = ty * kColRows + (threadIdx.x >> 6);
+        z0 = zs * g.planes_per_seg; z1 = min(z0 + g.planes_per_seg, D);
+        active = (x < W) && (y < H) && (z0 < z1);
+        i = active ? (unsigned)((z0 * H + y) * W + x) : 0u;
+    }
+};
+
+template <bool SMOOTH>
+__global__ __launch_bounds__(TRX_BLOCK) void flow_moments3_kernel(trx_volumes vol, const float *__restrict__ flow, float *__restrict__ partials, Slab slab,
+                                                                  ColGeom cg)
+{
+    const int b = blockIdx.y;
+    const int D = vol.D, H = vol.H, W = vol.W;
+    const unsigned HW = (unsigned)(H * W), nvox = (unsigned)D * HW;
+    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
+    const float *__restrict__ tgt = vol.target + (size_t)b * vol.target_stride;
+    const float *__restrict__ f0p = flow + (size_t)b * 3 * nvox, *__restrict__ f1p = f0p + nvox, *__restrict__ f2p = f1p + nvox;
+    float vals[kFlowNP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const ColWalk cw(cg, D, H, W);
+    if (cw.active) {
+        const int x = cw.x, y = cw.y;
+        const bool y_hi = y + 1 < H, x_hi = x + 1 < W;
+        unsigned i = cw.i;
+        float fc[3] = {f0p[i], f1p[i], f2p[i]}, tc = tgt[i];
+        for (int z = cw.z0; z < cw.z1; z++, i += HW) {
+            const bool z_hi = z + 1 < D;
+            const unsigned in = i + (z_hi ? HW : 0u);                  // the next plane's voxel (this one again at the far face: difference 0)
+            float fn[3] = {f0p[in], f1p[in], f2p[in]};
+            const float tn = tgt[in];
+            float d[3];
+            const float w = flow_sample_v<3>(mov, fc, slab.Dm, H, W, z + slab.zoff, y, x, d);
+            const float yv = tc;
+            vals[0] += yv; vals[1] += w;
+            vals[2] = fmaf(yv, yv, vals[2]); vals[3] = fmaf(w, w, vals[3]); vals[4] = fmaf(yv, w, vals[4]);
+            if constexpr (SMOOTH) {
+                // forward differences; dd = 0 (z): the next plane is in registers, across a slab boundary the lower slab counts it
+                float fz[3] = {fn[0], fn[1], fn[2]};
+                if (!z_hi && slab.halo_hi != nullptr) {
+                    const size_t hi = (size_t)y * W + x;
+                    fz[0] = slab.halo_hi[hi]; fz[1] = slab.halo_hi[(size_t)HW + hi]; fz[2] = slab.halo_hi[2 * (size_t)HW + hi];
+                }
+                const unsigned iy = i + (y_hi ? (unsigned)W : 0u), ix = i + (x_hi ? 1u : 0u);
+                const float fy[3] = {f0p[iy], f1p[iy], f2p[iy]}, fx[3] = {f0p[ix], f1p[ix], f2p[ix]};
+#pragma unroll
+                for (int c = 0; c < 3; c++) { const float df = fz[c] - fc[c]; vals[5] = fmaf(df, df, vals[5]); }
+#pragma unroll
+                for (int c = 0; c < 3; c++) { const float df = fy[c] - fc[c]; vals[6] = fmaf(df, df, vals[6]); }
+#pragma unroll
+                for (int c = 0; c < 3; c++) { const float df = fx[c] - fc[c]; vals[7] = fmaf(df, df, vals[7]); }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) fc[c] = fn[c];
+            tc = tn;
+        }
+    }
+    block_reduce_store<kFlowNP, 8>(vals, partials + ((size_t)b * gridDim.x + blockIdx.x) * kFlowNP);
+}
+
+// MODE 0: optimiser update (SGD / Adam) written to flow_out;  MODE 1: write the gradient to flow_out.  NEXT: see flow_update_kernel.
+// Registers: the smoothness variants hold a trip of prefetched state (up to 18 values) next to the gathers' operands - four waves per
+// SIMD with all of it in registers beat five with part of the prefetch undone (256^3: 367 against 407 us); the lighter variants fit 5-8.
+template <int MODE, bool SMOOTH, bool NEXT, bool ADAM>
+__global__ __launch_bounds__(TRX_BLOCK, SMOOTH ? 4 : 5) void flow_update3_kernel(trx_volumes vol, const float *flow, float *flow_out, float *__restrict__ adam_m,
+                                                                 float *__restrict__ adam_v, const FlowCoef *__restrict__ coef, trx_opt_cfg oc, Slab slab,
+                                                                 ColGeom cg, float *__restrict__ next_partials, float *__restrict__ flow_last, int save_last)
+{
+    static_assert(!NEXT || MODE == 0, "the fused next-iteration moments ride on the update");
+    float nv[kFlowNP] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int b = blockIdx.y;
+    const int D = vol.D, H = vol.H, W = vol.W;
+    const unsigned HW = (unsigned)(H * W), nvox = (unsigned)D * HW;
+    const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
+    const float *__restrict__ tgt = vol.target + (size_t)b * vol.target_stride;
+    const float *fl = flow + (size_t)b * 3 * nvox;   // may alias fo (in-place update without the regulariser): no restrict
+    float *fo = flow_out + (size_t)b * 3 * nvox;
+    const FlowCoef c = coef[b];
+    float *__restrict__ fkeep = nullptr;   // != nullptr: this update also keeps the flow it starts from (the flow of the last forward)
+    if constexpr (MODE == 0) {
+        if (c.mode >= kUpdCopy) {          // a pair that has stopped early (block-uniform): settle the buffers, no arithmetic
+            if (c.mode != kUpdSkip && fo != fl) {
+                float *__restrict__ keep = (c.mode == kUpdTransition && flow_last) ? flow_last + (size_t)b * 3 * nvox : nullptr;
+                for (size_t i = (size_t)blockIdx.x * TRX_BLOCK + threadIdx.x; i < (size_t)3 * nvox; i += (size_t)gridDim.x * TRX_BLOCK) {
+                    if (keep) keep[i] = fo[i];
+                    fo[i] = fl[i];
+                }
+            }
+            return;   // (a fused update leaves next_partials as they are: the coefficient kernel of a stopped pair does not read them)
+        }
+        if (flow_last && (save_last || c.mode == kUpdHit)) fkeep = flow_last + (size_t)b * 3 * nvox;
+    }
+    constexpr bool adam = (MODE != 1) && ADAM;
+    float *__restrict__ am = adam_m + (size_t)b * 3 * nvox, *__restrict__ av = adam_v + (size_t)b * 3 * nvox;
+    const ColWalk cw(cg, D, H, W);
+    if (cw.active) {
+        const int x = cw.x, y = cw.y;
+        const unsigned dyl = y > 0 ? (unsigned)W : 0u, dyh = y + 1 < H ? (unsigned)W : 0u, dxl = x > 0 ? 1u : 0u, dxh = x + 1 < W ? 1u : 0u;
+        const size_t hidx = (size_t)y * W + x;
+        unsigned i = cw.i;
+        float fc[3], fm[3] = {0.f, 0.f, 0.f}, tc = tgt[i];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) fc[ch] = fl[ch * (size_t)nvox + i];
+        if constexpr (SMOOTH) {   // the plane below the segment's first: the flow itself, the lower slab's plane, or (first plane of the volume) the voxel itself
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                fm[ch] = cw.z0 > 0 ? fl[ch * (size_t)nvox + i - HW] : (slab.halo_lo ? slab.halo_lo[ch * (size_t)HW + hidx] : fc[ch]);
+        }
+        // Everything a trip needs besides the gather has an address that is known one trip ahead (the walk is i += H W): the optimiser
+        // state and the in-plane neighbours of trip z + 1 are requested during trip z, next to the flow / target of z + 1 - one memory
+        // round trip per trip (the gather's) instead of three dependent ones.
+        struct Side { float m[3], v[3], yl[3], yh[3], xl[3], xh[3]; };
+        auto load_side = [&](unsigned iv) {
+            Side sd;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                sd.m[ch] = sd.v[ch] = sd.yl[ch] = sd.yh[ch] = sd.xl[ch] = sd.xh[ch] = 0.f;
+                if (adam) { sd.m[ch] = am[ch * (size_t)nvox + iv]; sd.v[ch] = av[ch * (size_t)nvox + iv]; }
+                if constexpr (SMOOTH) {
+                    const float *fch = fl + ch * (size_t)nvox;
+                    sd.yl[ch] = fch[iv - dyl]; sd.yh[ch] = fch[iv + dyh]; sd.xl[ch] = fch[iv - dxl]; sd.xh[ch] = fch[iv + dxh];
+                }
+            }
+            return sd;
+        };
+        Side cur = load_side(i);
+        // ... and so has the gather of trip z + 1 once the flow of plane z + 1 has arrived (it was requested a trip earlier): its eight
+        // corners are requested before trip z computes.  Only the second sample of a fused step (at the flow this trip writes) waits.
+        auto corners_at = [&](const float (&f)[3], int zz) {
+            return load_corners3(mov, slab.Dm, H, W, (float)x + f[2], (float)y + f[1], (float)(zz + slab.zoff) + f[0]);
+        };
+        Corners3 gc = corners_at(fc, cw.z0);
+        Corners3 g2 = gc;   // (NEXT) corners of the previous trip's second sample, and its target value
+        float y2 = 0.f;
+        auto fold_next = [&](const Corners3 &g, float yq) {
+            float d2[3];
+            const float w2 = lerp_corners3(g, d2);
+            nv[0] += yq; nv[1] += w2;
+            nv[2] = fmaf(yq, yq, nv[2]); nv[3] = fmaf(w2, w2, nv[3]); nv[4] = fmaf(yq, w2, nv[4]);
+        };
+        for (int z = cw.z0; z < cw.z1; z++, i += HW) {
+            const bool z_hi = z + 1 < D;
+            const unsigned in = i + (z_hi ? HW : 0u);
+            float fn[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) fn[ch] = fl[ch * (size_t)nvox + in];
+            const float tn = tgt[in];
+            const Side nxt = load_side(in);   // (the last trip of the volume re-reads its own voxel: harmless, discarded)
+            float d[3];
+            const float w = lerp_corners3(gc, d);
+            const float yv = tc;
+            const float go = fmaf(c.k1, yv - c.my, fmaf(c.k2, w - c.mw, c.q * (w - yv)));
+            float pnew[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                float g = go * d[ch];
+                const float f0 = fc[ch];
+                if constexpr (SMOOTH) {
+                    // (f0 - f[lo]) - (f[hi] - f0) per axis; at a face the neighbour is the voxel itself (term 0), across a slab boundary the halo plane
+                    const float zlo = fm[ch];
+                    float zhi = fn[ch];
+                    if (!z_hi && slab.halo_hi) zhi = slab.halo_hi[ch * (size_t)HW + hidx];
+                    g = fmaf(c.sm[0], (f0 - zlo) - (zhi - f0), g);
+                    g = fmaf(c.sm[1], (f0 - cur.yl[ch]) - (cur.yh[ch] - f0), g);
+                    g = fmaf(c.sm[2], (f0 - cur.xl[ch]) - (cur.xh[ch] - f0), g);
+                    if constexpr (NEXT) {   // smoothness sums of the flow this step STARTS from (flow_moments3_kernel's arithmetic and order)
+                        const float dz = zhi - f0, dy = cur.yh[ch] - f0, dx = cur.xh[ch] - f0;
+                        nv[5] = fmaf(dz, dz, nv[5]); nv[6] = fmaf(dy, dy, nv[6]); nv[7] = fmaf(dx, dx, nv[7]);
+                    }
+                }
+                if constexpr (MODE == 1) {
+                    fo[ch * (size_t)nvox + i] = g;
+                } else {
+                    float p = f0;
+                    if (adam) {
+                        const float m0 = cur.m[ch], v0 = cur.v[ch];
+                        const float mi = m0 + (g - m0) * (1.0f - oc.beta1);
+                        const float vi = oc.beta2 * v0 + (1.0f - oc.beta2) * g * g;
+                        am[ch * (size_t)nvox + i] = mi; av[ch * (size_t)nvox + i] = vi;
+                        const float denom = sqrtf(vi) * c.inv_sqrt_bc2 + oc.eps;
+                        p = p - c.step_size * (mi / denom);
+                    } else {
+                        p = p - c.step_size * g;
+                    }
+                    fo[ch * (size_t)nvox + i] = p;
+                    if (fkeep) fkeep[ch * (size_t)nvox + i] = f0;
+                    if constexpr (NEXT) pnew[ch] = p;
+                }
+            }
+            if constexpr (NEXT) {
+                // The sample at the flow this trip has just written (the next iteration's moments) is the one gather whose address no
+                // earlier trip knows: its corners are requested here and folded in ONE TRIP LATER - same values, same order of sums.
+                if (z > cw.z0) fold_next(g2, y2);
+                g2 = corners_at(pnew, z);
+                y2 = yv;
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) { fm[ch] = fc[ch]; fc[ch] = fn[ch]; }
+            tc = tn;
+            cur = nxt;
+            if (z + 1 < cw.z1) gc = corners_at(fc, z + 1);   // fc: the flow of plane z + 1, requested at the top of this trip
+        }
+        if constexpr (NEXT) fold_next(g2, y2);
+    }
+    if constexpr (NEXT) block_reduce_store<kFlowNP, 8>(nv, next_partials + ((size_t)b * gridDim.x + blockIdx.x) * kFlowNP);
+}
+
 template <int ND>
 __global__ __launch_bounds__(TRX_BLOCK) void flow_warp_kernel(trx_volumes vol, const float *__restrict__ flow, int channels,
                                                               float *__restrict__ out)
@@ -530,6 +817,7 @@ static int check_vol_flow(const trx_volumes *v, bool need_target)
 
 static unsigned flow_grid_x(const trx_volumes &v)
 {
+    if (v.ndim == 3) return (unsigned)flow_col_geom(v).nblk;   // the column-walk kernels
     const size_t nvox = (size_t)v.D * v.H * v.W;
     size_t nb = (nvox + TRX_BLOCK - 1) / TRX_BLOCK;
     const size_t total = 4096;             // blocks in flight overall (measured sweep: 2048 .. 8192 within 2 %)
@@ -568,8 +856,9 @@ static int launch_moments(const trx_volumes *vol, const float *flow, bool smooth
     if (slab.Dm < 0) slab.Dm = vol->D;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
     if (vol->ndim == 3) {
-        if (smooth) hipLaunchKernelGGL((flow_moments_kernel<3, true>), grid, block, 0, s, *vol, flow, partials, slab);
-        else hipLaunchKernelGGL((flow_moments_kernel<3, false>), grid, block, 0, s, *vol, flow, partials, slab);
+        const ColGeom cg = flow_col_geom(*vol);
+        if (smooth) hipLaunchKernelGGL((flow_moments3_kernel<true>), grid, block, 0, s, *vol, flow, partials, slab, cg);
+        else hipLaunchKernelGGL((flow_moments3_kernel<false>), grid, block, 0, s, *vol, flow, partials, slab, cg);
     } else {
         if (smooth) hipLaunchKernelGGL((flow_moments_kernel<2, true>), grid, block, 0, s, *vol, flow, partials, slab);
         else hipLaunchKernelGGL((flow_moments_kernel<2, false>), grid, block, 0, s, *vol, flow, partials, slab);
@@ -586,30 +875,37 @@ static int launch_update(const trx_volumes *vol, const float *flow, float *flow_
     if (slab.Dm < 0) slab.Dm = vol->D;
     dim3 grid(flow_grid_x(*vol), vol->B), block(TRX_BLOCK);
 #define TRX_LAUNCH_UPD(...) hipLaunchKernelGGL((flow_update_kernel<__VA_ARGS__>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, next_partials, flow_last, save_last)
+#define TRX_LAUNCH_UPD3(...) hipLaunchKernelGGL((flow_update3_kernel<__VA_ARGS__>), grid, block, 0, s, *vol, flow, flow_out, m, v, coef, oc, slab, cg, next_partials, flow_last, save_last)
+    if (vol->ndim == 3) {   // column-walk kernels
+        const ColGeom cg = flow_col_geom(*vol);
+        const bool adam = (MODE == 0) && oc.kind == TRX_OPT_ADAM;
+        if constexpr (MODE == 0) {
+            if (next_partials) {   // the update + the next iteration's pass A in one kernel
+                if (smooth) { if (adam) TRX_LAUNCH_UPD3(0, true, true, true); else TRX_LAUNCH_UPD3(0, true, true, false); }
+                else { if (adam) TRX_LAUNCH_UPD3(0, false, true, true); else TRX_LAUNCH_UPD3(0, false, true, false); }
+                TRX_CHECK_LAUNCH();
+                return TRX_OK;
+            }
+            if (smooth) { if (adam) TRX_LAUNCH_UPD3(0, true, false, true); else TRX_LAUNCH_UPD3(0, true, false, false); }
+            else { if (adam) TRX_LAUNCH_UPD3(0, false, false, true); else TRX_LAUNCH_UPD3(0, false, false, false); }
+        } else {
+            if (smooth) TRX_LAUNCH_UPD3(MODE, true, false, false);
+            else TRX_LAUNCH_UPD3(MODE, false, false, false);
+        }
+        TRX_CHECK_LAUNCH();
+        return TRX_OK;
+    }
     if constexpr (MODE == 0) {
-        if (next_partials && smooth) {
-            if (vol->ndim == 2) TRX_LAUNCH_UPD(2, 0, true, false, true);
-            else TRX_LAUNCH_UPD(3, 0, true, false, true);
-            TRX_CHECK_LAUNCH();
-            return TRX_OK;
-        }
-        if (next_partials && !smooth) {   // the update + the next iteration's pass A in one kernel
-            if (vol->ndim == 2) TRX_LAUNCH_UPD(2, 0, false, false, true);
-            else if (oc.kind != TRX_OPT_ADAM) TRX_LAUNCH_UPD(3, 0, false, true, true);
-            else TRX_LAUNCH_UPD(3, 0, false, false, true);
+        if (next_partials) {
+            if (smooth) TRX_LAUNCH_UPD(2, 0, true, false, true);
+            else TRX_LAUNCH_UPD(2, 0, false, false, true);
             TRX_CHECK_LAUNCH();
             return TRX_OK;
         }
     }
-    if (vol->ndim == 3) {
-        const bool pipe = (MODE == 0) && !smooth && oc.kind != TRX_OPT_ADAM;
-        if (smooth) TRX_LAUNCH_UPD(3, MODE, true);
-        else if (pipe) TRX_LAUNCH_UPD(3, MODE, false, true);
-        else TRX_LAUNCH_UPD(3, MODE, false);
-    } else {
-        if (smooth) TRX_LAUNCH_UPD(2, MODE, true);
-        else TRX_LAUNCH_UPD(2, MODE, false);
-    }
+    if (smooth) TRX_LAUNCH_UPD(2, MODE, true);
+    else TRX_LAUNCH_UPD(2, MODE, false);
+#undef TRX_LAUNCH_UPD3
 #undef TRX_LAUNCH_UPD
     TRX_CHECK_LAUNCH();
     return TRX_OK;
