@@ -244,6 +244,17 @@ size_t trx_lncc_workspace_bytes(int ndim, int B, int D, int H, int W);
 int trx_lncc_loss_grad(const float *target, const float *warped, int ndim, int B, int D, int H, int W, int window, float alpha,
                        float eps, float *loss, float *grad, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Direct flow field + LOCAL-window NCC (+ smoothness regulariser st->smooth_weight) as one device-side loop: `iters` iterations of
+ *   warp at the current flow -> window sums, loss, dL/dwarped (the kernels behind trx_lncc_loss_grad) -> loss curve / early stop / optimiser
+ *   scalars -> dL/dflow through the trilinear derivative + smoothness gradient + SGD / Adam in place
+ * with no autograd, no torch optimiser and no host sync (3-D only; 2-D callers compose trx_flow_warp / trx_lncc_loss_grad /
+ * trx_flow_warp_backward).  Recorded loss of pair b: lncc_alpha * (1 - mean cc) + smooth_weight / ndim * sum_d mean (forward difference)^2,
+ * both of the flow the iteration STARTS from.  State, early stop and flow_last as for trx_flow_run.  vol->target: dense [B][D][H][W].
+ * Extension (the reference has neither a local NCC nor a direct flow mode): arbiter = oracle/compose.py under torch autograd. */
+size_t trx_flow_lncc_workspace_bytes(const trx_volumes *vol);
+int trx_flow_lncc_run(const trx_volumes *vol, int window, float lncc_alpha, float lncc_eps, const trx_opt_cfg *opt,
+                      const trx_flow_state *st, int iters, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- Parzen-window PDF of the reference's NMI loss (ref:utils.py:18-37 K_gauss / PDF_xis / PDF).
  * signals [N][S], xis [N][bins] (bins <= 1024), h > 0:
  *   pdf[n][k] = (1/h) * mean_i K((signals[n][i] - xis[n][k]) / h),  K(u) = exp(-u*u/2) / (2 pi)   (the reference's constant)

@@ -124,3 +124,64 @@ def test_lncc_full_size_properties(eng):
     l2, g2 = eng.local_ncc_loss_grad(tgt, wrp, 9, 1.0)
     assert torch.equal(l1, l2) and torch.equal(g1, g2)
     assert 0.0 <= l1.item() <= 1.0 and torch.isfinite(g1).all()
+
+
+# ----------------------------------------------------------------------------- round 3: the local-NCC loop on the device
+def _torch_lncc_flow_loop(mov, tgt, lr, iters, optimizer, smooth, window, flow0, dtype):
+    """arbiter: oracle/compose.py (local_ncc_loss, flow_warp, smooth_regulariser) under torch autograd + torch.optim, on the CPU"""
+    from oracle import compose
+    mov, tgt = mov.to(dtype), tgt.to(dtype)
+    fl = flow0.to(dtype).clone().requires_grad_()
+    opt = torch.optim.SGD([fl], lr) if optimizer == "sgd" else torch.optim.Adam([fl], lr)
+    losses = []
+    for _ in range(iters):
+        opt.zero_grad()
+        e = compose.local_ncc_loss(tgt, compose.flow_warp(mov, fl), window=window)
+        if smooth:
+            e = e + compose.smooth_regulariser(fl, smooth)
+        e.backward()
+        opt.step()
+        losses.append(e.item())
+    return np.asarray(losses), fl.detach().numpy()
+
+
+@pytest.mark.parametrize("optimizer,lr,smooth,window", [("sgd", 30.0, 0.0, 5), ("adam", 0.05, 2.0, 9), ("adam", 0.05, 0.0, 7), ("sgd", 20.0, 3.0, 9)])
+def test_lncc_flow_loop_vs_torch_autograd(optimizer, lr, smooth, window):
+    """trx_flow_lncc_run (warp -> window sums -> gradient -> smoothness -> SGD / Adam, all on the device) against the same objective
+    under torch autograd in fp64; bar = max(floor, 2 x the arbiter's own fp32-vs-fp64 gap).  Starts off the voxel lattice."""
+    import torchregister_amd._engine as eng
+    from conftest import bar
+    shape, iters = (20, 24, 28), 12
+    tgt = ph.blobs(shape, 61) + 0.05 * ph.vol(shape, 0.031, "sin")
+    mov = ph.blobs(shape, 62) + 0.05 * ph.vol(shape, 0.027, "cos")
+    ax = [torch.arange(n, dtype=torch.float64) for n in shape]
+    comp = lambda a, b, c: (torch.sin(a * ax[0])[:, None, None] + torch.cos(b * ax[1])[None, :, None] + torch.sin(c * ax[2] + 0.4)[None, None, :])  # noqa: E731
+    f0 = torch.stack([0.4 * comp(0.21, 0.17, 0.13), 0.3 * comp(0.11, 0.23, 0.19), 0.35 * comp(0.15, 0.12, 0.27)]).float()[None] + 0.17
+    l32, f32 = _torch_lncc_flow_loop(mov, tgt, lr, iters, optimizer, smooth, window, f0, torch.float32)
+    l64, f64 = _torch_lncc_flow_loop(mov, tgt, lr, iters, optimizer, smooth, window, f0, torch.float64)
+    s = eng.FlowSolver(mov.cuda(), tgt.cuda(), optimizer=optimizer, lr=lr, init=f0, capacity=iters, smooth_weight=smooth, lncc=dict(window=window))
+    s.run(iters)
+    torch.cuda.synchronize()
+    e, b = np.max(np.abs(s.losses[0].cpu().numpy() - l64)), bar(l32, l64, 2e-5 * np.max(np.abs(l64)))
+    assert e <= b, ("loss curve", e, b)
+    e, b = np.max(np.abs(s.flow.cpu().numpy() - f64)), bar(f32, f64, 2e-4)
+    assert e <= b, ("flow", e, b)
+    assert l64[-1] < l64[0]
+
+
+def test_lncc_flow_loop_through_flow_register_and_batch_independence():
+    """flow_register(flow_model='direct', criterions=[LocalNCCLoss]) takes the device-side loop (no torch optimiser): same result as the
+    solver, and the pairs of a batch are independent registrations (pair 1 of a batch == the same pair alone, bit for bit)."""
+    import torchregister_amd as tr
+    shape, iters = (16, 24, 32), 6
+    tgt = torch.cat([ph.blobs(shape, 71), ph.blobs(shape, 72)]).cuda()
+    mov = torch.cat([ph.blobs(shape, 73), ph.blobs(shape, 74)]).cuda()
+    reg = tr.flow_register(shape, criterions=[tr.LocalNCCLoss(window=5, alpha=2.0)], weights=[0.5], lr=0.05, max_epochs=iters, stop_crit=-1.0,
+                           flow_model="direct", optimizer="adam", smooth_weight=1.0)
+    reg.optimize(mov, tgt, debug=False)
+    assert reg.solver.lncc == (5, 1.0, 1e-5) and reg.losses.shape == (2, iters)
+    solo = tr.FlowSolver(mov[1:], tgt[1:], optimizer="adam", lr=0.05, capacity=iters, smooth_weight=1.0, lncc=dict(window=5, alpha=1.0))
+    solo.run(iters)
+    torch.cuda.synchronize()
+    assert torch.equal(reg.final_flow[1], solo.flow[0]) and torch.equal(reg.losses[1], solo.losses[0, :iters])
+    assert torch.isfinite(reg.losses).all() and (reg.losses[:, -1] < reg.losses[:, 0]).all()

@@ -268,10 +268,12 @@ class FlowSolver:
     """Direct dense flow-field optimisation (the flow itself is the parameter), batched."""
 
     def __init__(self, moving, target, loss=None, optimizer="sgd", lr=1e-3, init=None, capacity=1000, smooth_weight=0.0,
-                 betas=(0.9, 0.999), eps=1e-8, stop_crit=None, keep_last=False, flags=0):
+                 betas=(0.9, 0.999), eps=1e-8, stop_crit=None, keep_last=False, flags=0, lncc=None):
         """stop_crit: the reference's early stop (ref:warpings.py:231-233), tested on the device per pair - a pair whose recorded loss
         is <= stop_crit keeps that iteration's update and ignores every later iteration; `step[b]` = number of recorded losses.
-        keep_last: also keep `flow_last`, the flow of the last forward (what the reference's flow_register.flow holds)."""
+        keep_last: also keep `flow_last`, the flow of the last forward (what the reference's flow_register.flow holds).
+        lncc: dict(window=9, alpha=1.0, eps=1e-5) - the data term is the LOCAL-window NCC (extension) instead of `loss`: the whole loop
+        (warp, window sums, gradient, smoothness, SGD / Adam) runs in trx_flow_lncc_run, 3-D only."""
         self.lib = _lib.load()
         self.batch = _Batch(moving, target, tables=False, flags=flags)
         if self.batch.C != 1:
@@ -291,7 +293,16 @@ class FlowSolver:
         self.losses = torch.full((b, self.capacity), float("nan"), device=dev)
         self.step = torch.zeros(b, dtype=torch.int32, device=dev)
         self.vol = self.batch.vol()
-        self.ws_bytes = self.lib.trx_flow_workspace_bytes(ctypes.byref(self.vol))
+        self.lncc = None
+        if lncc is not None:
+            if nd != 3:
+                raise ValueError("the fused local-NCC loop is 3-D only (2-D: LocalNCCLoss through the generic autograd path)")
+            self.lncc = (int(lncc.get("window", 9)), float(lncc.get("alpha", 1.0)), float(lncc.get("eps", 1e-5)))
+            self.ws_bytes = self.lib.trx_flow_lncc_workspace_bytes(ctypes.byref(self.vol))
+        else:
+            self.ws_bytes = self.lib.trx_flow_workspace_bytes(ctypes.byref(self.vol))
+        if self.ws_bytes == 0:
+            raise _lib.TrxError("the flow workspace query rejected the batch geometry")
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         st = _lib.FlowState()
         st.flow = self.flow.data_ptr()
@@ -315,6 +326,12 @@ class FlowSolver:
                                 f"{self.capacity} (create the solver with a larger `capacity`)")
         self.enqueued += iters
         with torch.cuda.device(self.batch.device):
+            if self.lncc is not None:
+                rc = self.lib.trx_flow_lncc_run(ctypes.byref(self.vol), self.lncc[0], self.lncc[1], self.lncc[2], ctypes.byref(self.opt),
+                                                ctypes.byref(self.state), int(iters), _lib.ptr(self.workspace), self.ws_bytes,
+                                                _lib.current_stream(self.batch.device))
+                _lib.check(rc, "trx_flow_lncc_run")
+                return
             rc = self.lib.trx_flow_run(ctypes.byref(self.vol), ctypes.byref(self.loss_c), ctypes.byref(self.opt),
                                        ctypes.byref(self.state), int(iters), _lib.ptr(self.workspace), self.ws_bytes,
                                        _lib.current_stream(self.batch.device))

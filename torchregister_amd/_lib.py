@@ -105,6 +105,9 @@ SIGNATURES = {
                                              ctypes.c_int, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_nmi_loop_update": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _P, ctypes.c_float, _P, ctypes.c_int, _P, _P, _P, _P, _P]),
     "trx_nmi_from_pdfs": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "trx_flow_lncc_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Volumes)]),
+    "trx_flow_lncc_run": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.POINTER(OptCfg),
+                                         ctypes.POINTER(FlowState), ctypes.c_int, _P, ctypes.c_size_t, _P]),
     "trx_lncc_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "trx_lncc_loss_grad": (ctypes.c_int, [_P, _P] + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_float, _P, _P, _P, ctypes.c_size_t, _P]),
 }

@@ -144,8 +144,12 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
                                                          float *__restrict__ terms, FlowCoef *__restrict__ coef,
                                                          double *__restrict__ mom_out, const double *__restrict__ mom_in, int D_full,
                                                          int lag = 0, double *__restrict__ stash = nullptr, float stop_crit = 0.f,
-                                                         int *__restrict__ stopped = nullptr, int double_buffered = 0)
+                                                         int *__restrict__ stopped = nullptr, int double_buffered = 0,
+                                                         const float *__restrict__ ext_loss = nullptr)
 {
+    // ext_loss != NULL (the local-NCC loop, trx_flow_lncc_run): the data term of pair b is ext_loss[b] - a criterion evaluated by other
+    // kernels, whose dL/dwarped the update reads from a buffer - instead of the closed forms of the five global moments; the smoothness
+    // term, the optimiser scalars, the loss curve and the early stop are handled as for them.
     // lag (fused steps with the smoothness term, trx_flow_run): the data moments S[0..4] describe THIS iteration's flow, the
     // smoothness sums S[5..7] the PREVIOUS one (they are collected by the update kernel, which is where the neighbours of a flow are
     // read).  The gradient step needs only the former; the recorded loss of iteration t - 1 gets its regulariser term one
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(1024) void flow_coef_kernel(const float *__restrict
     const double sd = sqrt(Saa * Sbb + 1e-10);
     const double alpha = lc.ncc_alpha, sq = Syy - 2.0 * Syw + Sww;
     const double mse = sq / n, ncc = alpha * (1.0 - Sab / sd), ssd = (double)lc.ssd_alpha * sq;
-    double total = (double)lc.w_mse * mse + (double)lc.w_ncc * ncc + (double)lc.w_ssd * ssd;
+    double total = ext_loss ? (double)ext_loss[b] : (double)lc.w_mse * mse + (double)lc.w_ncc * ncc + (double)lc.w_ssd * ssd;
     // smoothness (extension): lambda/ndim * sum_d mean_{c,p}(forward difference along d)^2
     const int ext[3] = {ndim == 3 ? D : H, ndim == 3 ? H : W, W};
     FlowCoef c;
@@ -476,7 +480,7 @@ struct ColWalk {
 
 template <bool SMOOTH>
 __global__ __launch_bounds__(TRX_BLOCK) void flow_moments3_kernel(trx_volumes vol, const float *__restrict__ flow, float *__restrict__ partials, Slab slab,
-                                                                  ColGeom cg)
+                                                                  ColGeom cg, float *__restrict__ warped_out = nullptr)
 {
     const int b = blockIdx.y;
     const int D = vol.D, H = vol.H, W = vol.W;
@@ -498,6 +502,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_moments3_kernel(trx_volumes vo
             const float tn = tgt[in];
             float d[3];
             const float w = flow_sample_v<3>(mov, fc, slab.Dm, H, W, z + slab.zoff, y, x, d);
+            if (warped_out) warped_out[(size_t)b * nvox + i] = w;   // (the local-NCC loop: this pass is also its forward warp)
             const float yv = tc;
             vals[0] += yv; vals[1] += w;
             vals[2] = fmaf(yv, yv, vals[2]); vals[3] = fmaf(w, w, vals[3]); vals[4] = fmaf(yv, w, vals[4]);
@@ -531,20 +536,23 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_moments3_kernel(trx_volumes vo
 template <int MODE, bool SMOOTH, bool NEXT, bool ADAM>
 __global__ __launch_bounds__(TRX_BLOCK, SMOOTH ? 4 : 5) void flow_update3_kernel(trx_volumes vol, const float *flow, float *flow_out, float *__restrict__ adam_m,
                                                                  float *__restrict__ adam_v, const FlowCoef *__restrict__ coef, trx_opt_cfg oc, Slab slab,
-                                                                 ColGeom cg, float *__restrict__ next_partials, float *__restrict__ flow_last, int save_last)
+                                                                 ColGeom cg, float *__restrict__ next_partials, float *__restrict__ flow_last, int save_last,
+                                                                 const float *__restrict__ go_buf = nullptr)
 {
+    // MODE 2 (the local-NCC loop): the optimiser update of MODE 0 with dL/dwarped of every voxel read from go_buf [B][D][H][W]
+    // instead of the closed form k1 (y - my) + k2 (w - mw) + q (w - y) of the global losses
     static_assert(!NEXT || MODE == 0, "the fused next-iteration moments ride on the update");
     float nv[kFlowNP] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int b = blockIdx.y;
     const int D = vol.D, H = vol.H, W = vol.W;
     const unsigned HW = (unsigned)(H * W), nvox = (unsigned)D * HW;
     const float *__restrict__ mov = vol.moving + (size_t)b * vol.moving_stride;
-    const float *__restrict__ tgt = vol.target + (size_t)b * vol.target_stride;
+    const float *__restrict__ tgt = (MODE == 2) ? go_buf + (size_t)b * nvox : vol.target + (size_t)b * vol.target_stride;
     const float *fl = flow + (size_t)b * 3 * nvox;   // may alias fo (in-place update without the regulariser): no restrict
     float *fo = flow_out + (size_t)b * 3 * nvox;
     const FlowCoef c = coef[b];
     float *__restrict__ fkeep = nullptr;   // != nullptr: this update also keeps the flow it starts from (the flow of the last forward)
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 0 || MODE == 2) {
         if (c.mode >= kUpdCopy) {          // a pair that has stopped early (block-uniform): settle the buffers, no arithmetic
             if (c.mode != kUpdSkip && fo != fl) {
                 float *__restrict__ keep = (c.mode == kUpdTransition && flow_last) ? flow_last + (size_t)b * 3 * nvox : nullptr;
@@ -616,7 +624,7 @@ __global__ __launch_bounds__(TRX_BLOCK, SMOOTH ? 4 : 5) void flow_update3_kernel
             float d[3];
             const float w = lerp_corners3(gc, d);
             const float yv = tc;
-            const float go = fmaf(c.k1, yv - c.my, fmaf(c.k2, w - c.mw, c.q * (w - yv)));
+            const float go = (MODE == 2) ? tc : fmaf(c.k1, yv - c.my, fmaf(c.k2, w - c.mw, c.q * (w - yv)));   // MODE 2: `tgt` IS go_buf (see below)
             float pnew[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
@@ -977,6 +985,82 @@ extern "C" int trx_flow_run(const trx_volumes *vol, const trx_loss_cfg *loss, co
     if (cur != st->flow) {  // odd number of double-buffered steps: result lives in flow_tmp
         const size_t bytes = (size_t)vol->B * vol->ndim * vol->D * vol->H * vol->W * sizeof(float);
         if (hipMemcpyAsync(st->flow, cur, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return TRX_ERR_HIP;
+    }
+    return TRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Direct flow + LOCAL-window NCC (+ smoothness) as one loop on the device (extension, SURVEY 8f.3: the VoxelMorph-style objective;
+// definition and arbiter: oracle/compose.py::local_ncc_loss + smooth_regulariser under torch autograd).  Per iteration:
+//   flow_moments3_kernel   warp at the current flow (written to the workspace) + the smoothness sums of that flow
+//   trx_lncc_loss_grad     window sums -> loss[b], dL/dwarped (csrc/lncc.hip: fields, finalise, gradient)
+//   flow_coef_kernel       total loss -> loss curve, step counter, early stop, Adam scalars, smoothness scales
+//   flow_update3_kernel<2> dL/dflow = dL/dwarped * (trilinear derivative) + smoothness gradient; SGD / Adam in place
+// No autograd, no host sync, no torch optimiser.
+// ---------------------------------------------------------------------------------------------------
+static size_t lncc_loop_offsets(const trx_volumes *vol, size_t *o_warped, size_t *o_go, size_t *o_loss, size_t *o_lncc)
+{
+    const size_t nvox = (size_t)vol->D * vol->H * vol->W;
+    size_t off = (trx_flow_workspace_bytes(vol) + 255) & ~(size_t)255;
+    *o_warped = off; off += ((size_t)vol->B * nvox * sizeof(float) + 255) & ~(size_t)255;
+    *o_go = off;     off += ((size_t)vol->B * nvox * sizeof(float) + 255) & ~(size_t)255;
+    *o_loss = off;   off += ((size_t)vol->B * sizeof(float) + 255) & ~(size_t)255;
+    *o_lncc = off;   off += trx_lncc_workspace_bytes(vol->ndim, vol->B, vol->D, vol->H, vol->W);
+    return off;
+}
+
+extern "C" size_t trx_flow_lncc_workspace_bytes(const trx_volumes *vol)
+{
+    if (check_vol_flow(vol, false) != TRX_OK || vol->ndim != 3) return 0;
+    size_t a, b, c, d;
+    return lncc_loop_offsets(vol, &a, &b, &c, &d);
+}
+
+extern "C" int trx_flow_lncc_run(const trx_volumes *vol, int window, float lncc_alpha, float lncc_eps, const trx_opt_cfg *opt, const trx_flow_state *st,
+                                 int iters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const trx_loss_cfg none = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int rc = check_flow_args(vol, &none, opt, st, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (vol->ndim != 3) return TRX_ERR_NDIM;
+    const size_t nvox = (size_t)vol->D * vol->H * vol->W;
+    if (iters < 0 || (window != 3 && window != 5 && window != 7 && window != 9)) return TRX_ERR_ARG;
+    if (vol->B > 1 && vol->target_stride != nvox) return TRX_ERR_ARG;   // the window kernels take a dense [B][D][H][W] target
+    if (workspace_bytes < trx_flow_lncc_workspace_bytes(vol)) return TRX_ERR_WORKSPACE;
+    if (st->losses && iters > st->losses_capacity) return TRX_ERR_CAPACITY;
+    hipStream_t s = (hipStream_t)stream;
+    size_t o_warped, o_go, o_loss, o_lncc;
+    lncc_loop_offsets(vol, &o_warped, &o_go, &o_loss, &o_lncc);
+    char *ws = (char *)workspace;
+    float *partials = (float *)workspace, *warped = (float *)(ws + o_warped), *go = (float *)(ws + o_go), *lloss = (float *)(ws + o_loss);
+    const size_t lncc_bytes = trx_lncc_workspace_bytes(3, vol->B, vol->D, vol->H, vol->W);
+    FlowCoef *coef = coef_ptr(vol, workspace);
+    const bool smooth = st->smooth_weight != 0.f, adam = opt->kind == TRX_OPT_ADAM;
+    float *cur = st->flow, *nxt = smooth ? st->flow_tmp : st->flow;
+    const ColGeom cg = flow_col_geom(*vol);
+    const Slab slab = {0, vol->D, nullptr, nullptr};
+    dim3 grid(cg.nblk, vol->B), block(TRX_BLOCK);
+    for (int i = 0; i < iters; i++) {
+        if (smooth) hipLaunchKernelGGL((flow_moments3_kernel<true>), grid, block, 0, s, *vol, cur, partials, slab, cg, warped);
+        else hipLaunchKernelGGL((flow_moments3_kernel<false>), grid, block, 0, s, *vol, cur, partials, slab, cg, warped);
+        TRX_CHECK_LAUNCH();
+        rc = trx_lncc_loss_grad(vol->target, warped, 3, vol->B, vol->D, vol->H, vol->W, window, lncc_alpha, lncc_eps, lloss, go, ws + o_lncc, lncc_bytes, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(flow_coef_kernel, dim3(vol->B), dim3(1024), 0, s, partials, cg.nblk, 3, vol->D, vol->H, vol->W, none, *opt, st->smooth_weight,
+                           st->losses, st->losses_capacity, st->step, (float *)nullptr, coef, (double *)nullptr, (const double *)nullptr, vol->D, 0,
+                           stash_ptr(vol, workspace), st->stop_crit, st->stopped, (int)(cur != nxt), lloss);
+        TRX_CHECK_LAUNCH();
+        const int save_last = (i + 1 == iters) ? 1 : 0;
+#define TRX_LAUNCH_L(SM, AD) hipLaunchKernelGGL((flow_update3_kernel<2, SM, false, AD>), grid, block, 0, s, *vol, cur, nxt, st->adam_m, st->adam_v, coef, *opt, slab, cg, \
+                                                (float *)nullptr, st->flow_last, save_last, go)
+        if (smooth) { if (adam) TRX_LAUNCH_L(true, true); else TRX_LAUNCH_L(true, false); }
+        else { if (adam) TRX_LAUNCH_L(false, true); else TRX_LAUNCH_L(false, false); }
+#undef TRX_LAUNCH_L
+        TRX_CHECK_LAUNCH();
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    if (cur != st->flow) {  // odd number of double-buffered steps: result lives in flow_tmp
+        if (hipMemcpyAsync(st->flow, cur, (size_t)vol->B * 3 * nvox * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return TRX_ERR_HIP;
     }
     return TRX_OK;
 }

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from . import _engine
 from ._engine import AffineSolver, FlowSolver, LossSpec
-from .utils import NCCLoss, NMILoss, SSDLoss, SpatialTransformer  # noqa: F401
+from .utils import LocalNCCLoss, NCCLoss, NMILoss, SSDLoss, SpatialTransformer  # noqa: F401
 
 
 class _AffineWarpFn(torch.autograd.Function):
@@ -411,13 +411,19 @@ class flow_register(nn.Module):
                 with torch.backends.cudnn.flags(enabled=True, benchmark=True):
                     return self._optimize_unet(moving, target, spec, debug)
             return self._optimize_unet(moving, target, spec, debug)
-        if spec is None:
+        lncc = None
+        if spec is None and moving.dim() == 5 and len(self.criterions) == 1 and isinstance(self.criterions[0], LocalNCCLoss):
+            # direct flow + local-window NCC (+ smoothness): the VoxelMorph-style objective as ONE device-side loop (trx_flow_lncc_run) -
+            # no autograd, no torch optimiser; a batch is B independent registrations as on the fused global-loss path below
+            c0 = self.criterions[0]
+            lncc = dict(window=c0.window, alpha=c0.alpha * float(self.weights[0]), eps=c0.eps)
+        if spec is None and lncc is None:
             return self._optimize_generic(moving, target, debug)
         # The whole loop is ONE call: the early stop of ref:warpings.py:231-233 is tested on the device after every iteration (per
         # pair: a batch is B independent registrations), a pair that has converged ignores the remaining iterations, and the flow
         # of its last forward is kept beside the final one - exactly the state the reference leaves behind, with one host sync.
         solver = FlowSolver(moving, target, loss=spec, optimizer=self.optimizer_kind, lr=self.lr, capacity=max(1, self.max_epochs),
-                            smooth_weight=self.smooth_weight, stop_crit=self.stop_crit, keep_last=True)
+                            smooth_weight=self.smooth_weight, stop_crit=self.stop_crit, keep_last=True, lncc=lncc)
         solver.run(self.max_epochs)
         done = solver.step.cpu()                       # iterations executed per pair (the only host sync)
         n = int(done.max()) if self.max_epochs > 0 else 0
