@@ -329,14 +329,15 @@ def test_rotated_deep_tile_vs_oracle(eng, shape, tname, loss):
     assert np.max(np.abs(grad - dth)) <= bar, (grad, dth, bar)
 
 
-def test_rotated_deep_tile_is_the_default_from_96_cubed(eng):
-    """At 96^3 (216 tiles of 16^3 >= 128) GeomRD is offered without any flag: the default run equals the flagged run bit for bit and
-    differs from the GeomR run (fp32 summation order) while agreeing with it to 2e-6."""
+def test_rotated_deep_tile_is_the_default_from_1024_tiles(eng):
+    """From 1024 tiles of 16^3 per launch (five pairs of 96^3: 216 tiles each, every volume >= 128 tiles) GeomRD is offered without any
+    flag: the default run equals the flagged run bit for bit and differs from the GeomR run (fp32 summation order) while agreeing with
+    it to 2e-6.  (Smaller launches run the two-body kernel: their steps are launch-bound, see launch_dual.)"""
     from torchregister_amd import _lib
     shape = (96, 96, 96)
-    tgt = ph.blobs(shape, 77).cuda()
-    mov = (ph.blobs(shape, 78) + 0.1 * ph.vol(shape, 0.013, "sin")).cuda()
-    th = torch.tensor(generic(ROT_DEEP_THETAS["rot_z_0.5"]), dtype=torch.float32)[None]
+    tgt = ph.blobs(shape, 77).cuda().repeat(5, 1, 1, 1, 1)
+    mov = (ph.blobs(shape, 78) + 0.1 * ph.vol(shape, 0.013, "sin")).cuda().repeat(5, 1, 1, 1, 1)
+    th = torch.tensor(generic(ROT_DEEP_THETAS["rot_z_0.5"]), dtype=torch.float32)[None].repeat(5, 1, 1)
     runs = {}
     for flags in (0, _lib.FLAG_DEEP_TILE, _lib.FLAG_NO_ROT_DEEP_TILE):
         s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=0.0, init=th, capacity=1, flags=flags)

@@ -435,6 +435,6 @@ __global__ __launch_bounds__(StreamCfg::Threads, 4) void affine_stream_kernel(tr
                 vals[o++] = xn * a; vals[o++] = acc.AB[q][c].y; vals[o++] = zn * a; vals[o++] = a;
             }
     }
-    block_reduce_store_nw<NP41, C::Waves>(vals, partials + ((size_t)b * rows_per_pair + bx) * NP41, box);
+    block_reduce_store_nw<NP41, C::Waves>(vals, partials + ((size_t)b * rows_per_pair + bx) * NP41, box, wave);
 }
 #pragma clang diagnostic pop

@@ -368,14 +368,20 @@ __device__ __forceinline__ void f1_accumulate_pk(const Samp3 &sm, float yv, floa
 
 constexpr int kTileThreads = GeomP::Threads;   // block size of the primary kernel (the dual kernel: 512)
 
+// Work-item id of a 1-D block WITHOUT keeping v0 (the packed ids the hardware delivers) alive: lane id from v_mbcnt, wave index read once
+// at kernel entry into an SGPR (trx_wave_index).  With five bodies inlined behind a dispatch the allocator spilled v0 to scratch at entry and
+// every body paid a memory round trip to get it back.
+__device__ __forceinline__ int trx_lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ int trx_wave_index() { return __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6); }
+
 template <int NV, int NW>
-__device__ __forceinline__ void block_reduce_store_nw(const float (&vals)[NV], float *__restrict__ out, float *smem)
+__device__ __forceinline__ void block_reduce_store_nw(const float (&vals)[NV], float *__restrict__ out, float *smem, int wave)
 {
-    // smem: >= NW*16*65 + NW*16 floats of scratch (aliases the tile box)
+    // smem: >= NW*16*65 + NW*16 floats of scratch (aliases the tile box); wave: this wave's index in the block (uniform)
     constexpr int CH = 16;
     float(*red)[CH][65] = reinterpret_cast<float(*)[CH][65]>(smem);
     float(*wsum)[CH] = reinterpret_cast<float(*)[CH]>(smem + NW * CH * 65);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = trx_lane_id(), tid = wave * 64 + lane;
 #pragma unroll
     for (int c0 = 0; c0 < NV; c0 += CH) {
 #pragma unroll
@@ -431,7 +437,7 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) { return __int_as
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 template <int MODE, class G>
 __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *__restrict__ theta, const TileGeom &tg, int channels,
-                                          float *__restrict__ partials, float *box, const int bx, const int by, const int rows_stride)
+                                          float *__restrict__ partials, float *box, const int bx, const int by, const int rows_stride, const int wave_in)
 {
     // geometry of this instantiation (bx, by: the block's index in the (blocks_per_pair, pairs x channels) grid)
     constexpr int kTX = G::TX, kTY = G::TY, kTZ = G::TZ, kBW = G::BW, kBH = G::BH, kBD = G::BD, kPP = G::PP, kBufs = G::Bufs;
@@ -456,8 +462,9 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
     float *__restrict__ wout = uni_ptr(partials + (size_t)by * D * H * W);
     const float *__restrict__ tgt = (MODE == 3) ? wout : uni_ptr(vol.target + (size_t)b * vol.target_stride + (MODE == 2 ? (size_t)ch * D * H * W : 0));
     const float *__restrict__ xtab = uni_ptr(vol.xn), *__restrict__ ytab = uni_ptr(vol.yn), *__restrict__ ztab = uni_ptr(vol.zn);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform (SGPR)
+    const int lane = trx_lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(wave_in);          // provably wave-uniform (SGPR)
+    const int tid = wave * 64 + lane;
     const int lx = tid & (kTX - 1), lz = (tid / kTX) & (kTZ - 1), lh = wave / (kTileWaves / kNH);
     const float fW = (float)W, fH = (float)H, fD = (float)D;
     const float hW = 0.5f * fW, hH = 0.5f * fH, hD = 0.5f * fD;
@@ -1103,7 +1110,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
             const float a = acc.AB[q][c].x;
             vals[o++] = xn * a; vals[o++] = acc.AB[q][c].y; vals[o++] = zn * a; vals[o++] = a;
         }
-    block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)by * rows_stride + bx) * NP, box);
+    block_reduce_store_nw<NP, kTileWaves>(vals, partials + ((size_t)by * rows_stride + bx) * NP, box, wave);
 }
 
 // The primary kernel: one geometry (GeomP) for every block.
@@ -1112,7 +1119,7 @@ __global__ __launch_bounds__(GeomP::Threads, TRX_TILE_MIN_WAVES) void affine_til
                                                                                           TileGeom tg, int channels, float *__restrict__ partials)
 {
     __shared__ __attribute__((aligned(16))) float box[GeomP::BoxAlloc + TRX_DEV_LDS_PAD];
-    tile_body<MODE, GeomP>(vol, theta, tg, channels, partials, box, blockIdx.x, blockIdx.y, gridDim.x);
+    tile_body<MODE, GeomP>(vol, theta, tg, channels, partials, box, blockIdx.x, blockIdx.y, gridDim.x, trx_wave_index());
 }
 
 #pragma clang diagnostic pop
@@ -1148,14 +1155,32 @@ __device__ __forceinline__ int dual_choice(const float *__restrict__ th, float f
 // The dual kernel: per pair, GeomA where its box holds the pre-image of a GeomA tile for this theta (decided from the
 // tile-independent maximum extent, the same bound the fast loop fetches), GeomR otherwise.  The grid is sized for the geometry
 // with more blocks; the surplus blocks of the other one write a zero partial row and leave.
-// WHICH = 0: both bodies in one kernel.  WHICH = 1 / 2: only the GeomA / GeomR body - the pair of launches (1 then 2) does the
+// WHICH = 0: every body in one kernel (3: only GeomA and GeomR, whatever the mode).  WHICH = 1 / 2: only the GeomA / GeomR body - the pair of launches (1 then 2) does the
 // same job with each body compiled on its own (measured alternative: bench.py 0.328 ms per step against 0.323 ms for the two-body
 // kernel and 0.311-0.320 ms for the single-geometry kernel): blocks of a pair that the other geometry owns leave at once.
+// The kernel arguments of affine_tile_dual_kernel as one struct: the kernel reads its arguments THROUGH THE KERNARG SEGMENT at the point
+// of use (a few scalar loads in front of the body that needs them) instead of through its parameters, which the compiler loads at entry
+// and keeps in SGPRs across the dispatch to five inlined bodies: that cost ~60 SGPRs, pushed the bodies' own scalars into VGPR lanes
+// and the work-item id into scratch, whose reload (a memory round trip in front of everything) made every launch 5-6 us longer -
+// 1 x 64^3: 15.5 -> 10 us per launch (tools/kbench.hip).  Field order and types = the parameter list (same layout rules).
+struct DualKArgs {
+    trx_volumes vol;
+    const float *theta;
+    TileGeom tgA, tgR;
+    int channels;
+    float *partials;
+    int zero_surplus;
+    TileGeom tgD, tgRD;
+    ZGeom zg;
+    int *rows_used;
+    int rows_stride;
+};
+
 template <int MODE, int WHICH = 0>
-__global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tgA,
-                                                                                   TileGeom tgR, int channels, float *__restrict__ partials,
-                                                                                   int zero_surplus = 1, TileGeom tgD = TileGeom{}, TileGeom tgRD = TileGeom{},
-                                                                                   ZGeom zg = ZGeom{}, int *__restrict__ rows_used = nullptr, int rows_stride = 0)
+__global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol_, const float *__restrict__ theta_, TileGeom tgA_,
+                                                                                   TileGeom tgR_, int channels_, float *__restrict__ partials_,
+                                                                                   int zero_surplus_ = 1, TileGeom tgD_ = TileGeom{}, TileGeom tgRD_ = TileGeom{},
+                                                                                   ZGeom zg_ = ZGeom{}, int *__restrict__ rows_used_ = nullptr, int rows_stride_ = 0)
 {
     static_assert(GeomA::Threads == 512 && GeomR::Threads == 512 && GeomD::Threads == 512 && GeomRD::Threads == 512, "every geometry runs 512-thread blocks");
     static_assert(GeomRD::BoxAlloc <= GeomR::BoxAlloc, "GeomRD lives in GeomR's box");
@@ -1167,13 +1192,29 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     __shared__ __attribute__((aligned(16))) float box[kAlloc];
     constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : (MODE == 4 ? kNpMse : 5));
-    const float fD = (float)vol.D, fH = (float)vol.H, fW = (float)vol.W;
-    const bool with_d = kDeep && tgD.blocks_per_pair > 0, with_rd = kDeep && tgRD.blocks_per_pair > 0;
-    const int zs_planes = kDeep && zg.blocks_per_pair > 0 ? zg.planes_per_seg : 0;
-    auto blocks_of = [&](int choice) {
-        return choice == 4 ? zg.blocks_per_pair
-                           : (choice == 0 ? tgD.blocks_per_pair : (choice == 3 ? tgRD.blocks_per_pair : (choice == 1 ? tgA.blocks_per_pair : tgR.blocks_per_pair)));
-    };   // (used before the item loop only)
+    // a fresh view of the arguments: the empty asm hides the pointer's identity, so loads through it stay where they are written
+    typedef const __attribute__((address_space(4))) DualKArgs *KArgs;
+    auto args = [&]() {
+        KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return p;
+    };
+    typedef const __attribute__((address_space(4))) TileGeom *KTile;
+    auto tile_of = [](KTile t) { return TileGeom{t->ntx, t->nty, t->ntz, t->ntiles, t->blocks_per_pair, t->ysplit, t->tiles_per_seg}; };   // (field by field: scalar loads)
+    float fD, fH, fW;
+    bool with_d, with_rd;
+    int zs_planes, rows_stride, nA, nR, nD, nRD, nZ;
+    const float *theta;
+    {
+        KArgs a = args();
+        fD = (float)a->vol.D; fH = (float)a->vol.H; fW = (float)a->vol.W;
+        nA = a->tgA.blocks_per_pair; nR = a->tgR.blocks_per_pair; nD = a->tgD.blocks_per_pair; nRD = a->tgRD.blocks_per_pair; nZ = a->zg.blocks_per_pair;
+        with_d = kDeep && nD > 0; with_rd = kDeep && nRD > 0;
+        zs_planes = kDeep && nZ > 0 ? a->zg.planes_per_seg : 0;
+        rows_stride = a->rows_stride;
+        theta = a->theta;
+    }
+    auto blocks_of = [&](int choice) { return choice == 4 ? nZ : (choice == 0 ? nD : (choice == 3 ? nRD : (choice == 1 ? nA : nR))); };
     // Work items of this block: (pair / slab `by`, block index v of that pair's geometry).  Classic grid: exactly one, from blockIdx.
     // FLAT grid (rows_stride > 0; the launcher's choice for big batches of the step kernels): gridDim.x persistent blocks share one list
     // of work items - pair 0's blocks, then pair 1's, ... each pair with the block count of the body ITS theta selects - and block p runs
@@ -1183,18 +1224,22 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     // then miss the L2 (GeomR: +28 %).  Pair-major items keep the dispatcher's order: all blocks on one pair, each XCD on its slab of
     // columns (block counts are multiples of 8, so item % 8 is the XCD of v as before).
     const bool flat = kDeep && rows_stride > 0;
-    const int lane = threadIdx.x & 63;
+    const int wave_idx = trx_wave_index();   // the only use of threadIdx in this kernel
+    const int lane = trx_lane_id();
+    const int tid_ = wave_idx * 64 + lane;
     // flat path: per pair (lane) the body its theta selects and the inclusive prefix sum of the block counts - kept in LDS, not in
     // registers, across the item loop (two more live VGPRs are two spilled ones in the bodies that sit at the register limit)
     __shared__ int s_choice[64], s_pre[64];
     int my_choice = 2, total = 1;
     if (flat) {
-        const int B = vol.B;
+        KArgs a = args();
+        const int B = a->vol.B;
+        int *rows_used = a->rows_used;
         int cnt = 0, ch = 2;
         if (lane < B) {
             ch = dual_choice(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, with_d, with_rd, zs_planes);
             cnt = blocks_of(ch);
-            if (rows_used && blockIdx.x == 0 && threadIdx.x < 64) rows_used[lane] = cnt;   // for the step's finalise kernel
+            if (rows_used && blockIdx.x == 0 && wave_idx == 0) rows_used[lane] = cnt;   // for the step's finalise kernel
         }
         int pre = cnt;   // inclusive prefix sum over the lanes (pairs)
 #pragma unroll
@@ -1203,9 +1248,11 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
             if (lane >= d) pre += t;
         }
         total = __builtin_amdgcn_readlane(pre, 63);
-        if (threadIdx.x < 64) { s_choice[lane] = ch; s_pre[lane] = pre; }
+        if (wave_idx == 0) { s_choice[lane] = ch; s_pre[lane] = pre; }
         __syncthreads();
     } else {
+        KArgs a = args();
+        const int channels = a->channels;
         const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
         my_choice = __builtin_amdgcn_readfirstlane(dual_choice(theta + (size_t)b * TRX_PSTRIDE, fD, fH, fW, with_d, with_rd, zs_planes));
         const bool useA = my_choice == 1;
@@ -1214,9 +1261,10 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         // zero_surplus = 0: surplus blocks write nothing; the reader (the step's finalise kernel) learns the pair's row count from
         // rows_used[], written here by the pair's first block - it does not repeat the choice (two inlined copies of a float test could
         // disagree by an ulp)
-        if (rows_used && blockIdx.x == 0 && threadIdx.x == 0) rows_used[blockIdx.y] = mine;
+        int *rows_used = a->rows_used;
+        if (rows_used && blockIdx.x == 0 && tid_ == 0) rows_used[blockIdx.y] = mine;
         if ((int)blockIdx.x >= mine) {
-            if (MODE != 3 && zero_surplus && threadIdx.x < NP) partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + threadIdx.x] = 0.f;
+            if (MODE != 3 && a->zero_surplus && tid_ < NP) a->partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + tid_] = 0.f;
             return;
         }
     }
@@ -1236,27 +1284,39 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         }
         choice = __builtin_amdgcn_readfirstlane(choice); v = __builtin_amdgcn_readfirstlane(v);   // all four ARE wave-uniform; say so to the
         by = __builtin_amdgcn_readfirstlane(by); stride = __builtin_amdgcn_readfirstlane(stride);  // compiler (the bodies pin them to SGPRs)
+        KArgs a = args();   // this item's view of the arguments: the volumes and ONE geometry
+        const trx_volumes vol = {a->vol.moving, a->vol.target, a->vol.moving_stride, a->vol.target_stride, a->vol.ndim, a->vol.B, a->vol.D, a->vol.H, a->vol.W,
+                                 a->vol.xn, a->vol.yn, a->vol.zn, a->vol.flags};
+        float *partials = a->partials;
+        const int channels = a->channels;
         if constexpr (kDeep) {
             if (choice == 4) {
-                zstream_body<MODE, ZS64>(vol, theta, zg, partials, box, v, by, stride);
+                const ZGeom zg = {a->zg.ntx, a->zg.nty, a->zg.nzseg, a->zg.planes_per_seg, a->zg.blocks_per_pair};
+                zstream_body<MODE, ZS64>(vol, theta, zg, partials, box, v, by, stride, wave_idx);
                 continue;
             }
             if (choice == 0) {
-                tile_body<MODE, GeomD>(vol, theta, tgD, channels, partials, box, v, by, stride);
+                const TileGeom t = tile_of(&a->tgD);
+                tile_body<MODE, GeomD>(vol, theta, t, channels, partials, box, v, by, stride, wave_idx);
                 continue;
             }
             if (choice == 3) {
-                tile_body<MODE, GeomRD>(vol, theta, tgRD, channels, partials, box, v, by, stride);
+                const TileGeom t = tile_of(&a->tgRD);
+                tile_body<MODE, GeomRD>(vol, theta, t, channels, partials, box, v, by, stride, wave_idx);
                 continue;
             }
         }
         if constexpr (WHICH != 1) {
             if (choice != 1) {
-                tile_body<MODE, GeomR>(vol, theta, tgR, channels, partials, box, v, by, stride);
+                const TileGeom t = tile_of(&a->tgR);
+                tile_body<MODE, GeomR>(vol, theta, t, channels, partials, box, v, by, stride, wave_idx);
                 continue;
             }
         }
-        if constexpr (WHICH != 2) tile_body<MODE, GeomA>(vol, theta, tgA, channels, partials, box, v, by, stride);
+        if constexpr (WHICH != 2) {
+            const TileGeom t = tile_of(&a->tgA);
+            tile_body<MODE, GeomA>(vol, theta, t, channels, partials, box, v, by, stride, wave_idx);
+        }
     }
 }
 
@@ -1266,7 +1326,12 @@ static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const fl
                         int zero_surplus = 1, TileGeom td = TileGeom{}, TileGeom trd = TileGeom{}, ZGeom zg = ZGeom{}, int *rows_used = nullptr, int rows_stride = 0)
 {
     if (how == 1) {
-        hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride);
+        // WHICH = 3: the two-body (GeomA / GeomR) instance for launches that offer nothing else - the five-body kernel's entry costs 2-3 us
+        // more (its arguments are fetched in front of the body that needs them), which is what a step of a small volume takes in all
+        if (td.blocks_per_pair == 0 && trd.blocks_per_pair == 0 && zg.blocks_per_pair == 0 && rows_stride == 0)
+            hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 3>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride);
+        else
+            hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride);
     } else {
         hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 1>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
         hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 2>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
@@ -1961,7 +2026,9 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             TileGeom trd = TileGeom{};
             if (step_kernel && TRX_ROT_DEEP_TILE && TRX_DEEP_TILE && !(vol->flags & TRX_FLAG_NO_ROT_DEEP_TILE)) {
                 const TileGeom cand = tile_geom<GeomRD>(*vol);
-                if (cand.ntiles >= 128 || (vol->flags & TRX_FLAG_DEEP_TILE)) trd = cand;   // tiny volumes (<= 64^3: at most 64 of these tiles) stay with GeomR's smaller tiles: measured +5 ... +14 % otherwise
+                // tiny volumes (<= 64^3: at most 64 of these tiles) stay with GeomR's smaller tiles: measured +5 ... +14 % otherwise; and a launch
+                // of fewer than 1024 of these tiles (one pair up to 128^3) is a step of ~15 us, of which the five-body kernel's entry is 2-3
+                if ((cand.ntiles >= 128 && (long)cand.ntiles * vol->B >= 1024) || (vol->flags & TRX_FLAG_DEEP_TILE)) trd = cand;
             }
             // the z-streaming body: pairs next to the identity (zs_fits) in launches that fill the chip
             ZGeom zg = ZGeom{};

@@ -101,7 +101,7 @@ __device__ __forceinline__ int zs_nsub(const float *__restrict__ th, float fD, f
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 template <int MODE, class C>
 __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float *__restrict__ theta, const ZGeom &zg, float *__restrict__ partials,
-                                             float *ring, const int bx, const int by, int rows_per_pair)
+                                             float *ring, const int bx, const int by, int rows_per_pair, const int wave_in)
 {
     static_assert(MODE == 0 || MODE == 1 || MODE == 4, "step kernels and the moments pass");
     constexpr int NQ = (MODE == 0) ? 3 : (MODE == 4 ? 1 : 0);
@@ -114,8 +114,9 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
     const float *__restrict__ mov = uni_ptr(vol.moving + (size_t)b * vol.moving_stride);
     const float *__restrict__ tgt = uni_ptr(vol.target + (size_t)b * vol.target_stride);
     const float *__restrict__ xtab = uni_ptr(vol.xn), *__restrict__ ytab = uni_ptr(vol.yn), *__restrict__ ztab = uni_ptr(vol.zn);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = trx_lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(wave_in);
+    const int tid = wave * 64 + lane;
     const float fW = (float)W, fH = (float)H, fD = (float)D;
     const float hW = 0.5f * fW, hH = 0.5f * fH, hD = 0.5f * fD;
     const float t00 = th[0], t01 = th[1], t02 = th[2], t03 = th[3];
@@ -419,7 +420,7 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
                 vals[o++] = xn * a; vals[o++] = acc.AB[q][c].y; vals[o++] = fmaf(dzn, fmaf(fn, a, -U[q][c]), zn0 * a); vals[o++] = a;
             }
     }
-    block_reduce_store_nw<NP, C::Waves>(vals, partials + ((size_t)by * rows_per_pair + bx) * NP, ring);
+    block_reduce_store_nw<NP, C::Waves>(vals, partials + ((size_t)by * rows_per_pair + bx) * NP, ring, wave);
 }
 
 template <int MODE, class C>
@@ -432,6 +433,6 @@ __global__ __launch_bounds__(C::Threads, TRX_ZS_MIN_WAVES) void affine_zstream_k
         if (threadIdx.x < 41) partials[((size_t)blockIdx.y * rows_per_pair + blockIdx.x) * 41 + threadIdx.x] = __builtin_nanf("");
         return;
     }
-    zstream_body<MODE, C>(vol, theta, zg, partials, ring, blockIdx.x, blockIdx.y, rows_per_pair);
+    zstream_body<MODE, C>(vol, theta, zg, partials, ring, blockIdx.x, blockIdx.y, rows_per_pair, trx_wave_index());
 }
 #pragma clang diagnostic pop
