@@ -199,17 +199,19 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
         const float slack = 0.05f;
         bool fits = (fabsf(mnx) < 1.0e6f) && (fabsf(mxx) < 1.0e6f) && (fabsf(mny) < 1.0e6f) && (fabsf(mxy) < 1.0e6f) && (fabsf(mnz0) < 1.0e6f) &&
                     (fabsf(mxz0) < 1.0e6f) && (fabsf(mnz1) < 1.0e6f) && (fabsf(mxz1) < 1.0e6f);   // also rejects NaN
-        int ox = 0, oy = 0, pbase = 0;
+        int ox = 0, oy = 0, pbase = 0, need_rows = 0, need_c4 = 0;   // need_*: the part of the window this anchor can touch (the rest is not fetched)
         if (fits) {
             ox = (int)floorf(mnx - slack) & ~3;
             oy = (int)floorf(mny - slack);
             const int hx = (int)floorf(mxx + slack) + 1, hy = (int)floorf(mxy + slack) + 1;
+            need_rows = hy - oy; need_c4 = (hx - ox) >> 2;
             const int hi0 = (int)floorf(mxz0 + slack) + 1, hi1 = (int)floorf(mxz1 + slack) + 1;
             const int lo0 = (int)floorf(mnz0 - slack), lo1 = (int)floorf(mnz1 - slack);
             pbase = max(hi0, hi1 - last);
             fits = (hx <= ox + C::BW - 1) && (hy <= oy + C::BH - 1) && (lo0 >= pbase - (C::Span - 1)) && (lo1 >= pbase + last - (C::Span - 1));
         }
         ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy); pbase = __builtin_amdgcn_readfirstlane(pbase);
+        need_rows = __builtin_amdgcn_readfirstlane(need_rows); need_c4 = __builtin_amdgcn_readfirstlane(need_c4);
         if (!__builtin_amdgcn_readfirstlane((int)fits)) { ok = false; break; }   // (cannot happen while zs_nsub holds; reported as NaN rows, never silent)
 
         // ---- ring: zero everything (cells outside the volume in x / y are never written by a DMA: they ARE the zero padding)
@@ -225,7 +227,7 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
             const bool valid = (lane < C::LPP) && (slot < C::PlaneSlots);
             const int row = slot / C::BW4, c4 = slot - row * C::BW4;
             const int gy = oy + row, gx = ox + 4 * c4;
-            const bool inb = valid && (gy >= 0) && (gy < H) && (gx >= 0) && (gx + 4 <= W);
+            const bool inb = valid && (row <= need_rows) && (c4 <= need_c4) && (gy >= 0) && (gy < H) && (gx >= 0) && (gx + 4 <= W);
             mk[k] = __builtin_amdgcn_ballot_w64(inb);
             voff[k] = inb ? (unsigned)((row * W + 4 * c4) * 4) : 0u;
             pvalid[k] = valid;
