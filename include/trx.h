@@ -222,6 +222,24 @@ int trx_flow_slab_update(const trx_volumes *vol, int z_offset, int D_full, const
  * moments[b][5].  trx_flow_slab_moments(..., halo_hi = NULL, ...) followed by this equals trx_flow_slab_moments with the halo - and lets
  * the first run while the neighbour's plane is still travelling over xGMI (SlabFlowSolver.run puts the exchange on a side stream). */
 int trx_flow_slab_boundary_smooth(const trx_volumes *vol, const float *flow, const float *halo_hi, double *moments, void *stream);
+
+/* Peer-mapped transport of the slab partition (not in the reference, which is single-device): the halo planes and
+ * the 64-byte sum of moments as direct writes into a PEER rank's mailbox - device memory of another GPU of the node (or of another
+ * process on the same GPU), mapped by the caller through HIP IPC / peer access - instead of torch.distributed.batch_isend_irecv and
+ * all_reduce (RCCL).  Flags are 32-bit iteration numbers that only increase; waits poll with system-scope loads in a one-thread
+ * kernel, give up after timeout_us and OR a bit into *status (1: trx_peer_wait, 2: trx_peer_gather) instead of hanging the device.
+ *   trx_peer_signal : *flag = value, ordered after everything enqueued on `stream` before it (e.g. the copy of a plane into the
+ *                     peer's halo slot);
+ *   trx_peer_wait   : returns (on the stream) once *flag >= value;
+ *   trx_peer_publish: sums[0..8) -> slot_ptrs[r][0..8) for r < n, then *flag_ptrs[r] = value (slot_ptrs / flag_ptrs: DEVICE arrays of n
+ *                     device pointers, one per peer: this rank's slot and flag inside that peer's mailbox);
+ *   trx_peer_gather : waits until flags[r] >= value for all r < n (this rank's own mailbox), then out[k] = sum over r in rank order of
+ *                     slots[r * 8 + k] - the same fp64 additions in the same order on every rank.
+ * torchregister_amd.SlabPeers wraps them (mailbox layout, IPC exchange of the handles, double buffering by iteration parity). */
+int trx_peer_signal(unsigned *flag, unsigned value, void *stream);
+int trx_peer_wait(const unsigned *flag, unsigned value, unsigned timeout_us, int *status, void *stream);
+int trx_peer_publish(const double *sums, const void *slot_ptrs, const void *flag_ptrs, int n, unsigned value, void *stream);
+int trx_peer_gather(const double *slots, const unsigned *flags, int n, unsigned value, unsigned timeout_us, double *out, int *status, void *stream);
 /* Without the smoothness term (3-D): the update that also leaves the slab's block partials of the UPDATED flow in the workspace, and the
  * reduction of those partials to the 8 sums - together they replace trx_flow_slab_moments from the second iteration on (one pass over
  * the slab per iteration instead of two; same numbers). */

@@ -1,0 +1,136 @@
+"""Peer-mapped transport of the Z-slab partition (include/trx.h: trx_peer_*; torchregister_amd.SlabPeers): the boundary planes and the
+sum of the 8 moments travel as direct writes into the peers' mailboxes instead of torch.distributed calls.
+
+  * one process, three slabs on the one GPU of the test box, driven in lock step (run_slabs_lockstep) - the "self-peer" arrangement:
+    the mailboxes are plain tensors of the same device; must reproduce the un-partitioned FlowSolver like the torch.distributed path
+    (tests/test_gpu_flow.py::test_slab_partition_equals_whole_volume), and every slab must record the SAME loss curve bit for bit
+    (the N slots are added in rank order on every rank);
+  * two processes on the one GPU, mailboxes mapped through HIP IPC (SlabPeers.exchange over a gloo group), SlabFlowSolver.run();
+  * a wait nobody answers times out, sets the status word and SlabPeers.check() raises - it does not hang the device."""
+import os
+import tempfile
+
+import pytest
+import torch
+
+import phantoms as ph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torchregister_amd._engine as e
+    assert torch.cuda.is_available()
+    return e
+
+
+@pytest.mark.parametrize("optimizer,lr,smooth", [("sgd", 2.0, 0.0), ("adam", 0.05, 0.0), ("sgd", 1.0, 4.0), ("adam", 0.05, 2.0)])
+def test_peer_lockstep_three_slabs_equal_whole_volume(eng, optimizer, lr, smooth):
+    shape = (36, 28, 40)
+    tgt, mov = ph.blobs(shape, 1021).cuda(), ph.blobs(shape, 1022).cuda()
+    iters = 6
+    kw = dict(loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr, capacity=iters, smooth_weight=smooth)
+    whole = eng.FlowSolver(mov, tgt, **kw)
+    whole.run(iters)
+    bounds = [0, 10, 25, 36]
+    world = len(bounds) - 1
+    boxes = [eng.SlabPeers.allocate(mov.device, shape[1], shape[2], world) for _ in range(world)]
+    slabs = [eng.SlabFlowSolver(mov, tgt[:, :, a:b].contiguous(), a, peers=eng.SlabPeers(r, boxes, shape[1], shape[2]), **kw)
+             for r, (a, b) in enumerate(zip(bounds[:-1], bounds[1:]))]
+    eng.run_slabs_lockstep(slabs, 4)
+    eng.run_slabs_lockstep(slabs, iters - 4)          # a second call continues (flags keep counting)
+    torch.cuda.synchronize()
+    for s in slabs:
+        s.peers.check()
+        assert torch.allclose(s.losses, whole.losses, rtol=1e-5, atol=1e-6)
+        assert torch.equal(s.losses, slabs[0].losses)                                  # the same fp64 additions on every rank
+    flow = torch.cat([s.flow for s in slabs], dim=2)
+    tol = 2e-3 if (optimizer == "adam" and smooth) else 1e-5                           # (see test_slab_partition_equals_whole_volume)
+    assert torch.max(torch.abs(flow - whole.flow)).item() <= tol * max(1.0, whole.flow.abs().max().item())
+
+
+def test_peer_path_equals_hand_exchange_bitwise(eng):
+    """The transport moves bytes, it must not change them: peer-mapped lock step == the same slabs with planes copied and sums added by
+    hand in rank order (what test_slab_partition_equals_whole_volume does), bit for bit."""
+    shape = (30, 24, 32)
+    tgt, mov = ph.blobs(shape, 77).cuda(), ph.blobs(shape, 78).cuda()
+    iters, bounds = 5, [0, 12, 30]
+    kw = dict(loss=eng.LossSpec(w_ncc=1.0), optimizer="adam", lr=0.03, capacity=iters, smooth_weight=1.5)
+    hand = [eng.SlabFlowSolver(mov, tgt[:, :, a:b].contiguous(), a, **kw) for a, b in zip(bounds[:-1], bounds[1:])]
+    for _ in range(iters):
+        planes = [s.boundary_planes() for s in hand]
+        hand[0].halo_hi.copy_(planes[1][0]); hand[1].halo_lo.copy_(planes[0][1])
+        ms = [s.local_moments_without_halo().clone() for s in hand]
+        for s, m in zip(hand, ms):
+            edge = torch.zeros_like(m)
+            s.add_boundary_smooth(edge)
+            m += edge
+        total = ms[0] + ms[1]
+        for s in hand:
+            s.apply(total.clone())
+    boxes = [eng.SlabPeers.allocate(mov.device, shape[1], shape[2], 2) for _ in range(2)]
+    peer = [eng.SlabFlowSolver(mov, tgt[:, :, a:b].contiguous(), a, peers=eng.SlabPeers(r, boxes, shape[1], shape[2]), **kw)
+            for r, (a, b) in enumerate(zip(bounds[:-1], bounds[1:]))]
+    eng.run_slabs_lockstep(peer, iters)
+    torch.cuda.synchronize()
+    for h, p in zip(hand, peer):
+        p.peers.check()
+        assert torch.equal(h.losses, p.losses) and torch.equal(h.flow, p.flow)
+
+
+def test_peer_wait_times_out_instead_of_hanging(eng):
+    boxes = [eng.SlabPeers.allocate(torch.device("cuda", 0), 8, 8, 2) for _ in range(2)]
+    pr = eng.SlabPeers(0, boxes, 8, 8)
+    pr.TIMEOUT_US = 2000
+    pr.wait_halo("hi")                      # nobody raises the flag
+    out = torch.zeros(1, 8, dtype=torch.float64, device="cuda")
+    pr.publish(out)                         # rank 1 never publishes
+    pr.gather(out)
+    torch.cuda.synchronize()
+    assert int(pr.status.item()) == 3
+    with pytest.raises(Exception, match="timed out"):
+        pr.check()
+
+
+def _ipc_worker(rank, world, port, tmp, shape, bounds, iters, kw):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    import torch.distributed as dist
+    import phantoms as ph2
+    import torchregister_amd._engine as e
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    tgt, mov = ph2.blobs(shape, 1021).cuda(), ph2.blobs(shape, 1022).cuda()
+    box = e.SlabPeers.allocate(mov.device, shape[1], shape[2], world)
+    boxes = e.SlabPeers.exchange(box)
+    a, b = bounds[rank], bounds[rank + 1]
+    s = e.SlabFlowSolver(mov, tgt[:, :, a:b].contiguous(), a, peers=e.SlabPeers(rank, boxes, shape[1], shape[2]), **kw)
+    s.run(iters)
+    torch.cuda.synchronize()
+    s.peers.check()
+    torch.save({"flow": s.flow.cpu(), "losses": s.losses.cpu()}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.barrier()                          # nobody unmaps a mailbox a peer may still be writing
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("optimizer,lr,smooth", [("sgd", 1.0, 4.0), ("adam", 0.05, 0.0)])
+def test_two_processes_ipc_mailboxes_equal_whole_volume(eng, optimizer, lr, smooth):
+    import torch.multiprocessing as mp
+    shape, bounds, iters = (36, 28, 40), [0, 14, 36], 6
+    kw = dict(loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr, capacity=iters, smooth_weight=smooth)
+    tgt, mov = ph.blobs(shape, 1021).cuda(), ph.blobs(shape, 1022).cuda()
+    whole = eng.FlowSolver(mov, tgt, **kw)
+    whole.run(iters)
+    torch.cuda.synchronize()
+    with tempfile.TemporaryDirectory() as tmp:
+        port = 29300 + (os.getpid() % 250)
+        mp.spawn(_ipc_worker, args=(2, port, tmp, shape, bounds, iters, kw), nprocs=2, join=True)
+        parts = [torch.load(os.path.join(tmp, f"rank{r}.pt")) for r in range(2)]
+    flow = torch.cat([p["flow"] for p in parts], dim=2)
+    for p in parts:
+        assert torch.allclose(p["losses"], whole.losses.cpu(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(parts[0]["losses"], parts[1]["losses"])
+    assert torch.max(torch.abs(flow - whole.flow.cpu())).item() <= 1e-5 * max(1.0, whole.flow.abs().max().item())

@@ -6,7 +6,8 @@
 
 Every rank builds the (closed-form) phantom, keeps the whole moving volume and its own slab of target / flow /
 Adam state, and runs SlabFlowSolver: per iteration one 64-byte all-reduce (+ two one-plane P2P halo exchanges with
-the smoothness term).  Rank 0 prints one JSON line."""
+the smoothness term) over torch.distributed, or (--transport peer) the same two exchanges as direct writes into the peers'
+IPC-mapped mailboxes.  Rank 0 prints one JSON line."""
 import argparse, json, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +22,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--optimizer", default="adam")
     ap.add_argument("--smooth", type=float, default=1.0)
+    ap.add_argument("--transport", choices=("dist", "peer"), default="dist",
+                    help="dist: torch.distributed (RCCL) P2P + all_reduce; peer: direct writes into IPC-mapped mailboxes (SlabPeers)")
     a = ap.parse_args()
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
@@ -35,8 +38,12 @@ def main():
     tgt = blobs_gpu(shape, 1000, dev)
     mov = tr.get_affine_warp(torch.tensor(THETA_STAR, device=dev)[None], tgt)
     z0, z1 = slab_range(rank, world, a.size)
+    peers = None
+    if a.transport == "peer" and world > 1:
+        box = tr.SlabPeers.allocate(dev, a.size, a.size, world)
+        peers = tr.SlabPeers(rank, tr.SlabPeers.exchange(box), a.size, a.size)
     s = tr.SlabFlowSolver(mov, tgt[:, :, z0:z1].contiguous(), z0, loss=tr.LossSpec(w_ncc=1.0), optimizer=a.optimizer,
-                          lr=0.01 if a.optimizer == "adam" else 1.0, capacity=a.iters + a.warmup, smooth_weight=a.smooth)
+                          lr=0.01 if a.optimizer == "adam" else 1.0, capacity=a.iters + a.warmup, smooth_weight=a.smooth, peers=peers)
     del tgt
     s.run(a.warmup)
     torch.cuda.synchronize()
@@ -48,11 +55,13 @@ def main():
     if dist is not None:
         dist.barrier()
     el = max_over_ranks(time.perf_counter() - t0, dev)
+    if peers is not None:
+        peers.check()
     if rank == 0:
         ls = s.losses[0, : a.iters + a.warmup]
         print(json.dumps({"config": f"{a.size}^3 direct flow + NCC + {a.optimizer} + smooth {a.smooth}, {world} Z-slab(s)", "iters": a.iters,
                           "ms_per_iter": 1e3 * el / a.iters, "iters_per_s": a.iters / el, "loss_first": ls[0].item(), "loss_last": ls[-1].item(),
-                          "n_gpus": world}), flush=True)
+                          "n_gpus": world, "transport": a.transport if world > 1 else "none"}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

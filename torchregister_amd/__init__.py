@@ -6,7 +6,7 @@ HIP kernels in lib/libtrx.so (C ABI: include/trx.h).  There is no CPU fallback.
 """
 __version__ = "0.2.0"
 
-from ._engine import AffineSolver, FlowSolver, LossSpec, SlabFlowSolver  # noqa: F401
+from ._engine import AffineSolver, FlowSolver, LossSpec, SlabFlowSolver, SlabPeers, run_slabs_lockstep  # noqa: F401
 from .sharding import register_sharded  # noqa: F401
 from .torchregister import Register  # noqa: F401
 from .utils import (EPSILON, Attention_UNet, K_gauss, LocalNCCLoss, NCCLoss, NMI, NMILoss, PDF, PDF_xis, Regressor, SpatialTransformer, SSDLoss,  # noqa: F401

@@ -385,6 +385,124 @@ def flow_loss_grad(moving, target, flow, loss, need_grad=True):
     return terms, dfl
 
 
+class SlabPeers:
+    """Peer-mapped transport for SlabFlowSolver (include/trx.h: trx_peer_*): one MAILBOX per rank - device memory that the other ranks
+    of the node write into directly (HIP IPC / peer access; xGMI between GPUs) - instead of torch.distributed P2P and all_reduce.
+
+    Mailbox of rank r (one uint8 tensor): [parity 0, 1] x (halo_lo [3,H,W] f32, halo_hi [3,H,W] f32, slots [N,8] f64) | flags: lo, hi,
+    sums[N] (uint32 iteration numbers, only ever raised).  Use:
+        box = SlabPeers.allocate(device, H, W, world)            # on every rank
+        peers = SlabPeers.exchange(box, group)                   # IPC handles through the process group -> the N mailboxes, mapped
+        solver = SlabFlowSolver(..., peers=SlabPeers(rank, peers, H, W))
+    In one process (several slabs driven in lock step on one or several GPUs: run_slabs_lockstep) the mailboxes are passed as they are."""
+
+    TIMEOUT_US = 5_000_000
+
+    @staticmethod
+    def layout(H, W, world):
+        plane = 3 * H * W * 4
+        slots = world * 8 * 8
+        per_parity = 2 * plane + slots
+        flags_off = 2 * per_parity
+        total = flags_off + (2 + world) * 4
+        return plane, slots, per_parity, flags_off, (total + 255) // 256 * 256
+
+    @staticmethod
+    def allocate(device, H, W, world):
+        return torch.zeros(SlabPeers.layout(H, W, world)[4], dtype=torch.uint8, device=device)
+
+    @staticmethod
+    def exchange(box, group=None):
+        """All-gathers the IPC handles of the ranks' mailboxes over `group` and maps them: the list of the N mailboxes (this rank's own
+        entry is `box` itself).  The mailbox must be the only tensor of its storage (allocate() guarantees it)."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        handle = box.untyped_storage()._share_cuda_()
+        handles = [None] * world
+        dist.all_gather_object(handles, handle, group=group)
+        boxes = []
+        for r, h in enumerate(handles):
+            if r == rank:
+                boxes.append(box)
+            else:
+                st = torch.UntypedStorage._new_shared_cuda(*h)
+                boxes.append(torch.empty(0, dtype=torch.uint8, device=st.device).set_(st))
+        return boxes
+
+    def __init__(self, rank, boxes, H, W):
+        self.lib = _lib.load()
+        self.rank, self.world, self.boxes = int(rank), len(boxes), boxes
+        self.H, self.W = int(H), int(W)
+        self.plane, self.slots_bytes, self.per_parity, self.flags_off, total = SlabPeers.layout(H, W, self.world)
+        for b in boxes:
+            if b.numel() < total:
+                raise ValueError("mailbox smaller than SlabPeers.layout")
+        self.mine = boxes[self.rank]
+        dev = self.mine.device
+        self.device = dev
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.t = 0          # iterations completed through this transport (flag values are t + 1)
+        # this rank's slot and flag inside every peer's mailbox, as device arrays of pointers, per parity
+        self._slot_ptrs, self._flag_ptrs = [], None
+        for par in (0, 1):
+            ptrs = [b.data_ptr() + par * self.per_parity + 2 * self.plane + self.rank * 64 for b in boxes]
+            self._slot_ptrs.append(torch.tensor(ptrs, dtype=torch.int64, device=dev))
+        self._flag_ptrs = torch.tensor([b.data_ptr() + self.flags_off + (2 + self.rank) * 4 for b in boxes], dtype=torch.int64, device=dev)
+
+    # -- views into mailboxes
+    def halo(self, box, par, which):
+        off = par * self.per_parity + (0 if which == "lo" else self.plane)
+        return box[off:off + self.plane].view(torch.float32).view(3, self.H, self.W)
+
+    def _flag_ptr(self, box, idx):
+        return box.data_ptr() + self.flags_off + idx * 4
+
+    def _stream(self):
+        return _lib.current_stream(self.device)
+
+    def put_halos(self, lo_plane, hi_plane, has_lo, has_hi):
+        """This rank's lowest / highest flow plane into the halo_hi slot of the rank below / the halo_lo slot of the rank above, then
+        their flags; on the current stream."""
+        par, v = self.t & 1, self.t + 1
+        with torch.cuda.device(self.device):
+            if has_lo:
+                below = self.boxes[self.rank - 1]
+                self.halo(below, par, "hi").copy_(lo_plane, non_blocking=True)
+                _lib.check(self.lib.trx_peer_signal(self._flag_ptr(below, 1), v, self._stream()), "trx_peer_signal")
+            if has_hi:
+                above = self.boxes[self.rank + 1]
+                self.halo(above, par, "lo").copy_(hi_plane, non_blocking=True)
+                _lib.check(self.lib.trx_peer_signal(self._flag_ptr(above, 0), v, self._stream()), "trx_peer_signal")
+
+    def wait_halo(self, which):
+        """Blocks the current stream until the neighbour's plane of this iteration has arrived; returns the plane (a view of the mailbox)."""
+        par, v = self.t & 1, self.t + 1
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.trx_peer_wait(self._flag_ptr(self.mine, 0 if which == "lo" else 1), v, self.TIMEOUT_US, _lib.ptr(self.status), self._stream()), "trx_peer_wait")
+        return self.halo(self.mine, par, which)
+
+    def publish(self, sums):
+        """sums ([1,8] fp64 on this device) into this rank's slot of every mailbox."""
+        par, v = self.t & 1, self.t + 1
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.trx_peer_publish(_lib.ptr(sums), _lib.ptr(self._slot_ptrs[par]), _lib.ptr(self._flag_ptrs), self.world, v, self._stream()), "trx_peer_publish")
+
+    def gather(self, out):
+        """The whole-volume sums into `out` ([1,8] fp64): waits for every rank's publish of this iteration, adds in rank order; ends the iteration."""
+        par, v = self.t & 1, self.t + 1
+        slots = self.mine.data_ptr() + par * self.per_parity + 2 * self.plane
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.trx_peer_gather(slots, self.mine.data_ptr() + self.flags_off + 8, self.world, v, self.TIMEOUT_US, _lib.ptr(out), _lib.ptr(self.status),
+                                                self._stream()), "trx_peer_gather")
+        self.t += 1
+
+    def check(self):
+        """Host sync: raises when a wait timed out (a peer never wrote)."""
+        st = int(self.status.item())
+        if st:
+            raise _lib.TrxError(f"peer transport timed out (status {st}: 1 = halo plane, 2 = sums)")
+
+
 class SlabFlowSolver:
     """One rank's Z-slab of a single-volume direct-flow registration (BASELINE config 5).
 
@@ -396,8 +514,9 @@ class SlabFlowSolver:
     The loss curve holds the WHOLE-volume loss on every rank."""
 
     def __init__(self, moving_full, target_slab, z_offset, loss=None, optimizer="sgd", lr=1e-3, capacity=1000, betas=(0.9, 0.999),
-                 eps=1e-8, group=None, smooth_weight=0.0, stop_crit=None, flags=0):
+                 eps=1e-8, group=None, smooth_weight=0.0, stop_crit=None, flags=0, peers=None):
         self.lib = _lib.load()
+        self.peers = peers      # SlabPeers: halo planes and the sum of moments as direct writes into the peers' mailboxes instead of torch.distributed
         _require_gpu(moving_full, "moving_full")
         _require_gpu(target_slab, "target_slab")
         if moving_full.dim() != 5 or target_slab.dim() != 5 or moving_full.shape[:2] != (1, 1) or target_slab.shape[:2] != (1, 1):
@@ -540,11 +659,19 @@ class SlabFlowSolver:
         """`iters` iterations.  With more than one rank and the smoothness term, the exchange of the boundary flow planes with the Z
         neighbours (P2P over xGMI, 3 MB per face at 512^2) runs on a side stream while pass A covers the slab: pass A leaves the one
         term that needs the neighbour's plane to a small kernel behind the exchange (trx_flow_slab_boundary_smooth).  The 64-byte
-        all-reduce of the sums stays between pass A and pass B, where the algorithm needs it."""
+        all-reduce of the sums stays between pass A and pass B, where the algorithm needs it.  With `peers` (SlabPeers) both exchanges
+        are direct writes into the peers' mailboxes and no torch.distributed call is made."""
         import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         if self.enqueued + int(iters) > self.capacity:
             raise _lib.TrxError(f"loss-curve capacity exceeded: {self.enqueued} + {int(iters)} > {self.capacity}")
+        if self.peers is not None:
+            self.enqueued += int(iters)
+            for it in range(int(iters)):
+                self.peer_post(last=(it == int(iters) - 1))
+                self.peer_join()
+                self.peer_finish()
+            return
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         self.enqueued += int(iters)
         overlap = multi and bool(self.smooth)
         if overlap and getattr(self, "_side", None) is None:
@@ -573,6 +700,80 @@ class SlabFlowSolver:
                 dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.group)   # 64 bytes per iteration
             self.apply(m)
         self.vol.flags = base_flags
+
+    # -- one iteration over the peer-mapped transport, in three steps so that ONE process can drive several slabs in lock step
+    # (run_slabs_lockstep: every slab posts, then every slab joins, then every slab finishes - no wait is enqueued before the write it
+    # waits for); run() calls them back to back for its own slab.
+    def peer_post(self, last=False, side_stream=True):
+        """Sends the boundary planes (their copies and flags on a side stream, so they travel while pass A runs) and runs pass A."""
+        pr = self.peers
+        self._base_flags = getattr(self, "_base_flags", int(self.vol.flags))
+        self.vol.flags = self._base_flags | (_lib.FLAG_SAVE_LAST if (self.flow_last is not None and last) else 0)
+        if not self.smooth:
+            self._m = self.local_moments()
+            return
+        if getattr(self, "_edge", None) is None:
+            self._edge = torch.zeros(1, 8, dtype=torch.float64, device=self.device)
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        self._use_side = bool(side_stream)
+        lo, hi = self.boundary_planes()
+        if self._use_side:
+            self._side.wait_stream(main)
+            lo.record_stream(self._side); hi.record_stream(self._side)
+            with torch.cuda.stream(self._side):
+                pr.put_halos(lo, hi, self.has_lo, self.has_hi)
+        else:
+            pr.put_halos(lo, hi, self.has_lo, self.has_hi)
+        self._m = self.local_moments_without_halo()
+
+    def peer_join(self):
+        """Waits for the neighbours' planes, adds the cross-slab smoothness term, publishes this slab's sums to every mailbox."""
+        pr = self.peers
+        if self.smooth:
+            main = torch.cuda.current_stream(self.device)
+
+            def arrive():
+                self._edge.zero_()
+                if self.has_hi:
+                    self.halo_hi = pr.wait_halo("hi")
+                    self.add_boundary_smooth(self._edge)
+                if self.has_lo:
+                    self.halo_lo = pr.wait_halo("lo")
+            if self._use_side:
+                with torch.cuda.stream(self._side):
+                    arrive()
+                main.wait_stream(self._side)
+            else:
+                arrive()
+            self._m += self._edge
+        pr.publish(self._m)
+
+    def peer_finish(self):
+        """Whole-volume sums (every rank adds the N slots in rank order) and pass B."""
+        self.peers.gather(self._m)
+        self.apply(self._m)
+        self.vol.flags = self._base_flags
+
+
+def run_slabs_lockstep(solvers, iters):
+    """One process driving several SlabFlowSolvers that share a SlabPeers transport (each with its own SlabPeers of the same mailboxes,
+    on one GPU or several): all post, all join, all finish - per iteration.  The single-process counterpart of N ranks calling run()."""
+    for s in solvers:
+        if s.enqueued + int(iters) > s.capacity:
+            raise _lib.TrxError(f"loss-curve capacity exceeded: {s.enqueued} + {int(iters)} > {s.capacity}")
+        s.enqueued += int(iters)
+    for it in range(int(iters)):
+        last = it == int(iters) - 1
+        for s in solvers:
+            with torch.cuda.device(s.device):
+                s.peer_post(last=last, side_stream=False)
+        for s in solvers:
+            with torch.cuda.device(s.device):
+                s.peer_join()
+        for s in solvers:
+            with torch.cuda.device(s.device):
+                s.peer_finish()
 
 
 def local_ncc_loss_grad(target, warped, window=9, alpha=1.0, eps=1e-5, need_grad=True):

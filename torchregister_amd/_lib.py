@@ -85,6 +85,10 @@ SIGNATURES = {
                                     ctypes.POINTER(FlowState), ctypes.c_int, _P, ctypes.c_size_t, _P]),
     "trx_flow_slab_moments": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_flow_slab_boundary_smooth": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, _P, _P, _P]),
+    "trx_peer_signal": (ctypes.c_int, [_P, ctypes.c_uint, _P]),
+    "trx_peer_wait": (ctypes.c_int, [_P, ctypes.c_uint, ctypes.c_uint, _P, _P]),
+    "trx_peer_publish": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_uint, _P]),
+    "trx_peer_gather": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_uint, ctypes.c_uint, _P, _P, _P]),
     "trx_flow_slab_update": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, ctypes.POINTER(LossCfg),
                                             ctypes.POINTER(OptCfg), ctypes.POINTER(FlowState), _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_flow_slab_update_fused": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, ctypes.POINTER(LossCfg),
