@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the z-streaming F1 body (csrc/affine_zstream.h) against the C oracle in fp64.
+   python tests/fuzz_zstream.py [cases] [seed] [case to re-run verbosely]
+Shapes the body tiles (W a multiple of 64, H of 32, any depth from 8), batches of 1-4 pairs whose thetas sit at random distances
+from the identity - well inside the window, at its edge (where a pair re-anchors 2 / 4 / 8 times along z) and beyond it (the pair falls
+back to a tile geometry inside the same launch) - with shifts of whole and fractional voxels, random MSE / NCC / SSD weights (the
+NCC step and the MSE-only step kernel).  TRX_FLAG_ZSTREAM offers the body whatever the launch size; every case
+also runs with TRX_FLAG_NO_ZSTREAM, and the two must agree to the same bars.  Tolerances as in tests/fuzz_affine.py."""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # test infrastructure: the oracle may only be used from tests/
+import oracle
+import phantoms as ph
+import torchregister_amd._engine as eng
+from torchregister_amd import _lib
+from fuzz_affine import kink_variants, smooth
+
+
+def near_identity(rng, eps):
+    th = np.eye(3, 4) + eps * rng.uniform(-1.0, 1.0, (3, 4))
+    mode = rng.integers(0, 4)
+    if mode == 1:
+        th[:, 3] += rng.uniform(-0.08, 0.08, 3)                       # a few voxels of translation
+    elif mode == 2:
+        th[:, 3] = 2.0 * rng.integers(-2, 3, 3) / np.array([64.0, 32.0, 16.0])   # near whole-voxel shifts: samples next to the lattice
+        th[:, 3] += 1e-3 * rng.standard_normal(3)
+    return th + 1e-4 * rng.standard_normal(th.shape)
+
+
+def run(n, seed, grad_bar=2e-4, verbose=True, only=None):
+    rng = np.random.default_rng(seed)
+    worst = {"loss": 0.0, "grad": 0.0, "ab": 0.0}
+    fails = ran = 0
+    for it in range(n):
+        W = 64 * int(rng.integers(1, 3)); H = 32 * int(rng.integers(1, 4)); D = int(rng.integers(8, 72))
+        shape = (D, H, W)
+        B = int(rng.integers(1, 5))
+        epss = [float(rng.choice([0.0, 2e-3, 6e-3, 1.2e-2, 2e-2, 3e-2, 5e-2])) for _ in range(B)]
+        kind = int(rng.integers(0, 2))     # 0: NCC (+MSE) step, 1: MSE / SSD only (the MODE 4 kernel)
+        kw = dict(w_ncc=float(rng.uniform(0.2, 1)), w_mse=float(rng.uniform(0, 1))) if kind != 1 else dict(w_mse=float(rng.uniform(0.2, 1)), w_ssd=float(rng.uniform(0, 0.5)))
+        ths = np.stack([near_identity(rng, e) for e in epss])
+        if only is not None and it != only:
+            continue
+        tgt = torch.cat([ph.blobs(shape, 700 + 3 * it + b) + 0.05 * smooth(shape, 0.29 + 0.02 * b) for b in range(B)])
+        mov = torch.cat([ph.blobs(shape, 800 + 5 * it + b) + 0.1 * smooth(shape, 0.21) for b in range(B)])
+        th = torch.tensor(ths, dtype=torch.float32)
+        out = {}
+        for name, flags in (("zs", _lib.FLAG_ZSTREAM), ("tile", _lib.FLAG_NO_ZSTREAM)):
+            s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=flags)
+            s.run(1)
+            torch.cuda.synchronize()
+            out[name] = (s.losses[:, 0].cpu().numpy().copy(), s.grad[:, :12].cpu().numpy().reshape(B, 3, 4).copy(), s.rows_used().tolist())
+        ran += any(r == 64 or r < min(out["tile"][2]) for r in out["zs"][2])
+        tabs64, tabs32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)
+        for b in range(B):
+            tu = th[b].double().numpy()
+            m64, t64 = mov[b, 0].double().numpy(), tgt[b, 0].double().numpy()
+            total, _, dth, _ = oracle.c_affine_loss_grad(m64, t64, tu, oracle.wts(**kw), tabs64)
+            _, _, dth32, _ = oracle.c_affine_loss_grad(mov[b, 0].numpy(), tgt[b, 0].numpy(), th[b].numpy(), oracle.wts(**kw), tabs32)
+            gmax = max(np.max(np.abs(dth)), 1e-12)
+            ksens = max(np.max(np.abs(oracle.c_affine_loss_grad(m64, t64, t, oracle.wts(**kw), tabs64)[2] - dth)) for t in kink_variants(tu)) / gmax
+            gbar = max(grad_bar, 2.0 * np.max(np.abs(dth32 - dth)) / gmax, 1.5 * ksens)
+            errs = {}
+            for name in ("zs", "tile"):
+                loss, grad, _ = out[name]
+                errs[name] = (abs(loss[b] - total) / max(1.0, abs(total)), np.max(np.abs(grad[b] - dth)) / gmax / gbar * grad_bar)
+            ab = np.max(np.abs(out["zs"][1][b] - out["tile"][1][b])) / gmax / gbar * grad_bar
+            el = max(errs["zs"][0], errs["tile"][0]); eg = max(errs["zs"][1], errs["tile"][1])
+            worst["loss"] = max(worst["loss"], el); worst["grad"] = max(worst["grad"], eg); worst["ab"] = max(worst["ab"], ab)
+            bad = el > 2e-5 or eg > grad_bar or ab > 2 * grad_bar or not np.isfinite(out["zs"][0][b])
+            if bad:
+                fails += 1
+                if verbose:
+                    print(f"FAIL case {it} pair {b}: shape {shape} B {B} eps {epss} kw {kw} loss err zs {errs['zs'][0]:.2e} tile {errs['tile'][0]:.2e} "
+                          f"grad err zs {errs['zs'][1]:.2e} tile {errs['tile'][1]:.2e} zs-vs-tile {ab:.2e} rows {out['zs'][2]} / {out['tile'][2]}\n theta {tu.tolist()}")
+    if verbose:
+        print(f"{n} cases ({ran} with at least one pair on the z-streaming body), {fails} failures; worst loss rel {worst['loss']:.2e} (bar 2e-5), "
+              f"grad rel-to-max {worst['grad']:.2e} (bar {grad_bar:.0e}), body-vs-tiles {worst['ab']:.2e}")
+    return fails, worst
+
+
+if __name__ == "__main__":
+    f, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+               only=int(sys.argv[3]) if len(sys.argv) > 3 else None)
+    sys.exit(1 if f else 0)

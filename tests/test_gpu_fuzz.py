@@ -39,3 +39,12 @@ def test_random_sweep_2d_channels_trajectories():
     import fuzz_misc
     fails, worst = fuzz_misc.run(60, 7, verbose=True)
     assert fails == 0, worst
+
+
+def test_random_sweep_zstream_body():
+    """The z-streaming F1 body at random distances from the identity - inside its window, at the edge (re-anchoring) and beyond (fallback
+    inside the same launch) - mixed batches, NCC and MSE-only steps, against the C oracle and against the tile kernels
+    (tests/fuzz_zstream.py)."""
+    import fuzz_zstream
+    fails, worst = fuzz_zstream.run(40, 5, grad_bar=3e-4, verbose=True)
+    assert fails == 0, worst
