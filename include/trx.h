@@ -257,7 +257,7 @@ int trx_flow_warp_backward(const trx_volumes *vol, const float *flow, int channe
  * oracle/compose.py::local_ncc_loss).  target / warped: [B][D][H][W] fp32 (D = 1 for ndim 2), contiguous.
  *   loss[b] = alpha * (1 - mean_q cc_b(q)),  cc = c^2 / (a b + eps) over the window^ndim box around q (zero padding),
  *   grad[b] = d loss[b] / d warped[b]   (same shape as warped).  Either output may be NULL.
- * window: 3, 5, 7 or 9.  Workspace: trx_lncc_workspace_bytes (16 B per voxel of intermediate fields + block partials). */
+ * window: 3, 5, 7 or 9.  Workspace: trx_lncc_workspace_bytes (12 B per voxel of intermediate fields + block partials). */
 size_t trx_lncc_workspace_bytes(int ndim, int B, int D, int H, int W);
 int trx_lncc_loss_grad(const float *target, const float *warped, int ndim, int B, int D, int H, int W, int window, float alpha,
                        float eps, float *loss, float *grad, void *workspace, size_t workspace_bytes, void *stream);

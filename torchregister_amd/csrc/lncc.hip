@@ -7,17 +7,19 @@
 //     loss = alpha * (1 - mean_q cc(q))
 //
 // and its derivative wrt J (I = target, J = warped) is again a set of box sums:
-//     dloss/dJ_p = -(alpha/N) * ( I_p box(P)_p - box(P uI)_p - J_p box(Q)_p + box(Q uJ)_p ),
-//     P = 2c/den, Q = 2 c^2 a / den^2, den = a b + eps, uI = S_I / n, uJ = S_J / n.
+//     dloss/dJ_p = -(alpha/N) * ( I_p box(P)_p - J_p box(Q)_p + box(Q uJ - P uI)_p ),
+//     P = 2c/den, Q = 2 c^2 a / den^2, den = a b + eps, uI = S_I / n, uJ = S_J / n
+// (box is linear: the two fields that are not multiplied by a per-voxel value travel as one, T = Q uJ - P uI - three fields instead of
+// four: 12 instead of 16 bytes per voxel between the kernels, three instead of four sets of window sums in the second).
 //
-// Kernel 1 (lncc_fields_kernel): per voxel the 5 window sums -> cc (loss partial) and the 4 fields P, P uI, Q, Q uJ.
-// Kernel 2 (lncc_grad_kernel):   the 4 window sums of those fields, combined with I_p, J_p -> dloss/dJ.
+// Kernel 1 (lncc_fields_kernel): per voxel the 5 window sums -> cc (loss partial) and the 3 fields P, Q, T.
+// Kernel 2 (lncc_grad_kernel):   the 3 window sums of those fields, combined with I_p, J_p -> dloss/dJ.
 // Both walk a (32 x, 8 y) column of the volume along z: per plane the tile (+4 halo) goes to LDS, the x window is a
 // sliding sum over float4 reads (4 outputs per thread), the y window 2R+1 LDS reads per field, and the z window a
 // running sum over a register ring of the last 2R+1 plane sums (re-summed exactly once per ring turn, so rounding
 // does not drift along z).  Window sums are separable box filters - adds only; MFMA has nothing to contract here
 // (a banded-matrix formulation would spend 40 MACs where 9 adds do).
-// Algorithmic bytes: kernel 1 reads I, J (8) and writes 16; kernel 2 reads 16 + 8 and writes 4 -> 52 B / voxel.
+// Algorithmic bytes: kernel 1 reads I, J (8) and writes 12; kernel 2 reads 12 + 8 and writes 4 -> 44 B / voxel.
 #include "trx_common.h"
 
 namespace trx {
@@ -118,17 +120,22 @@ __device__ __forceinline__ void plane_window_sums(const PlaneRegs<NL> &r, Expand
 
 // Walks the column along z, keeping the z window as a running sum over a register ring; emit(z, Z) is called for
 // every output plane with the full window sums Z[NF] of this thread's voxel.
-template <int R, int NF, int NL, typename Fetch, typename Expand, typename Emit>
-__device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0, int Y0, int z0, int z1, Fetch fetch, Expand expand, Emit emit,
+// pre(z, o) is called one plane's worth of window passes BEFORE emit(z, Z, o, pre(z, o)): what emit needs from global memory about its
+// own voxel (the gradient kernel: I_p, J_p) is requested there, so that its latency hides under the passes instead of stalling every plane.
+template <int R, int NF, int NL, typename Fetch, typename Expand, typename Pre, typename Emit>
+__device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0, int Y0, int z0, int z1, Fetch fetch, Expand expand, Pre pre, Emit emit,
                                             float (*raw)[kLRows][kLCols], float (*xs)[kLX][kLRows + 1])
 {   // output planes [z0, z1) of the column (a z segment: small batches split columns so that the chip is filled)
     PlaneRegs<NL> regs;
     if (nd == 2) {   // images: the window has no z extent
         float P[kLO][NF];
         plane_fetch<NL>(0, 1, H, W, X0, Y0, fetch, regs);
+        decltype(pre(0, 0)) pv[kLO];
+#pragma unroll
+        for (int o = 0; o < kLO; o++) pv[o] = pre(0, o);
         plane_window_sums<R, NF, NL>(regs, expand, raw, xs, P);
 #pragma unroll
-        for (int o = 0; o < kLO; o++) emit(0, P[o], o);
+        for (int o = 0; o < kLO; o++) emit(0, P[o], o, pv[o]);
         return;
     }
     constexpr int WN = 2 * R + 1;
@@ -149,6 +156,11 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
             const int zin = base + k;
             if (zin < z1 + R) {
                 float P[kLO][NF];
+                decltype(pre(0, 0)) pv[kLO];
+                if (zin - R >= z0) {
+#pragma unroll
+                    for (int o = 0; o < kLO; o++) pv[o] = pre(zin - R, o);
+                }
                 if (zin >= 0 && zin < D) {   // uniform
                     PlaneRegs<NL> cur = regs;
                     plane_fetch<NL>(zin + 1, D, H, W, X0, Y0, fetch, regs);   // next plane in flight during this plane's passes
@@ -175,7 +187,7 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
                             ring[o][k][f] = P[o][f];
                         }
                     }
-                    if (zin - R >= z0) emit(zin - R, Z[o], o);
+                    if (zin - R >= z0) emit(zin - R, Z[o], o, pv[o]);
                 }
             }
         }
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_fields_kernel(const float 
     const int zlen = (D + zsplit - 1) / zsplit, z0 = seg * zlen, z1 = min(D, z0 + zlen);
     const size_t n = (size_t)D * H * W;
     const float *__restrict__ I = tgt + (size_t)b * n, *__restrict__ J = wrp + (size_t)b * n;
-    float *__restrict__ F = fields + (size_t)b * 4 * n;
+    float *__restrict__ F = fields + (size_t)b * 3 * n;
     const int tid = threadIdx.x, x = X0 + (tid & (kLX - 1)), y = Y0 + kLO * (tid >> 5);   // this thread's rows: y, ..., y + kLO - 1
     const float wn = (nd == 3) ? (float)((2 * R + 1) * (2 * R + 1) * (2 * R + 1)) : (float)((2 * R + 1) * (2 * R + 1));
     const float inv_n = 1.0f / wn;
@@ -207,7 +219,8 @@ __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_fields_kernel(const float 
         const float i = in[0], j = in[1];
         cell[0] = i; cell[FS] = j; cell[2 * FS] = i * i; cell[3 * FS] = j * j; cell[4 * FS] = i * j;
     };
-    auto emit = [&](int z, const float (&Z)[5], int o) {
+    auto pre = [](int, int) { return 0; };
+    auto emit = [&](int z, const float (&Z)[5], int o, int) {
         if (x >= W || y + o >= H) return;
         const float Is = Z[0], Js = Z[1];
         const float c = Z[4] - Is * Js * inv_n, a = Z[2] - Is * Is * inv_n, bv = Z[3] - Js * Js * inv_n;
@@ -215,9 +228,9 @@ __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_fields_kernel(const float 
         const float Pq = 2.0f * c * rden, Qq = Pq * c * a * rden;
         lsum += c * c * rden;
         const size_t off = ((size_t)z * H + y + o) * W + x;
-        F[off] = Pq; F[n + off] = Pq * (Is * inv_n); F[2 * n + off] = Qq; F[3 * n + off] = Qq * (Js * inv_n);
+        F[off] = Pq; F[n + off] = Qq; F[2 * n + off] = (Qq * Js - Pq * Is) * inv_n;
     };
-    column_walk<R, 5, 2>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, emit, raw, xs);
+    column_walk<R, 5, 2>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, pre, emit, raw, xs);
     // block sum of the cc partials in a fixed order: butterfly inside each wave, then the 4 wave sums through LDS
     // (a generic block_reduce_store would add 16 KB of static LDS and halve the blocks per CU)
 #pragma unroll
@@ -233,31 +246,40 @@ template <int R, int MW>
 __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_grad_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
                                                              int W, int zsplit, float scale, const float *__restrict__ fields, float *__restrict__ grad)
 {
-    __shared__ __attribute__((aligned(16))) float raw[4][kLRows][kLCols];
-    __shared__ float xs[4][kLX][kLRows + 1];
+    __shared__ __attribute__((aligned(16))) float raw[3][kLRows][kLCols];
+    __shared__ float xs[3][kLX][kLRows + 1];
     const int b = blockIdx.z / zsplit, seg = blockIdx.z - b * zsplit, X0 = blockIdx.x * kLX, Y0 = blockIdx.y * kLY;
     const int zlen = (D + zsplit - 1) / zsplit, z0 = seg * zlen, z1 = min(D, z0 + zlen);
     const size_t n = (size_t)D * H * W;
     const float *__restrict__ I = tgt + (size_t)b * n, *__restrict__ J = wrp + (size_t)b * n;
-    const float *__restrict__ F = fields + (size_t)b * 4 * n;
+    const float *__restrict__ F = fields + (size_t)b * 3 * n;
     float *__restrict__ G = grad + (size_t)b * n;
     const int tid = threadIdx.x, x = X0 + (tid & (kLX - 1)), y = Y0 + kLO * (tid >> 5);
     constexpr int FS = kLRows * kLCols;
-    auto fetch = [&](int z, int gy, int gx, float (&o)[4]) {
+    auto fetch = [&](int z, int gy, int gx, float (&o)[3]) {
         const size_t off = ((size_t)z * H + gy) * W + gx;
 #pragma unroll
-        for (int f = 0; f < 4; f++) o[f] = F[(size_t)f * n + off];
+        for (int f = 0; f < 3; f++) o[f] = F[(size_t)f * n + off];
     };
-    auto expand = [&](float *cell, const float (&in)[4]) {
+    auto expand = [&](float *cell, const float (&in)[3]) {
 #pragma unroll
-        for (int f = 0; f < 4; f++) cell[f * FS] = in[f];
+        for (int f = 0; f < 3; f++) cell[f * FS] = in[f];
     };
-    auto emit = [&](int z, const float (&Z)[4], int o) {
+    struct IJ { float i, j; };
+    auto pre = [&](int z, int o) {
+        IJ v = {0.f, 0.f};
+        if (x < W && y + o < H) {
+            const size_t off = ((size_t)z * H + y + o) * W + x;
+            v.i = I[off]; v.j = J[off];
+        }
+        return v;
+    };
+    auto emit = [&](int z, const float (&Z)[3], int o, const IJ &v) {
         if (x >= W || y + o >= H) return;
         const size_t off = ((size_t)z * H + y + o) * W + x;
-        G[off] = scale * (I[off] * Z[0] - Z[1] - J[off] * Z[2] + Z[3]);
+        G[off] = scale * (v.i * Z[0] - v.j * Z[1] + Z[2]);
     };
-    column_walk<R, 4, 4>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, emit, raw, xs);
+    column_walk<R, 3, 3>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, pre, emit, raw, xs);
 }
 
 // loss[b] = alpha * (1 - sum(partials) / N), partials reduced in fp64 in a fixed order
@@ -329,7 +351,7 @@ using namespace trx;
 extern "C" size_t trx_lncc_workspace_bytes(int ndim, int B, int D, int H, int W)
 {
     if ((ndim != 2 && ndim != 3) || B < 1 || D < 1 || H < 1 || W < 1 || (ndim == 2 && D != 1)) return 0;
-    return lncc_partials_bytes(ndim, B, D, H, W) + (size_t)4 * B * D * H * W * sizeof(float);
+    return lncc_partials_bytes(ndim, B, D, H, W) + (size_t)3 * B * D * H * W * sizeof(float);
 }
 
 extern "C" int trx_lncc_loss_grad(const float *target, const float *warped, int ndim, int B, int D, int H, int W, int window, float alpha,
