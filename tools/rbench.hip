@@ -8,6 +8,7 @@
 #include "../torchregister_amd/csrc/affine.hip"
 namespace trx {
 #include "experiments/affine_rot.h"   // the shelved packed-box rotated-tile body (round 3): a measured alternative, never part of the library
+#include "experiments/affine_rot2.h"  // its double-buffered 1024-thread variant
 }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -101,6 +102,23 @@ int main(int argc, char **argv)
         if (getenv("SB_DUMP")) for (int k = 0; k < 41; k++) printf("   sum %2d: %.6e  %.6e\n", k, got[k], ref[k]);
         rep("tile kernels (rows used below)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, none, ru, 0); }, reps));
         printf("   rows used by the tile kernels: %d\n", hru[0]);
+        CK(hipMemset(partials, 0, (size_t)B * prow * 41 * 4));
+        hipLaunchKernelGGL((trx::affine_rot2_kernel<0>), dim3(trd.blocks_per_pair, B), dim3(1024), 0, 0, vol, theta, trd, partials, trd.blocks_per_pair);
+        CK(hipDeviceSynchronize());
+        {
+            const std::vector<double> g2 = sums(trd.blocks_per_pair);
+            double w2 = 0; bool nan2 = false;
+            for (int b = 0; b < B; b++) {
+                double scale = 0;
+                for (int k = 5; k < 41; k++) scale = std::max(scale, fabs(ref[b * 41 + k]));
+                for (int k = 0; k < 41; k++) {
+                    if (!(g2[b * 41 + k] == g2[b * 41 + k])) nan2 = true;
+                    w2 = std::max(w2, fabs(g2[b * 41 + k] - ref[b * 41 + k]) / (k < 5 ? std::max(1.0, fabs(ref[b * 41 + k])) : scale));
+                }
+            }
+            printf("double-buffered vs tile kernels: worst relative difference %.3e%s   Sy %.3f Sw %.3f\n", w2, nan2 ? "  NaN" : "", g2[0], g2[1]);
+        }
+        rep("packed-box, double-buffered (1024 thr)", time_it([&] { hipLaunchKernelGGL((trx::affine_rot2_kernel<0>), dim3(trd.blocks_per_pair, B), dim3(1024), 0, 0, vol, theta, trd, partials, trd.blocks_per_pair); }, reps));
         rep("packed-box 16^3 tiles", time_it([&] { hipLaunchKernelGGL((trx::affine_rot_kernel<0>), dim3(trd.blocks_per_pair, B), dim3(512), 0, 0, vol, theta, trd, partials, trd.blocks_per_pair); }, reps));
     }
     return 0;
