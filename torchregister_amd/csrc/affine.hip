@@ -1913,7 +1913,11 @@ static ZGeom zs_launch_geom(const trx_volumes &v)
     if ((v.flags & TRX_FLAG_NO_ZSTREAM) || !zs_shape_ok<ZS64>(v)) return none;
     const ZGeom g = zs_geom<ZS64>(v);
     if (v.flags & TRX_FLAG_ZSTREAM) return g;
-    if ((long)g.blocks_per_pair * v.B < TRX_ZS_MIN_BLOCKS || g.planes_per_seg < TRX_ZS_MIN_PLANES) return none;
+    const long zb = (long)g.blocks_per_pair * v.B;
+    if (zb < TRX_ZS_MIN_BLOCKS || g.planes_per_seg < TRX_ZS_MIN_PLANES) return none;
+    // between one block per CU and a full round the streaming blocks share CUs unevenly; where the tile kernels fit ONE round of block
+    // slots they win that case (3 x 192^3: 62 us against 69), everywhere else measured the streaming body is ahead
+    if (zb > TRX_PERSISTENT_BLOCKS / 2 && zb < TRX_PERSISTENT_BLOCKS && (long)tile_geom<GeomA>(v).blocks_per_pair * v.B <= TRX_PERSISTENT_BLOCKS) return none;
     return g;
 }
 

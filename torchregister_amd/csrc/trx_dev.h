@@ -53,10 +53,11 @@
 #define TRX_FLAT_GRID 1             // 0: big batches launch (largest geometry) x (pairs) blocks like the small ones (measured alternative)
 #endif
 #ifndef TRX_ZS_MIN_BLOCKS
-#define TRX_ZS_MIN_BLOCKS 512   // the z-streaming body is offered to launches of at least this many of its blocks ...
+#define TRX_ZS_MIN_BLOCKS 200   // the z-streaming body is offered to launches of at least this many of its blocks (measured, profiles/r03f_zstream_small_batches.txt:
+                                // 216 blocks - 2 x 192^3 - gain 20 %, 128 blocks - 4 x 128^3 - lose a factor of two) ...
 #endif
 #ifndef TRX_ZS_MIN_PLANES
-#define TRX_ZS_MIN_PLANES 64    // ... of at least this many planes each (a block pays ~7 planes of pipeline fill)
+#define TRX_ZS_MIN_PLANES 32    // ... of at least this many planes each (a block pays ~7 planes of pipeline fill; zs_geom never cuts segments shorter)
 #endif
 #ifndef TRX_SWP
 #define TRX_SWP 1   // software pipeline of the gather: LDS reads of row j+1 issued before the arithmetic of row j (0: at use)
