@@ -47,8 +47,8 @@ def smooth_flow_gpu(shape, amp=1.0):
 def test_config4_share_b8_256_vs_oracle_and_singles(eng):
     """B = 8 pairs of 256^3, affine + NCC, one launch (bench.py's workload).  (a) two of the eight against the C oracle in fp64 (loss
     2e-5 rel, dL/dtheta 2e-4 of its maximum or twice the oracle's own fp32-vs-fp64 gap); (b) a pair's result does not depend on its
-    slot in the batch (bit for bit, pairs permuted); (c) the batch equals eight single-pair launches to fp32 rounding (a single
-    pair splits its columns differently, so its partial sums are added in another order); (d) three Adam iterations of the batch
+    slot in the batch (bit for bit, pairs permuted); (c) the batch equals eight single-pair launches to the fp32 floors (a single
+    pair splits its columns differently and may run another kernel body); (d) three Adam iterations of the batch
     stay bit-for-bit reproducible."""
     shape = (256, 256, 256)
     B = 8
@@ -82,9 +82,11 @@ def test_config4_share_b8_256_vs_oracle_and_singles(eng):
         s1 = eng.AffineSolver(mov[b:b + 1], tgt[b:b + 1], mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th[b:b + 1], capacity=1)
         s1.run(1)
         torch.cuda.synchronize()
-        assert abs(s1.losses[0, 0].item() - s.losses[b, 0].item()) <= 5e-6 * max(1.0, abs(s.losses[b, 0].item()))   # (the NCC loss is 100 (1 - ncc))
+        # a single pair may run another kernel body than the batch (the z-streaming body in 8 z segments, or a tile geometry, where the batch
+        # streams whole columns): the bars are the fp32 floors between bodies (tests/fuzz_zstream.py: body vs tiles), not a summation-order bar
+        assert abs(s1.losses[0, 0].item() - s.losses[b, 0].item()) <= 2e-5 * max(1.0, abs(s.losses[b, 0].item()))   # (the NCC loss is 100 (1 - ncc))
         gb = s.grad[b, :12]
-        assert torch.max(torch.abs(s1.grad[0, :12] - gb)).item() <= 2e-5 * gb.abs().max().item()
+        assert torch.max(torch.abs(s1.grad[0, :12] - gb)).item() <= 2e-4 * gb.abs().max().item()
     # (d)
     runs = []
     for _ in range(2):
