@@ -86,7 +86,7 @@ def test_more_argument_validation_without_gpu():
     assert lib.trx_lncc_workspace_bytes(4, 1, 8, 8, 8) == 0
     assert lib.trx_lncc_workspace_bytes(2, 1, 3, 8, 8) == 0               # 2-D needs D == 1
     n = lib.trx_lncc_workspace_bytes(3, 2, 8, 8, 8)
-    assert n >= 4 * 2 * 512 * 4
+    assert n >= 3 * 2 * 512 * 4                                            # three intermediate fields of fp32 per voxel
     args = (P(16), P(16), 3, 2, 8, 8, 8)
     assert lib.trx_lncc_loss_grad(*args, 9, 1.0, 1e-5, P(16), P(16), P(16), n - 1, None) == -3
     assert lib.trx_lncc_loss_grad(*args, 4, 1.0, 1e-5, P(16), P(16), P(16), n, None) == -1     # even window
