@@ -118,3 +118,30 @@ def test_zstream_default_choice_at_headline_share(eng):
         assert abs(s.losses[i, 0].item() - total) <= 2e-5 * max(1.0, abs(total))
         assert np.max(np.abs(s.grad[i, :12].cpu().numpy().reshape(3, 4) - dth)) <= 2e-4 * np.max(np.abs(dth))
     assert torch.equal(s.losses[0], s.losses[2]) and torch.equal(s.grad[1], s.grad[3])   # slot independence, bit for bit
+
+
+@pytest.mark.parametrize("B", [64, 65])
+def test_largest_flat_grid_batch_and_the_first_classic_one(eng, B):
+    """64 pairs is the largest batch the flat persistent grid takes (per-pair choices live in one wave's lanes), 65 the first that goes
+    back to the (blocks, pairs) grid: both against single-pair launches of a few of their pairs (fp32 floors between bodies) and with
+    per-pair bodies mixed in the batch (every fourth pair far from the identity)."""
+    shape = (64, 64, 64)
+    base_t = [ph.blobs(shape, 900 + i) for i in range(4)]
+    base_m = [ph.blobs(shape, 950 + i) for i in range(4)]
+    tgt = torch.cat([base_t[i % 4] for i in range(B)])
+    mov = torch.cat([base_m[(i + i // 4) % 4] for i in range(B)])
+    ths = [near_identity(i, 0.25 if i % 4 == 3 else 4e-3 + 1e-4 * i) for i in range(B)]
+    th = torch.stack([torch.tensor(t, dtype=torch.float32) for t in ths])
+    s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(w_ncc=1.0, w_mse=0.2), lr=0.0, init=th, capacity=1)
+    s.run(1)
+    torch.cuda.synchronize()
+    rows = s.rows_used().tolist()
+    assert len(set(rows)) > 1, rows                       # streaming pairs and tile pairs in one launch
+    assert torch.isfinite(s.losses[:, 0]).all() and torch.isfinite(s.grad).all()
+    for b in (0, 3, B // 2, B - 2, B - 1):
+        s1 = eng.AffineSolver(mov[b:b + 1].cuda(), tgt[b:b + 1].cuda(), mode="affine", loss=eng.LossSpec(w_ncc=1.0, w_mse=0.2), lr=0.0, init=th[b:b + 1], capacity=1)
+        s1.run(1)
+        torch.cuda.synchronize()
+        assert abs(s1.losses[0, 0].item() - s.losses[b, 0].item()) <= 2e-5 * max(1.0, abs(s.losses[b, 0].item())), b
+        gb = s.grad[b, :12]
+        assert torch.max(torch.abs(s1.grad[0, :12] - gb)).item() <= 2e-4 * gb.abs().max().item(), b
