@@ -298,16 +298,18 @@ __global__ __launch_bounds__(TRX_BLOCK) void lncc_finalize_kernel(const float *_
     if (tid == 0) loss[b] = (float)((double)alpha * (1.0 - red[0] / nvox));
 }
 
-// z segments per column: enough blocks to fill the block slots, each segment at least 32 planes deep (it re-reads 2R halo planes).
-static int lncc_zsplit(int nd, int B, int D, int H, int W)
+// z segments per column: enough blocks to fill `want` block slots, each segment at least 32 planes deep (it re-reads 2R halo planes).
+static int lncc_zsplit(int nd, int B, int D, int H, int W, long want)
 {
     if (nd == 2) return 1;
     const long cols = (long)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * B;
-    const long want = TRX_LNCC_TWO_ROWS ? 768 : 1024;   // block slots (two-row version: three 256-thread blocks per CU, see above)
     long z = (want + cols - 1) / cols;
     if (z > D / 32) z = D / 32;
     return (int)(z < 1 ? 1 : z);
 }
+// block slots of the register builds: windows 3 and 5 fit four 256-thread blocks per CU (116 / 106 VGPRs under __launch_bounds__(256, 4),
+// no scratch; 4 x 35 KB of LDS), windows 7 and 9 three (the z ring: 2 x 9 x 5 registers) or two
+constexpr long kLnccSlots4 = 1024, kLnccSlots3 = TRX_LNCC_TWO_ROWS ? 768 : 1024;
 
 template <int R, int MW>
 static int launch_lncc_mw(const float *target, const float *warped, int nd, int B, int D, int H, int W, float alpha, float eps, float *loss, float *grad,
@@ -332,7 +334,9 @@ template <int R>
 static int launch_lncc(const float *target, const float *warped, int nd, int B, int D, int H, int W, float alpha, float eps, float *loss, float *grad,
                        float *fields, float *partials, hipStream_t s)
 {
-    const int zsplit = lncc_zsplit(nd, B, D, H, W);   // the same split for every window: 768 block slots (measured with the three-blocks-per-CU build; the workspace is sized for it)
+    if (TRX_LNCC_TWO_ROWS && R <= 2)   // small windows: the four-blocks-per-CU build, whatever the batch (8 x 256^3: 1024 columns resident in one round)
+        return launch_lncc_mw<R, 4>(target, warped, nd, B, D, H, W, alpha, eps, loss, grad, fields, partials, lncc_zsplit(nd, B, D, H, W, kLnccSlots4), s);
+    const int zsplit = lncc_zsplit(nd, B, D, H, W, kLnccSlots3);
     if (TRX_LNCC_TWO_ROWS && R >= 3 && zsplit > 1)   // a small batch of a wide window: the three-blocks-per-CU build (see the note on registers above)
         return launch_lncc_mw<R, 3>(target, warped, nd, B, D, H, W, alpha, eps, loss, grad, fields, partials, zsplit, s);
     return launch_lncc_mw<R, 1>(target, warped, nd, B, D, H, W, alpha, eps, loss, grad, fields, partials, zsplit, s);
@@ -340,7 +344,7 @@ static int launch_lncc(const float *target, const float *warped, int nd, int B, 
 
 static size_t lncc_partials_bytes(int nd, int B, int D, int H, int W)
 {
-    const size_t nb = (size_t)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * lncc_zsplit(nd, B, D, H, W);
+    const size_t nb = (size_t)((W + kLX - 1) / kLX) * ((H + kLY - 1) / kLY) * lncc_zsplit(nd, B, D, H, W, kLnccSlots4);   // the finest split any window uses
     return ((size_t)B * nb * sizeof(float) + 255) & ~(size_t)255;
 }
 
