@@ -134,3 +134,44 @@ def test_two_processes_ipc_mailboxes_equal_whole_volume(eng, optimizer, lr, smoo
         assert torch.allclose(p["losses"], whole.losses.cpu(), rtol=1e-5, atol=1e-6)
     assert torch.equal(parts[0]["losses"], parts[1]["losses"])
     assert torch.max(torch.abs(flow - whole.flow.cpu())).item() <= 1e-5 * max(1.0, whole.flow.abs().max().item())
+
+
+def test_peer_early_stop_and_single_rank(eng):
+    """Early stop over the peer transport: the whole-volume loss is bit-identical on every rank (rank-order sum), so every slab stops at the
+    same iteration without exchanging anything else - as the un-partitioned solver does; and a world of one rank (its own mailbox) equals
+    the plain solver bit for bit."""
+    shape = (30, 24, 32)
+    tgt, mov = ph.blobs(shape, 401).cuda(), ph.blobs(shape, 402).cuda()
+    iters = 12
+    kw = dict(loss=eng.LossSpec(w_ncc=1.0), optimizer="sgd", lr=2.0, capacity=iters)
+    probe = eng.FlowSolver(mov, tgt, **kw)
+    probe.run(iters)
+    torch.cuda.synchronize()
+    crit = 0.5 * (probe.losses[0, 4] + probe.losses[0, 5]).item()          # met by iteration 5's loss
+    whole = eng.FlowSolver(mov, tgt, stop_crit=crit, **kw)
+    whole.run(iters)
+    bounds = [0, 13, 30]
+    boxes = [eng.SlabPeers.allocate(mov.device, shape[1], shape[2], 2) for _ in range(2)]
+    slabs = [eng.SlabFlowSolver(mov, tgt[:, :, a:b].contiguous(), a, stop_crit=crit, peers=eng.SlabPeers(r, boxes, shape[1], shape[2]), **kw)
+             for r, (a, b) in enumerate(zip(bounds[:-1], bounds[1:]))]
+    eng.run_slabs_lockstep(slabs, iters)
+    torch.cuda.synchronize()
+    n = int(whole.step[0].item())
+    for s in slabs:
+        s.peers.check()
+        assert int(s.step_t.item()) == int(slabs[0].step_t.item())
+    k = int(slabs[0].step_t.item())
+    for s in slabs:
+        assert torch.equal(s.losses[0, :k], slabs[0].losses[0, :k]) and torch.isnan(s.losses[0, k:]).all()   # nothing recorded after the stop
+    assert 0 < k < iters
+    assert k == n
+    assert torch.allclose(slabs[0].losses[0, :k], whole.losses[0, :k], rtol=1e-5, atol=1e-6)
+    # one rank
+    one_box = [eng.SlabPeers.allocate(mov.device, shape[1], shape[2], 1)]
+    one = eng.SlabFlowSolver(mov, tgt, 0, peers=eng.SlabPeers(0, one_box, shape[1], shape[2]), **kw)
+    one.run(iters)
+    plain = eng.SlabFlowSolver(mov, tgt, 0, **kw)
+    plain.run(iters)
+    torch.cuda.synchronize()
+    one.peers.check()
+    assert torch.equal(one.losses, plain.losses) and torch.equal(one.flow, plain.flow)
