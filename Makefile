@@ -5,7 +5,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := torchregister_amd/csrc
 SRCS    := $(CSRC)/api.hip $(CSRC)/affine.hip $(CSRC)/flow.hip $(CSRC)/lncc.hip $(CSRC)/kde.hip $(CSRC)/peer.hip
-HDRS    := $(CSRC)/trx_common.h $(CSRC)/trx_dev.h $(CSRC)/affine_zstream.h include/trx.h
+HDRS    := $(CSRC)/trx_common.h $(CSRC)/trx_dev.h $(CSRC)/affine_zstream.h $(CSRC)/affine_eft.h include/trx.h
 OBJS    := $(SRCS:$(CSRC)/%.hip=build/%.o)
 LIB     := torchregister_amd/lib/libtrx.so
 # -fno-slp-vectorize: on gfx950 v_pk_*_f32 is no faster than two scalar VALU ops, and the SLP

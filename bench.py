@@ -62,6 +62,27 @@ def make_batch(rank, device, size=SIZE, pairs=PAIRS_PER_GPU):
     return mov, tgt
 
 
+def rot(ax, ay, az):
+    import math
+    cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+    rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return rz @ ry @ rx
+
+
+def pose_rot(device, pairs=PAIRS_PER_GPU):
+    """config.value_rot: theta = R(0.5, 0.4, 0.3) diag(1.05, 0.95, 1.02) | (0.01, -0.02, 0.015), for every pair."""
+    th = torch.cat([rot(0.5, 0.4, 0.3).float() @ torch.diag(torch.tensor([1.05, 0.95, 1.02])), torch.tensor([[0.01], [-0.02], [0.015]])], dim=1)
+    return th.to(device)[None].expand(pairs, 3, 4).contiguous()
+
+
+def pose_rigid_randinit(device, pairs=PAIRS_PER_GPU):
+    """config.value_rigid_randinit: the reference's initial rigid pose, torch.manual_seed(0); torch.rand(6) (ref:utils.py:316-321)."""
+    torch.manual_seed(0)
+    return torch.rand(6)[None].expand(pairs, 6).contiguous().to(device)
+
+
 def _cpu_loop(budget_s, max_iters):
     """Reference loop re-composed from torch CPU ops (oracle/compose.py) on ONE 256^3 pair; returns (iterations, seconds)."""
     from oracle import compose
@@ -238,30 +259,20 @@ def main():
         fence()
         return time.perf_counter() - t
 
-    import math
-    def rot(ax, ay, az):
-        cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
-        rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
-        ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
-        rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
-        return rz @ ry @ rx
     pose_steps = min(args.steps, 100)
     extra = {"value_theta_star": None, "value_rot": None, "value_rigid_randinit": None, "flow_value": None}
     # (a) theta* itself - the pose the headline run converges to; (b) R(0.5, 0.4, 0.3) x anisotropic scale; (c) the rigid mode from the
     # reference's own initial pose: torch.manual_seed(0); torch.rand(6) radians / tanh-translations (ref:utils.py:316-321)
     th_star = torch.tensor(THETA_STAR, device=device)[None].expand(PAIRS_PER_GPU, 3, 4).contiguous()
-    th_rot = torch.cat([rot(0.5, 0.4, 0.3).float() @ torch.diag(torch.tensor([1.05, 0.95, 1.02])), torch.tensor([[0.01], [-0.02], [0.015]])], dim=1)
-    th_rot = th_rot.to(device)[None].expand(PAIRS_PER_GPU, 3, 4).contiguous()
+    th_rot = pose_rot(device)
     for key, th0 in (() if args.no_pose_legs else (("value_theta_star", th_star), ("value_rot", th_rot))):
         sv = tr.AffineSolver(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer=args.optimizer, lr=1e-6, init=th0,
                              capacity=pose_steps + 40)
         extra[key] = world * PAIRS_PER_GPU * pose_steps / max_over_ranks(timed_run(sv, pose_steps), device)
         del sv
     if not args.no_pose_legs:
-        torch.manual_seed(0)
-        pose0 = torch.rand(6)
         sv = tr.AffineSolver(mov, tgt, mode="rigid", loss=tr.LossSpec(w_ncc=1.0), optimizer=args.optimizer, lr=1e-6,
-                             init=pose0[None].expand(PAIRS_PER_GPU, 6).contiguous().to(device), capacity=pose_steps + 40)
+                             init=pose_rigid_randinit(device), capacity=pose_steps + 40)
         extra["value_rigid_randinit"] = world * PAIRS_PER_GPU * pose_steps / max_over_ranks(timed_run(sv, pose_steps), device)
         del sv
         # BASELINE.json configs[2]: one 256^3 pair, direct flow field + NCC + smoothness regulariser, Adam, 100 iterations (iterations / s)

@@ -1,0 +1,110 @@
+// Development harness for the exact-footprint F1 body (not shipped): its 41 sums against the tile kernels' (GeomR / GeomRD through the fused
+// step kernel) at a rotated pose, and hipEvent timing of both.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize tools/ebench.hip -o build/ebench
+//   build/ebench [B] [S] [ax ay az] [scale] [reps] [only]
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../torchregister_amd/csrc/affine.hip"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+template <typename F>
+static float time_it(F f, int reps)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < (reps >= 50 ? 100 : 3); i++) f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; i++) f();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1000.f / reps;
+}
+
+int main(int argc, char **argv)
+{
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    const int B = argc > 1 ? atoi(argv[1]) : 8, S = argc > 2 ? atoi(argv[2]) : 256;
+    const double ax = argc > 3 ? atof(argv[3]) : 0.5, ay = argc > 4 ? atof(argv[4]) : 0.4, az = argc > 5 ? atof(argv[5]) : 0.3;
+    const double scale = argc > 6 ? atof(argv[6]) : 1.0;
+    const int reps = argc > 7 ? atoi(argv[7]) : 50;
+    const bool only = argc > 8;   // profiling runs: only the exact-footprint kernel
+    const size_t nvox = (size_t)S * S * S, n = nvox * B;
+    std::vector<float> h(n);
+    srand(1);
+    for (size_t i = 0; i < n; i++) h[i] = (float)rand() / RAND_MAX;
+    float *mov, *tgt, *theta, *partials;
+    CK(hipMalloc(&mov, n * 4)); CK(hipMalloc(&tgt, n * 4));
+    CK(hipMemcpy(mov, h.data(), n * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < n; i++) h[i] = (float)rand() / RAND_MAX;
+    CK(hipMemcpy(tgt, h.data(), n * 4, hipMemcpyHostToDevice));
+    std::vector<float> th(B * 12);
+    {
+        const double Rx[9] = {1, 0, 0, 0, cos(ax), -sin(ax), 0, sin(ax), cos(ax)}, Ry[9] = {cos(ay), 0, sin(ay), 0, 1, 0, -sin(ay), 0, cos(ay)},
+                     Rz[9] = {cos(az), -sin(az), 0, sin(az), cos(az), 0, 0, 0, 1};
+        const double sc[3] = {1.05 * scale, 0.95 * scale, 1.02 * scale};
+        double T[9], Rm[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { T[i * 3 + j] = 0; for (int k = 0; k < 3; k++) T[i * 3 + j] += Rz[i * 3 + k] * Ry[k * 3 + j]; }
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Rm[i * 3 + j] = 0; for (int k = 0; k < 3; k++) Rm[i * 3 + j] += T[i * 3 + k] * Rx[k * 3 + j]; }
+        for (int b = 0; b < B; b++) for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) th[b * 12 + i * 4 + j] = (float)(Rm[i * 3 + j] * sc[j]); th[b * 12 + i * 4 + 3] = 0.01f * (i + 1) + 0.003f * b; }
+    }
+    CK(hipMalloc(&theta, B * 12 * 4));
+    CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
+    float *tab;
+    CK(hipMalloc(&tab, 3 * S * 4));
+    hipLaunchKernelGGL(trx::fill_tables_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, tab, S, S, S);
+    trx_volumes vol = {mov, tgt, nvox, nvox, 3, B, S, S, S, tab, tab + S, tab + 2 * S, 0};
+    const size_t prow = 8192;
+    CK(hipMalloc(&partials, (size_t)B * prow * 41 * 4));
+    const double alg = 8.0 * nvox;
+    auto rep = [&](const char *name, float us) { printf("%-40s %9.1f us/launch  %7.2f us/pair  %6.2f TB/s alg  frac %.3f\n", name, us, us / B, alg * B / us / 1e6, alg * B / us / 1e6 / 8.0); };
+    auto sums = [&](int rows) {
+        std::vector<float> hp((size_t)B * rows * 41);
+        CK(hipMemcpy(hp.data(), partials, hp.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<double> out((size_t)B * 41, 0.0);
+        for (int b = 0; b < B; b++) for (int r = 0; r < rows; r++) for (int k = 0; k < 41; k++) out[b * 41 + k] += hp[((size_t)b * rows + r) * 41 + k];
+        return out;
+    };
+    printf("B=%d S=%d R(%.2f, %.2f, %.2f) diag(1.05, .95, 1.02) x %.2f\n", B, S, ax, ay, az, scale);
+    const trx::TileGeom ta = trx::tile_geom<trx::GeomA>(vol), tr = trx::tile_geom<trx::GeomR>(vol), td = trx::tile_geom<trx::GeomD>(vol), trd = trx::tile_geom<trx::GeomRD>(vol);
+    const int gx = std::max(std::max(ta.blocks_per_pair, tr.blocks_per_pair), std::max(td.blocks_per_pair, trd.blocks_per_pair));
+    int *ru; CK(hipMalloc(&ru, B * 4));
+    std::vector<double> ref;
+    if (!only) {
+        CK(hipMemset(partials, 0, (size_t)B * prow * 41 * 4));
+        hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 1, td, trd, trx::ZGeom{}, ru, 0);
+        CK(hipDeviceSynchronize());
+        ref = sums(gx);
+        std::vector<int> hru(B); CK(hipMemcpy(hru.data(), ru, B * 4, hipMemcpyDeviceToHost));
+        printf("tile kernels: %d rows used of %d\n", hru[0], gx);
+    }
+    CK(hipMemset(partials, 0, (size_t)B * prow * 41 * 4));
+    hipLaunchKernelGGL((trx::affine_eft_kernel<0>), dim3(trd.blocks_per_pair, B), dim3(512), 0, 0, vol, theta, trd, partials);
+    CK(hipDeviceSynchronize());
+    if (!only) {
+        const std::vector<double> got = sums(trd.blocks_per_pair);
+        double worst = 0; int wk = -1, wb = -1;
+        bool nan = false;
+        for (int b = 0; b < B; b++) {
+            double scl = 0;
+            for (int k = 5; k < 41; k++) scl = std::max(scl, fabs(ref[b * 41 + k]));
+            for (int k = 0; k < 41; k++) {
+                if (!(got[b * 41 + k] == got[b * 41 + k])) nan = true;
+                const double e = fabs(got[b * 41 + k] - ref[b * 41 + k]) / (k < 5 ? std::max(1.0, fabs(ref[b * 41 + k])) : scl);
+                if (e > worst) { worst = e; wk = k; wb = b; }
+            }
+        }
+        printf("exact-footprint vs tile kernels: worst relative difference of the 41 sums %.3e (sum %d, pair %d)%s   Sw %.4f / %.4f  Syw %.4f / %.4f  S[5] %.5f / %.5f\n", worst, wk, wb,
+               nan ? "  NaN" : "", got[1], ref[1], got[4], ref[4], got[5], ref[5]);
+    }
+    rep("exact-footprint 16^3 tiles", time_it([&] { hipLaunchKernelGGL((trx::affine_eft_kernel<0>), dim3(trd.blocks_per_pair, B), dim3(512), 0, 0, vol, theta, trd, partials); }, reps));
+    if (only) return 0;
+    rep("tile kernels, classic grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, trx::ZGeom{}, ru, 0); }, reps));
+    rep("tile kernels, flat grid 512", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(512, 1), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, trx::ZGeom{}, ru, gx); }, reps));
+    rep("exact-footprint 16^3 tiles (again)", time_it([&] { hipLaunchKernelGGL((trx::affine_eft_kernel<0>), dim3(trd.blocks_per_pair, B), dim3(512), 0, 0, vol, theta, trd, partials); }, reps));
+    return 0;
+}

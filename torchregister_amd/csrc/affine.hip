@@ -1124,6 +1124,7 @@ __global__ __launch_bounds__(GeomP::Threads, TRX_TILE_MIN_WAVES) void affine_til
 
 #pragma clang diagnostic pop
 #include "affine_zstream.h"   // z-streaming F1 body for transforms near the identity: the fifth per-pair choice of the step kernels
+#include "affine_eft.h"       // exact-footprint F1 body for rotated transforms: the sixth per-pair choice of the step kernels
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"

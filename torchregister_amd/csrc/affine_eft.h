@@ -1,0 +1,569 @@
+// EXACT-FOOTPRINT variant of the fused F1 pass (3-D) for ROTATED transforms.  Included by affine.hip inside namespace trx.
+//
+// Why a third kernel family.  Counters of the tile kernels at theta = R(0.5, 0.4, 0.3) diag(1.05, 0.95, 1.02), 8 x 256^3
+// (profiles/r04a_pose_pmc.txt): 620 us per launch, 46.5 M L2 requests of 128 B = 5.5 x the algorithmic bytes, 41 % of them misses
+// (HBM side 2.4 GB = 2.2 x), waves parked 44 % of their cycles.  A rotated 16 x 16 x 8 tile stages the AXIS-ALIGNED bounding box of its
+// pre-image (5.3 floats per voxel, of which a third is read), as a burst that nothing overlaps inside the block.  Here:
+//   * a block stages what the tile can TOUCH: per source row (y, z) of the pre-image the x-window [wlo, whi] that any voxel of the tile may
+//     read, whatever the fractional position of the tile's corner - a function of theta and the tile shape only (the map is affine), so the
+//     PLAN (row windows, their packing, which thread fetches which 16 bytes) is made once per block and every tile of the column re-uses it
+//     with its own integer origin R = floor(image of the tile's corner).  ~2.0 floats per voxel for a general rotation of a 16^3 tile;
+//   * rows are packed back to back in LDS in 16-byte granules that start AT wlo (unaligned 16-byte global loads: no alignment slack), and a
+//     row table E[(y, z)] = byte address of x = 0 of that row turns the gather's address into  E + 4 floor(x)  - two more LDS reads and two
+//     more vector instructions per voxel than a dense box, for a third of its bytes;
+//   * ~33 KB per tile instead of 78.6 KB, so a block holds TWO buffers: the granules of tile t + 1 travel global -> VGPR -> the other buffer
+//     while tile t is gathered (two batches per tile, 20 staging registers), one barrier per tile.
+// Per-voxel arithmetic is tile_body's (same coordinates up to the rounding of the origin shift, same accumulators, same partial-row layout
+// as GeomRD: 16 x 16 x 16 tiles, column (x-tile, z-tile) walking y), so the finalise kernel and the tests see another choice of the same pass.
+
+#ifndef TRX_EF_DBG
+#define TRX_EF_DBG 0   // development ablation (tools/ebench.hip): bits: 1 = no staging loads, 2 = no target loads, 4 = no gather
+#endif
+#ifndef TRX_EF_EPS
+#define TRX_EF_EPS 0.05f   // slack of every window bound: fp32 rounding of the coordinates + non-uniformity of ATen's coordinate tables
+#endif
+
+struct ECfg {
+    static constexpr int TX = 16, TY = 16, TZ = 16, Threads = 512, Waves = 8, NH = 2, Rows = 8;
+    static constexpr int K = 5;              // granule slots (16 B) a thread fetches per tile
+    static constexpr int KA = 3;             // ... of which the first batch
+    static constexpr int NY = 32, NZ = 32;   // rows of the plan: at most NY x NZ (any rotation of the tile with a zoom up to ~1.1)
+    static constexpr int TP = 40;            // row table: entry (dy - dy0) + TP (dz - dz0).  The pitch is 8 mod 32 banks: the rows a half-wave
+                                             // looks up lie in a patch of a few y by a few z, which a pitch of 32 would fold onto one bank each
+    static constexpr int GCap = 2304;        // granule slots of one buffer (36 KB)
+    static constexpr int BufFloats = GCap * 4, TabInts = TP * NZ;
+    static constexpr int ReduceScratch = Waves * 16 * 65 + Waves * 16;
+    static constexpr int OrgInts = 64 * 8;   // origins of 64 tiles of the column (8 ints each)
+    static constexpr int Alloc = 2 * BufFloats + TabInts + OrgInts;   // 20224 floats = 79.0 KB: two blocks per CU
+    static_assert(Alloc >= ReduceScratch && K * Threads >= GCap && NY * NZ == 2 * Threads && TabInts + 2 * Waves <= BufFloats, "geometry");
+};
+
+// theta -> slope matrix of the voxel-space map s = b + A q (q = voxel offset inside a tile), its inverse, the extent of a tile's pre-image
+struct EfMap {
+    float A[3][3], N[3][3], ext_lo[3], ext_hi[3];
+    bool ok;
+};
+__device__ __forceinline__ EfMap ef_map(const float *__restrict__ th, float fD, float fH, float fW)
+{
+    EfMap m;
+    const float A[3][3] = {{th[0], th[1] * fW / fH, th[2] * fW / fD}, {th[4] * fH / fW, th[5], th[6] * fH / fD}, {th[8] * fD / fW, th[9] * fD / fH, th[10]}};
+    const float c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2], c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const float det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { m.A[c][a] = A[c][a]; amax = fmaxf(amax, fabsf(A[c][a])); }
+    m.ok = (fabsf(det) > 0.05f) && (amax < 4.0f);   // NaN compares false
+    const float r = 1.0f / det;
+    m.N[0][0] = c00 * r; m.N[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * r; m.N[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * r;
+    m.N[1][0] = c01 * r; m.N[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * r; m.N[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * r;
+    m.N[2][0] = c02 * r; m.N[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * r; m.N[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * r;
+    const float ex = (float)(ECfg::TX - 1);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        m.ext_lo[c] = m.ext_hi[c] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const float e = A[c][a] * ex; m.ext_lo[c] += fminf(e, 0.f); m.ext_hi[c] += fmaxf(e, 0.f); }
+    }
+    return m;
+}
+// Rows of the plan: dy = dy0 .. dy0 + ny - 1 relative to R_y = floor(b_y), likewise z; x windows lie inside [xmin, xmax].
+struct EfDims {
+    int dy0, dz0, ny, nz, xmin, xmax;
+    bool ok;
+};
+__device__ __forceinline__ EfDims ef_dims(const EfMap &m)
+{
+    EfDims d;
+    const float e = TRX_EF_EPS;
+    d.dy0 = (int)floorf(m.ext_lo[1] - e); d.ny = (int)floorf(m.ext_hi[1] + e) + 3 - d.dy0;
+    d.dz0 = (int)floorf(m.ext_lo[2] - e); d.nz = (int)floorf(m.ext_hi[2] + e) + 3 - d.dz0;
+    d.xmin = (int)floorf(m.ext_lo[0] - 2.f * e); d.xmax = (int)floorf(m.ext_hi[0] + 2.f * e) + 2;
+    d.ok = m.ok && d.ny <= ECfg::NY && d.nz <= ECfg::NZ && d.ny > 0 && d.nz > 0 && (d.xmax - d.xmin) < 120;
+    return d;
+}
+// x-window of relative row (dy, dz): every cell (x, dy, dz) - relative to R = floor(b) - that the 2 x 2 x 2 neighbourhood of ANY voxel of the
+// tile can touch for ANY fractional part of b.  Voxel q touches row dy iff floor(bf_y + v_y) + {0, 1} contains dy for some bf_y in [0, 1),
+// v = A q, i.e. v_y in (dy - 2, dy + 1); its x cells are floor(bf_x + v_x) + {0, 1}, inside [floor(v_x), floor(v_x) + 2].  Over the real box
+// q = N v in [0, 15]^3 each axis bounds v_x given the (v_y, v_z) rectangle; the three bounds are taken independently (a superset: +10 % of
+// granules against the exact union, tools/eft_plan_check.py).  Returns the granule count (0: the row is never touched).
+__device__ __forceinline__ int ef_row_window(const EfMap &m, int dy, int dz, int &wlo)
+{
+    const float e = TRX_EF_EPS, hw = 1.5f + e, yc = (float)dy - 0.5f, zc = (float)dz - 0.5f, ex = (float)(ECfg::TX - 1);
+    float lo = m.ext_lo[0] - e, hi = m.ext_hi[0] + e;
+    bool feasible = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float gc = m.N[a][1] * yc + m.N[a][2] * zc, gh = (fabsf(m.N[a][1]) + fabsf(m.N[a][2])) * hw;
+        const float l = -gc - gh, h = ex - gc + gh, n = m.N[a][0];
+        if (fabsf(n) < 1.0e-6f) {
+            feasible = feasible && (l <= 1.0e-3f) && (h >= -1.0e-3f);
+        } else {
+            const float r = 1.0f / n;
+            const float a0 = l * r, a1 = h * r;
+            lo = fmaxf(lo, fminf(a0, a1)); hi = fminf(hi, fmaxf(a0, a1));
+        }
+    }
+    if (!feasible || !(lo <= hi)) { wlo = 0; return 0; }
+    wlo = (int)floorf(lo - e);
+    const int whi = (int)floorf(hi + e) + 2;
+    return (whi - wlo + 4) >> 2;
+}
+
+// Granule count of the plan of this theta, by the whole block (512 threads, two rows each): the per-pair test of dual_choice.
+// `scratch`: 8 ints of LDS.  Ends with a barrier; the result is block-uniform.
+__device__ __forceinline__ int ef_plan_granules(const EfMap &m, const EfDims &d, int tid, int wave, int lane, int *scratch)
+{
+    int cnt = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int r = tid + h * ECfg::Threads, iy = r & (ECfg::NY - 1), iz = r >> 5;
+        int wlo;
+        if (iy < d.ny && iz < d.nz) cnt += ef_row_window(m, d.dy0 + iy, d.dz0 + iz, wlo);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    __syncthreads();   // (the scratch may still be read from a previous call)
+    if (lane == 0) scratch[wave] = cnt;
+    __syncthreads();
+    int g = 0;
+#pragma unroll
+    for (int w = 0; w < ECfg::Waves; w++) g += scratch[w];
+    return __builtin_amdgcn_readfirstlane(g);
+}
+// theta-only part of the offer (cheap, per lane): the plan's table fits and the map is well conditioned
+__device__ __forceinline__ bool ef_candidate(const float *__restrict__ th, float fD, float fH, float fW)
+{
+    const EfMap m = ef_map(th, fD, fH, fW);
+    return ef_dims(m).ok;
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+template <int MODE>
+__device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__restrict__ theta, const TileGeom &tg, float *__restrict__ partials,
+                                         float *lds, const int bx, const int by, const int rows_stride, const int wave_in)
+{
+    static_assert(MODE == 0 || MODE == 1 || MODE == 4, "step kernels and the moments pass");
+    using C = ECfg;
+    constexpr int NQ = (MODE == 0) ? 3 : (MODE == 4 ? 1 : 0);
+    constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 4 ? kNpMse : 5);
+    constexpr bool kGrad = MODE != 1;
+    constexpr int kRows = C::Rows, K = C::K, KA = C::KA;
+    const int b = by;
+    const int D = vol.D, H = vol.H, W = vol.W;
+    const float *__restrict__ th = uni_ptr(theta + (size_t)b * TRX_PSTRIDE);
+    const float *__restrict__ mov = uni_ptr(vol.moving + (size_t)b * vol.moving_stride);
+    const float *__restrict__ tgt = uni_ptr(vol.target + (size_t)b * vol.target_stride);
+    const float *__restrict__ xtab = uni_ptr(vol.xn), *__restrict__ ytab = uni_ptr(vol.yn), *__restrict__ ztab = uni_ptr(vol.zn);
+    const int lane = trx_lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(wave_in);
+    const int tid = wave * 64 + lane;
+    const int lx = tid & (C::TX - 1), lz = (tid / C::TX) & (C::TZ - 1), lh = wave / (C::Waves / C::NH);
+    const float fW = (float)W, fH = (float)H, fD = (float)D;
+    const float hW = 0.5f * fW, hH = 0.5f * fH, hD = 0.5f * fD;
+    const float t00 = th[0], t01 = th[1], t02 = th[2], t03 = th[3];
+    const float t10 = th[4], t11 = th[5], t12 = th[6], t13 = th[7];
+    const float t20 = th[8], t21 = th[9], t22 = th[10], t23 = th[11];
+    const float sx = uni(hW * t01), sy = uni(hH * (t11 - 1.0f)), sz = uni(hD * t21);
+
+    // column of this block (same order as tile_body: XCD-contiguous slabs of columns)
+    const int ncol = tg.ntx * tg.ntz;
+    const int yseg = bx / ncol, cb = bx - yseg * ncol;
+    int col = cb;
+    if ((ncol & 7) == 0) col = (cb & 7) * (ncol >> 3) + (cb >> 3);
+    const int X0 = (col % tg.ntx) * C::TX, Z0 = (col / tg.ntx) * C::TZ;
+    const int nx = min(C::TX, W - X0), nz = min(C::TZ, D - Z0);
+    const bool act = (lx < nx) && (lz < nz);
+    const int x = X0 + (act ? lx : 0), z = Z0 + (act ? lz : 0);
+    const float xn = xtab[x], zn = ztab[z];
+    const float base_x = unnorm<3>(xn, fW) + hW * fmaf(t00 - 1.0f, xn, fmaf(t02, zn, t03));
+    const float base_y = hH * fmaf(t10, xn, fmaf(t12, zn, t13));
+    const float base_z = unnorm<3>(zn, fD) + hD * fmaf(t20, xn, fmaf(t22 - 1.0f, zn, t23));
+    const float cxn = xtab[X0], czn = ztab[Z0];
+    const float corner_x = uni(unnorm<3>(cxn, fW) + hW * fmaf(t00 - 1.0f, cxn, fmaf(t02, czn, t03)));
+    const float corner_y = uni(hH * fmaf(t10, cxn, fmaf(t12, czn, t13)));
+    const float corner_z = uni(unnorm<3>(czn, fD) + hD * fmaf(t20, cxn, fmaf(t22 - 1.0f, czn, t23)));
+    const int ty_begin = yseg * tg.tiles_per_seg, ty_end = min((yseg + 1) * tg.tiles_per_seg, tg.nty);
+
+    // ---------------- the plan (position independent): rows, packing, row table, this thread's granules ----------------
+    const EfMap mp = ef_map(th, fD, fH, fW);
+    const EfDims dm = ef_dims(mp);
+    int *ilds = reinterpret_cast<int *>(lds);
+    int *tab = ilds + 2 * C::BufFloats;
+    int *desc = ilds + C::BufFloats;          // (prologue scratch in buffer 1) granule slot -> packed (iz, iy, x - xmin)
+    int *wtot = ilds;                         // (prologue scratch in buffer 0) 16 chunk totals
+    int cnt_r[2], wlo_r[2], pre_r[2];
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int r = tid + h * C::Threads, iy = r & (C::NY - 1), iz = r >> 5;
+        cnt_r[h] = 0; wlo_r[h] = 0;
+        if (dm.ok && iy < dm.ny && iz < dm.nz) cnt_r[h] = ef_row_window(mp, dm.dy0 + iy, dm.dz0 + iz, wlo_r[h]);
+        int p = cnt_r[h];   // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(p, o, 64);
+            if (lane >= o) p += t;
+        }
+        pre_r[h] = p;
+        if (lane == 63) wtot[h * C::Waves + wave] = p;
+    }
+    __syncthreads();
+    int G = 0;
+    {
+        int before[2] = {0, 0};
+#pragma unroll
+        for (int c = 0; c < 2 * C::Waves; c++) {
+            const int t = wtot[c];
+            if (c < wave) before[0] += t;
+            if (c < C::Waves + wave) before[1] += t;
+            G += t;
+        }
+        pre_r[0] += before[0] - cnt_r[0];   // exclusive: first granule slot of the row
+        pre_r[1] += before[1] - cnt_r[1];
+    }
+    G = __builtin_amdgcn_readfirstlane(G);
+    const bool plan_ok = dm.ok && G <= C::GCap && G > 0;
+    __syncthreads();   // wtot is read; buffer 0 may be written from here on
+    if (plan_ok) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int r = tid + h * C::Threads, iy = r & (C::NY - 1), iz = r >> 5;
+            // E = dword index of (x = 0) of this row inside a buffer; rows nobody touches point at granule 0 (never read)
+            tab[iz * C::TP + iy] = pre_r[h] * 4 - wlo_r[h];
+            for (int k = 0; k < cnt_r[h]; k++) desc[pre_r[h] + k] = (iz << 20) | (iy << 12) | ((wlo_r[h] + 4 * k - dm.xmin) << 2);
+        }
+    }
+    __syncthreads();
+    // this thread's granules: slot g = tid + 512 k; geo = (iz << 20) | (iy << 12) | ((x - xmin) << 2): row of the plan and x offset (bytes) from
+    // its corner (one register per granule; the byte offset inside the volume is re-formed per tile: iz (H W 4) + iy (W 4) + x 4)
+    int geo[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int g = tid + k * C::Threads;
+        geo[k] = (plan_ok && g < G) ? desc[g] : 0;
+    }
+    int w4_s, hw4_s;   // row / plane pitch of the volume in bytes, pinned in SGPRs (v_mad_u32_u24 operands)
+    asm("s_mov_b32 %0, %1" : "=s"(w4_s) : "s"(W * 4));
+    asm("s_mov_b32 %0, %1" : "=s"(hw4_s) : "s"(H * W * 4));
+    auto goff_of = [&](int pk) -> unsigned {
+        unsigned t0, t1, t2;
+        asm("v_and_b32 %0, 0xffc, %1" : "=v"(t0) : "v"(pk));
+        asm("v_bfe_u32 %0, %1, 12, 8" : "=v"(t1) : "v"(pk));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t2) : "v"(t1), "s"(w4_s), "v"(t0));
+        asm("v_lshrrev_b32 %0, 20, %1" : "=v"(t1) : "v"(pk));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t0) : "v"(t1), "s"(hw4_s), "v"(t2));
+        return t0;
+    };
+    __syncthreads();   // desc (buffer 1) is consumed
+
+    F1Acc acc;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc.AB[q][c] = (f2)(0.f);
+    acc.M01 = acc.M23 = (f2)(0.f);
+    acc.M4 = 0.f;
+    const int j0 = lh * kRows;
+    const unsigned toffb = (unsigned)((z * H + j0) * W + x) * 4u;
+    const unsigned lane7b = (unsigned)(lane & (kRows - 1)) * 4u;
+
+    if (plan_ok) {
+        typedef const __attribute__((address_space(3))) f2u *lds_f2;
+        typedef const __attribute__((address_space(3))) i2u *lds_i2;
+        // ---- per tile: integer origin R = floor(image of the tile's corner voxel), where the plan lies against the volume, byte offset of the
+        // plan's corner.  Computed for 64 tiles at a time, ONE TILE PER LANE, and fetched with v_readlane (a per-tile scalar load of the row
+        // table in front of everything it feeds was ~1 us of exposed latency per tile).
+        struct TileOrg { int rx, ry, rz; bool interior, outside; const char *base; int dP; };
+        int *org = ilds + 2 * C::BufFloats + C::TabInts;
+        auto lane_origins = [&](int ty_first) {   // (wave 0 writes; the caller's barrier publishes)
+            if (wave != 0) return;
+            const int ty = min(ty_first + lane, tg.nty - 1);
+            const float yn0 = ytab[ty * C::TY], yid0 = unnorm<3>(yn0, fH);
+            const float cx = fmaf(sx, yn0, corner_x), cy = yid0 + fmaf(sy, yn0, corner_y), cz = fmaf(sz, yn0, corner_z);
+            const bool sane = (fabsf(cx) < 1.0e6f) && (fabsf(cy) < 1.0e6f) && (fabsf(cz) < 1.0e6f);
+            const int rx = sane ? (int)floorf(cx) : -100000, ry = sane ? (int)floorf(cy) : -100000, rz = sane ? (int)floorf(cz) : -100000;
+            const int x0 = rx + dm.xmin, y0 = ry + dm.dy0, z0 = rz + dm.dz0;
+            const bool interior = (x0 >= 0) && (rx + dm.xmax + 3 < W) && (y0 >= 0) && (y0 + dm.ny <= H) && (z0 >= 0) && (z0 + dm.nz <= D);
+            // the plan's bounding box misses the volume: every sample of the tile is zero padding (nothing is staged or gathered)
+            const bool outside = (rx + dm.xmax < 0) || (x0 >= W) || (y0 + dm.ny <= 0) || (y0 >= H) || (z0 + dm.nz <= 0) || (z0 >= D);
+            int4 v;
+            v.x = rx; v.y = ry; v.z = rz;
+            v.w = outside ? 0 : (int)((((long long)z0 * H + y0) * W + x0) * 4);   // byte offset of the plan's corner (only dereferenced where inside the volume)
+            *reinterpret_cast<int4 *>(org + lane * 8) = v;
+            org[lane * 8 + 4] = (interior ? 1 : 0) | (outside ? 2 : 0);
+        };
+        auto tile_org = [&](int ty) -> TileOrg {
+            const int g = (ty - ty_begin) & 63;
+            const int4 v = *reinterpret_cast<const int4 *>(org + g * 8);
+            const int fl = org[g * 8 + 4];
+            TileOrg o;
+            o.rx = __builtin_amdgcn_readfirstlane(v.x); o.ry = __builtin_amdgcn_readfirstlane(v.y); o.rz = __builtin_amdgcn_readfirstlane(v.z);
+            o.dP = __builtin_amdgcn_readfirstlane(v.w);
+            const int f = __builtin_amdgcn_readfirstlane(fl);
+            o.interior = f & 1; o.outside = (f >> 1) & 1;
+            o.base = reinterpret_cast<const char *>(mov) + (o.interior ? (long long)o.dP : 0ll);
+            return o;
+        };
+        // ---- granule loads of one batch: ONE unconditional load per granule (a lane with nothing to fetch reads offset 0 of `mov`)
+        f4 stg[K];
+        unsigned fullmask = 0;   // boundary tiles: bit k = granule k lies wholly inside the volume, bit 8 + k = it straddles a face in x
+        auto issue_batch = [&](const TileOrg &o, int k0, int k1) {
+            const char *bs = uni_ptr(o.base);
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (k < k0 || k >= k1) continue;
+                int pk = geo[k];
+                asm volatile("" : "+v"(pk));   // (opaque: what is derived from it is re-formed per tile, not hoisted into registers that live across the walk)
+                unsigned off = goff_of(pk);
+                if (!o.interior) {
+                    const int gz = o.rz + dm.dz0 + (pk >> 20), gy = o.ry + dm.dy0 + ((pk >> 12) & 0xff), gx = o.rx + dm.xmin + ((pk & 0xfff) >> 2);
+                    const bool rowin = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H);
+                    const bool full = rowin && (gx >= 0) && (gx + 3 < W);
+                    const bool part = rowin && !full && (gx + 3 >= 0) && (gx < W);
+                    off = full ? (unsigned)((int)off + o.dP) : 0u;
+                    fullmask = (fullmask & ~(0x101u << k)) | (full ? (1u << k) : 0u) | (part ? (0x100u << k) : 0u);
+                }
+                if (TRX_EF_DBG & 1) { stg[k] = (f4)(0.5f); continue; }
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(stg[k]) : "v"(off), "s"(bs) : "memory");
+            }
+        };
+        // ---- after landing: boundary tiles zero what lies outside the volume (a granule that straddles a face in x is patched element by
+        // element: rare, behind a wave-uniform test); then the granules go to buffer `buf`
+        auto commit_batch = [&](const TileOrg &o, int buf, int k0, int k1) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (k < k0 || k >= k1) continue;
+                asm volatile("" : "+v"(stg[k]));
+                int tt = tid;
+                asm volatile("" : "+v"(tt));   // (opaque, as above)
+                const int g = tt + k * C::Threads;
+                if (!o.interior) {
+                    if (!((fullmask >> k) & 1u)) stg[k] = (f4)(0.f);
+                    const bool part = (fullmask >> (8 + k)) & 1u;
+                    if (__builtin_amdgcn_ballot_w64(part)) {
+                        if (part) {
+                            int pk = geo[k];
+                            asm volatile("" : "+v"(pk));
+                            const int gz = o.rz + dm.dz0 + (pk >> 20), gy = o.ry + dm.dy0 + ((pk >> 12) & 0xff), gx = o.rx + dm.xmin + ((pk & 0xfff) >> 2);
+                            const float *row = mov + ((size_t)gz * H + gy) * W;
+                            f4 v;
+                            v.x = ((unsigned)(gx + 0) < (unsigned)W) ? row[gx + 0] : 0.f;
+                            v.y = ((unsigned)(gx + 1) < (unsigned)W) ? row[gx + 1] : 0.f;
+                            v.z = ((unsigned)(gx + 2) < (unsigned)W) ? row[gx + 2] : 0.f;
+                            v.w = ((unsigned)(gx + 3) < (unsigned)W) ? row[gx + 3] : 0.f;
+                            stg[k] = v;
+                        }
+                    }
+                }
+                if (g < G) *reinterpret_cast<f4 *>(lds + buf * C::BufFloats + g * 4) = stg[k];
+            }
+        };
+        // ---- targets: ONE register per row, refilled in place - once row j of tile t is accumulated, tv[j] receives row j of tile t + 1 -
+        // and the row constants of a tile (lanes 0..7 of every wave hold yn of rows j0 .. j0 + 7)
+        auto issue_yn = [&](int ty, float &yn_l) {
+            const unsigned yoff = (unsigned)min(ty * C::TY + j0 + (int)(lane7b >> 2), H - 1) * 4u;   // (rows past the volume repeat the last one: never accumulated)
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(yn_l) : "v"(yoff), "s"(ytab) : "memory");
+        };
+        auto issue_target = [&](int ty, int j, float &tvj) {
+            const int Y0 = ty * C::TY;
+            const float *trow = tgt + (size_t)min(Y0 + j, H - 1 - j0) * W;   // (a row past the volume: any valid address; never accumulated)
+            if (TRX_EF_DBG & 2) { tvj = 1.f; return; }
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(tvj) : "v"(toffb), "s"(trow) : "memory");
+        };
+        // ---- gather of rows [ja, jb) of tile `ty` from buffer `buf`
+        auto gather_rows = [&](int ty, const TileOrg &o, int buf, float yn_l, float (&tv)[kRows], int ja, int jb, bool more) {
+            if (TRX_EF_DBG & 4) {
+                if (more) for (int j = ja; j < jb; j++) issue_target(ty + 1, j, tv[j]);
+                return;
+            }
+            const int Y0 = ty * C::TY, ny = min(C::TY, H - Y0);
+            // row terms of the coordinates, one row per lane (lanes 0..7), broadcast below: i = (per-thread base) + (row term)
+            const float px_l = sx * yn_l, py_l = unnorm<3>(yn_l, fH) + sy * yn_l, pz_l = sz * yn_l;
+            // coordinates relative to the plan's row origin: x to R_x, y / z to R + (dy0, dz0)
+            const float bxt = base_x - (float)o.rx, byt = base_y - (float)(o.ry + dm.dy0), bzt = base_z - (float)(o.rz + dm.dz0);
+            const int tab_s = (int)lds0 + 2 * C::BufFloats * 4;
+            int tp_s, bufdw_s;   // table pitch and the buffer's dword index inside the LDS array, pinned in SGPRs
+            asm("s_mov_b32 %0, %1" : "=s"(tp_s) : "i"(C::TP));
+            asm("s_mov_b32 %0, %1" : "=s"(bufdw_s) : "s"((int)(lds0 >> 2) + buf * C::BufFloats));
+            struct S1 { int e00, e01, e10, e11, xi; float fx, fy, fz; };
+            struct S2 { f2 r00, r01, r10, r11; float fx, fy, fz; };
+            auto stage1 = [&](int j) -> S1 {
+                const float ix = bxt + lane_bcast(px_l, j), iy = byt + lane_bcast(py_l, j), iz = bzt + lane_bcast(pz_l, j);
+                int t, ta;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(floor_to_int(iz)), "s"(tp_s), "v"(floor_to_int(iy)));
+                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ta) : "v"(t), "s"(tab_s));
+                S1 s;
+                const i2u ea = *(lds_i2)(unsigned)ta, eb = *(lds_i2)(unsigned)(ta + C::TP * 4);
+                s.e00 = ea.x; s.e01 = ea.y; s.e10 = eb.x; s.e11 = eb.y;
+                asm("v_add_u32 %0, %1, %2" : "=v"(s.xi) : "s"(bufdw_s), "v"(floor_to_int(ix)));   // dword index of x inside this buffer, before the row's E
+                s.fx = __builtin_amdgcn_fractf(ix); s.fy = __builtin_amdgcn_fractf(iy); s.fz = __builtin_amdgcn_fractf(iz);
+                return s;
+            };
+            auto stage2 = [&](const S1 &s) -> S2 {
+                int a00, a01, a10, a11;
+                asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a00) : "v"(s.xi), "v"(s.e00));
+                asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a01) : "v"(s.xi), "v"(s.e01));
+                asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a10) : "v"(s.xi), "v"(s.e10));
+                asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a11) : "v"(s.xi), "v"(s.e11));
+                S2 f;
+                f.r00 = *(lds_f2)(unsigned)a00; f.r01 = *(lds_f2)(unsigned)a01;
+                f.r10 = *(lds_f2)(unsigned)a10; f.r11 = *(lds_f2)(unsigned)a11;
+                f.fx = s.fx; f.fy = s.fy; f.fz = s.fz;
+                return f;
+            };
+            const int je = min(jb, ny - j0);   // rows of this half that exist (uniform)
+            // two rows in flight: the data reads of row j + 1 are issued before the arithmetic of row j (their table reads just before them);
+            // two named register sets taken in turns (a conditional `next = ...` made the compiler copy 11 registers per row)
+            auto consume = [&](const S2 &f, int j) {
+                const Samp3 sm = lerp3_pairs<kGrad>(f.r00, f.r01, f.r10, f.r11, f.fx, f.fy, f.fz);
+                if (j < je) f1_accumulate_pk<MODE>(sm, tv[j], lane_bcast(yn_l, j), acc);   // (uniform: rows of the last, partial tile)
+                if (more) issue_target(ty + 1, j, tv[j]);
+            };
+            static_assert(kRows / 2 == 4, "four rows per call");
+            // (a third row in flight - table reads of row j + 2 - was measured: 473 against 471 us per 8 x 256^3 launch, for 4 more registers)
+            S2 fa = stage2(stage1(ja));
+            S2 fb = stage2(stage1(ja + 1));
+            consume(fa, ja);
+            fa = stage2(stage1(ja + 2));
+            consume(fb, ja + 1);
+            fb = stage2(stage1(ja + 3));
+            consume(fa, ja + 2);
+            consume(fb, ja + 3);
+        };
+
+        // ---------------- the column walk: tile t gathered from buffer t & 1 while tile t + 1 lands in the other one ----------------
+        // Tiles whose plan misses the volume altogether (warped = 0, gradient 0: only the target's moments count) form a prefix and a suffix
+        // of the column - the plan's box moves along a straight line, and it meets the volume's box in one interval of tiles - and are
+        // taken out of the pipelined walk: [ty_begin, t0) and [t1, ty_end) run the plain loop below, [t0, t1) the walk.
+        lane_origins(ty_begin);
+        __syncthreads();
+        int t0 = ty_begin, t1 = ty_end;
+        while (t0 < ty_end && tile_org(t0).outside) t0++;
+        while (t1 > t0 && tile_org(t1 - 1).outside) t1--;
+        auto target_only = [&](int ta, int tb) {
+            for (int ty = ta; ty < tb; ty++) {
+                const int Y0 = ty * C::TY, ny = min(C::TY, H - Y0);
+                for (int j = j0; j < min(j0 + kRows, ny); j++) {
+                    const float yv = tgt[(size_t)(z * H + Y0 + j) * W + x];
+                    if constexpr (MODE == 4) acc.M4 = fmaf(yv, yv, acc.M4);
+                    else { acc.M01.x += yv; acc.M23.x = fmaf(yv, yv, acc.M23.x); }
+                }
+            }
+        };
+        target_only(ty_begin, t0);
+        // Vector-memory operations of a wave per tile, in program order:  YN' A0 A1 A2 | T'0 T'1 T'2 T'3 | B0 B1 | T'4 T'5 T'6 T'7  (' = of
+        // the next tile); the counted waits below rely on that order (every target load is issued, also for rows past the volume).
+        float tv[kRows], yn_cur = 0.f, yn_nxt = 0.f;
+#pragma unroll
+        for (int j = 0; j < kRows; j++) tv[j] = 0.f;
+        TileOrg cur = tile_org(min(t0, ty_end - 1));
+        if (t0 < t1) {
+            issue_yn(t0, yn_cur);
+#pragma unroll
+            for (int j = 0; j < kRows; j++) issue_target(t0, j, tv[j]);
+            issue_batch(cur, 0, K);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            commit_batch(cur, 0, 0, K);
+#pragma unroll
+            for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tv[j]));
+            asm volatile("" : "+v"(yn_cur));
+        }
+        __syncthreads();
+        for (int ty = t0; ty < t1; ty++) {
+            const int par = (ty - t0) & 1;
+            const bool more = ty + 1 < t1;
+            TileOrg nxt = cur;
+            if (more) {
+                if (((ty + 1 - ty_begin) & 63) == 0) {   // (columns of more than 64 tiles: the next chunk of origins)
+                    __syncthreads();
+                    lane_origins(ty + 1);
+                    __syncthreads();
+                }
+                nxt = tile_org(ty + 1);
+                issue_yn(ty + 1, yn_nxt);
+                issue_batch(nxt, 0, KA);
+            }
+            gather_rows(ty, cur, par, yn_cur, tv, 0, kRows / 2, more);
+            if (more) {
+                if (TRX_EF_DBG & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // batch A has landed (the four targets behind it may still fly)
+                commit_batch(nxt, par ^ 1, 0, KA);
+                issue_batch(nxt, KA, K);
+            }
+            gather_rows(ty, cur, par, yn_cur, tv, kRows / 2, kRows, more);
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                commit_batch(nxt, par ^ 1, KA, K);
+#pragma unroll
+                for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tv[j]));
+                asm volatile("" : "+v"(yn_nxt));
+            }
+            cur = nxt;
+            yn_cur = yn_nxt;
+            __syncthreads();
+        }
+        target_only(t1, ty_end);
+    } else {
+        // the plan does not fit (dual_choice tests the same numbers, so this is a safety net): every voxel gathers from global memory
+        for (int ty = ty_begin; ty < ty_end; ty++) {
+            const int Y0 = ty * C::TY, ny = min(C::TY, H - Y0);
+            for (int j = j0; j < min(j0 + kRows, ny); j++) {
+                const float yn = ytab[Y0 + j];
+                const float ix = fmaf(sx, yn, base_x), iy = unnorm<3>(yn, fH) + fmaf(sy, yn, base_y), iz = fmaf(sz, yn, base_z);
+                const Samp3 sm = sample3_padded(mov, D, H, W, ix, iy, iz);
+                const float yv = tgt[(size_t)(z * H + Y0 + j) * W + x];
+                f1_accumulate_pk<MODE>(sm, yv, yn, acc);
+            }
+        }
+        __syncthreads();
+    }
+    if (!act) {
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc.AB[q][c] = (f2)(0.f);
+        acc.M01 = acc.M23 = (f2)(0.f);
+        acc.M4 = 0.f;
+    }
+    float vals[NP];
+    int o = 0;
+    if constexpr (MODE == 4) {
+        vals[0] = acc.M4;
+        o = 1;
+    } else {
+        vals[0] = acc.M01.x; vals[1] = acc.M01.y; vals[2] = acc.M23.x; vals[3] = acc.M23.y; vals[4] = acc.M4;
+        o = 5;
+    }
+    {
+        int tt = tid;   // (re-formed from the thread id: not kept live across the walk)
+        asm volatile("" : "+v"(tt));
+        const int lx2 = tt & (C::TX - 1), lz2 = (tt / C::TX) & (C::TZ - 1);
+        const int xx = X0 + ((lx2 < nx && lz2 < nz) ? lx2 : 0), zz = Z0 + ((lx2 < nx && lz2 < nz) ? lz2 : 0);
+        const float xn_e = xtab[xx], zn_e = ztab[zz];
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float a = acc.AB[q][c].x;
+                vals[o++] = xn_e * a; vals[o++] = acc.AB[q][c].y; vals[o++] = zn_e * a; vals[o++] = a;
+            }
+    }
+    block_reduce_store_nw<NP, C::Waves>(vals, partials + ((size_t)by * rows_stride + bx) * NP, lds, wave);
+}
+
+// stand-alone kernel (tools/ebench.hip; the library runs the body inside affine_tile_dual_kernel)
+template <int MODE>
+__global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tg, float *__restrict__ partials)
+{
+    __shared__ __attribute__((aligned(16))) float lds[ECfg::Alloc];
+    if ((int)blockIdx.x >= tg.blocks_per_pair) return;
+    eft_body<MODE>(vol, theta, tg, partials, lds, blockIdx.x, blockIdx.y, gridDim.x, trx_wave_index());
+}
+#pragma clang diagnostic pop
