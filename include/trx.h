@@ -53,6 +53,8 @@ typedef enum {
 #define TRX_FLAG_NEAREST 128u        /* trx_flow_warp: nearest-neighbour sampling (SpatialTransformer(mode='nearest'), ref:utils.py:339-365) instead of bi/trilinear */
 #define TRX_FLAG_NO_ZSTREAM 32u     /* affine steps: never use the z-streaming body (pairs next to the identity run GeomD / GeomA like the others) */
 #define TRX_FLAG_ZSTREAM 64u        /* affine steps: offer the z-streaming body whatever the batch size (by default only to launches that fill the chip) */
+#define TRX_FLAG_NO_EFT 512u        /* affine steps: never use the exact-footprint body (rotated pairs run GeomR as before) */
+#define TRX_FLAG_EFT 1024u          /* affine steps: offer the exact-footprint body whatever the batch size (by default only to launches that fill the chip) */
 #define TRX_FLAG_NO_ROT_DEEP_TILE 16u /* affine steps: never use GeomRD (the 16 x 16 x 16 tile in GeomR's box) - rotated pairs all run GeomR */
 
 /* A batch of B independent (moving, target) pairs. */

@@ -105,6 +105,26 @@ int main(int argc, char **argv)
     if (only) return 0;
     rep("tile kernels, classic grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, trx::ZGeom{}, ru, 0); }, reps));
     rep("tile kernels, flat grid 512", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(512, 1), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, trx::ZGeom{}, ru, gx); }, reps));
+    {   // what trx_affine_step launches: the exact-footprint step kernel (takes the rotated pairs, marks them rows_used < 0) + the fused kernel behind it
+        const int er = trd.blocks_per_pair;
+        auto ef_flat = [&] { hipLaunchKernelGGL((trx::affine_eft_step_kernel<0>), dim3(512, 1), dim3(512), 0, 0, vol, theta, trd, partials, ru, gx, 1, 1, 0); };
+        auto ef_classic = [&] { hipLaunchKernelGGL((trx::affine_eft_step_kernel<0>), dim3(er, B), dim3(512), 0, 0, vol, theta, trd, partials, ru, -gx, 1, 1, 0); };
+        auto fused_flat = [&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(512, 1), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, trx::ZGeom{}, ru, gx, 1); };
+        auto fused_classic = [&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, trx::ZGeom{}, ru, 0, 1); };
+        rep("   EF step kernel alone, flat", time_it(ef_flat, reps));
+        rep("   EF step kernel alone, classic", time_it(ef_classic, reps));
+        rep("   fused kernel alone (skips every pair), flat", time_it(fused_flat, reps));
+        rep("step launches (EF kernel + fused), flat", time_it([&] { ef_flat(); fused_flat(); }, reps));
+        CK(hipMemset(partials, 0, (size_t)B * prow * 41 * 4));
+        ef_flat(); fused_flat();
+        CK(hipDeviceSynchronize());
+        std::vector<int> hru(B); CK(hipMemcpy(hru.data(), ru, B * 4, hipMemcpyDeviceToHost));
+        const std::vector<double> got = sums(gx);
+        double worst = 0;
+        for (int b = 0; b < B; b++) for (int k = 0; k < 5; k++) worst = std::max(worst, fabs(got[b * 41 + k] - ref[b * 41 + k]) / std::max(1.0, fabs(ref[b * 41 + k])));
+        printf("   rows_used[0] = %d; moments vs tile kernels %.2e\n", hru[0], worst);
+        rep("step launches (EF kernel + fused), classic", time_it([&] { ef_classic(); fused_classic(); }, reps));
+    }
     rep("exact-footprint 16^3 tiles (again)", time_it([&] { hipLaunchKernelGGL((trx::affine_eft_kernel<0>), dim3(trd.blocks_per_pair, B), dim3(512), 0, 0, vol, theta, trd, partials); }, reps));
     return 0;
 }

@@ -1175,13 +1175,15 @@ struct DualKArgs {
     ZGeom zg;
     int *rows_used;
     int rows_stride;
+    int eft;
 };
 
 template <int MODE, int WHICH = 0>
 __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kernel(trx_volumes vol_, const float *__restrict__ theta_, TileGeom tgA_,
                                                                                    TileGeom tgR_, int channels_, float *__restrict__ partials_,
                                                                                    int zero_surplus_ = 1, TileGeom tgD_ = TileGeom{}, TileGeom tgRD_ = TileGeom{},
-                                                                                   ZGeom zg_ = ZGeom{}, int *__restrict__ rows_used_ = nullptr, int rows_stride_ = 0)
+                                                                                   ZGeom zg_ = ZGeom{}, int *__restrict__ rows_used_ = nullptr, int rows_stride_ = 0,
+                                                                                   int eft_ = 0)
 {
     static_assert(GeomA::Threads == 512 && GeomR::Threads == 512 && GeomD::Threads == 512 && GeomRD::Threads == 512, "every geometry runs 512-thread blocks");
     static_assert(GeomRD::BoxAlloc <= GeomR::BoxAlloc, "GeomRD lives in GeomR's box");
@@ -1205,6 +1207,7 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     float fD, fH, fW;
     bool with_d, with_rd;
     int zs_planes, rows_stride, nA, nR, nD, nRD, nZ;
+    bool with_ef;
     const float *theta;
     {
         KArgs a = args();
@@ -1214,8 +1217,11 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         zs_planes = kDeep && nZ > 0 ? a->zg.planes_per_seg : 0;
         rows_stride = a->rows_stride;
         theta = a->theta;
+        with_ef = kDeep && (TRX_EFT_BODY != 0) && a->eft != 0 && a->rows_used != nullptr;
     }
-    auto blocks_of = [&](int choice) { return choice == 4 ? nZ : (choice == 0 ? nD : (choice == 3 ? nRD : (choice == 1 ? nA : nR))); };
+    // 6 = taken by the exact-footprint kernel (affine_eft_step_kernel, launched IN FRONT of this one: it left rows_used[b] = -(its row
+    // count) for the pairs it took - rotated pairs that GeomR would run and whose plan fits its buffers): no block here
+    auto blocks_of = [&](int choice) { return choice == 6 ? 0 : (choice == 4 ? nZ : (choice == 0 ? nD : (choice == 3 ? nRD : (choice == 1 ? nA : nR)))); };
     // Work items of this block: (pair / slab `by`, block index v of that pair's geometry).  Classic grid: exactly one, from blockIdx.
     // FLAT grid (rows_stride > 0; the launcher's choice for big batches of the step kernels): gridDim.x persistent blocks share one list
     // of work items - pair 0's blocks, then pair 1's, ... each pair with the block count of the body ITS theta selects - and block p runs
@@ -1237,10 +1243,11 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         const int B = a->vol.B;
         int *rows_used = a->rows_used;
         int cnt = 0, ch = 2;
+        if (lane < B) ch = dual_choice(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, with_d, with_rd, zs_planes);
+        if (with_ef && lane < B && rows_used[lane] < 0) ch = 6;   // taken by the exact-footprint kernel, which ran in front of this one
         if (lane < B) {
-            ch = dual_choice(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, with_d, with_rd, zs_planes);
             cnt = blocks_of(ch);
-            if (rows_used && blockIdx.x == 0 && wave_idx == 0) rows_used[lane] = cnt;   // for the step's finalise kernel
+            if (rows_used && blockIdx.x == 0 && wave_idx == 0 && ch != 6) rows_used[lane] = cnt;   // for the step's finalise kernel
         }
         int pre = cnt;   // inclusive prefix sum over the lanes (pairs)
 #pragma unroll
@@ -1256,6 +1263,7 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         const int channels = a->channels;
         const int b = kPerChannel ? blockIdx.y / channels : blockIdx.y;
         my_choice = __builtin_amdgcn_readfirstlane(dual_choice(theta + (size_t)b * TRX_PSTRIDE, fD, fH, fW, with_d, with_rd, zs_planes));
+        if (with_ef && a->rows_used[b] < 0) my_choice = 6;   // taken by the exact-footprint kernel, which ran in front of this one
         const bool useA = my_choice == 1;
         if ((WHICH == 1 && !useA) || (WHICH == 2 && useA)) return;   // the other launch owns this pair (and its surplus rows)
         const int mine = blocks_of(my_choice);
@@ -1263,7 +1271,7 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         // rows_used[], written here by the pair's first block - it does not repeat the choice (two inlined copies of a float test could
         // disagree by an ulp)
         int *rows_used = a->rows_used;
-        if (rows_used && blockIdx.x == 0 && tid_ == 0) rows_used[blockIdx.y] = mine;
+        if (rows_used && blockIdx.x == 0 && tid_ == 0 && my_choice != 6) rows_used[blockIdx.y] = mine;
         if ((int)blockIdx.x >= mine) {
             if (MODE != 3 && a->zero_surplus && tid_ < NP) a->partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + tid_] = 0.f;
             return;
@@ -1321,10 +1329,88 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     }
 }
 
+// The exact-footprint kernel of a step, launched IN FRONT of affine_tile_dual_kernel.  It decides which pairs are its own - those that
+// kernel would give to GeomR (dual_choice, same arguments) and whose plan fits its buffers (counted exactly, one pair per wave) - leaves
+// rows_used[b] = -(partial rows it writes) for them and 0 for the others (the step kernel behind it skips the negative ones; so does the
+// finalise kernel's reading of the count: |rows_used|), and runs them.  Why a kernel of its own: inlined into affine_tile_dual_kernel as a
+// sixth body - or called from it, or with only this decision in its prologue - it changed the code the compiler makes of the z-streaming
+// loop (a reload and a vmcnt(0) per step): the headline lost 7-12 % (profiles/r04c_eft_placement_ab.txt).
+// stride > 0: FLAT grid of persistent blocks over the pair-major list of those pairs' blocks (partial rows of stride `stride` per pair);
+// stride < 0: block (x, pair) of a (blocks_per_pair, pairs) grid, rows of stride -stride.  No pair of its own: every block leaves at once.
+template <int MODE>
+__global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tg, float *__restrict__ partials,
+                                                                           int *__restrict__ rows_used, int stride, int with_d, int with_rd, int zs_planes)
+{
+    __shared__ __attribute__((aligned(16))) float lds[ECfg::Alloc];
+    __shared__ int s_ef[64];
+    const int wave = trx_wave_index(), lane = trx_lane_id();
+    const float fD = (float)vol.D, fH = (float)vol.H, fW = (float)vol.W;
+    if (stride < 0) {   // (small launches: the body is offered by TRX_FLAG_EFT only)
+        if ((int)blockIdx.x >= tg.blocks_per_pair) return;
+        const int b = blockIdx.y;
+        const float *th = theta + (size_t)b * TRX_PSTRIDE;
+        bool take = __builtin_amdgcn_readfirstlane(dual_choice(th, fD, fH, fW, with_d != 0, with_rd != 0, zs_planes)) == 2 &&
+                    __builtin_amdgcn_readfirstlane((int)ef_candidate(th, fD, fH, fW));
+        if (take) {
+            const EfMap m = ef_map(th, fD, fH, fW);
+            const EfDims d = ef_dims(m);
+            const int g = ef_plan_granules_wave(m, d, lane);   // (every wave counts: no barrier)
+            take = d.ok && g > 0 && g <= ECfg::GCap;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) rows_used[b] = take ? -tg.blocks_per_pair : 0;
+        if (!take) return;
+        eft_body<MODE>(vol, theta, tg, partials, lds, blockIdx.x, b, -stride, wave);
+        return;
+    }
+    // flat: per pair (lane) the decision, one candidate pair per wave and round
+    const bool cand_l = lane < vol.B && dual_choice(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, with_d != 0, with_rd != 0, zs_planes) == 2 &&
+                        ef_candidate(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW);
+    const unsigned long long cand = __builtin_amdgcn_ballot_w64(cand_l);
+    unsigned long long fit = 0;
+    if (cand) {
+        if (wave == 0) s_ef[lane] = 0;
+        __syncthreads();
+        unsigned long long rest = cand;
+        for (int k = 0; rest; k++) {
+            const int pb = __builtin_ctzll(rest);
+            rest &= rest - 1;
+            if ((k & (ECfg::Waves - 1)) != wave) continue;
+            const EfMap m = ef_map(theta + (size_t)pb * TRX_PSTRIDE, fD, fH, fW);
+            const EfDims d = ef_dims(m);
+            const int g = ef_plan_granules_wave(m, d, lane);
+            if (lane == 0) s_ef[pb] = (d.ok && g > 0 && g <= ECfg::GCap) ? 1 : 0;
+        }
+        __syncthreads();
+        fit = __builtin_amdgcn_ballot_w64(s_ef[lane] != 0) & cand;
+    }
+    const int mine = ((fit >> lane) & 1ull) ? tg.blocks_per_pair : 0;
+    if (blockIdx.x == 0 && wave == 0 && lane < vol.B) rows_used[lane] = -mine;
+    if (fit == 0) return;
+    int pre = mine;   // inclusive prefix sum over the lanes (pairs)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(pre, d, 64);
+        if (lane >= d) pre += t;
+    }
+    const int total = __builtin_amdgcn_readlane(pre, 63);
+    // A block's items (pair-major index blockIdx + k gridDim) would be the SAME column in pair after pair - and columns differ widely in
+    // cost (those that leave the source volume early are cheap): the column index is rotated per pair (by a multiple of 8: blocks b, b + 8,
+    // ... still share an XCD's L2 with the neighbouring columns), which evens the blocks' loads without any shared counter.
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const int pair = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= item)));
+        const int off = pair > 0 ? __builtin_amdgcn_readlane(pre, pair - 1) : 0;
+        int v = item - off + 104 * pair;
+        v = __builtin_amdgcn_readfirstlane(v % tg.blocks_per_pair);
+        if (item != (int)blockIdx.x) __syncthreads();   // the previous item's reduction scratch aliases the buffers
+        eft_body<MODE>(vol, theta, tg, partials, lds, v, pair, stride, wave);
+    }
+}
+
 // GeomA / GeomR per pair: one two-body launch or the pair of single-body launches (TRX_AFFINE_DUAL = 1 / 2, default 1: the pair costs one more launch and gains nothing).
 template <int MODE>
 static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const float *theta, const TileGeom &ta, const TileGeom &tr, int channels, float *out, int how,
-                        int zero_surplus = 1, TileGeom td = TileGeom{}, TileGeom trd = TileGeom{}, ZGeom zg = ZGeom{}, int *rows_used = nullptr, int rows_stride = 0)
+                        int zero_surplus = 1, TileGeom td = TileGeom{}, TileGeom trd = TileGeom{}, ZGeom zg = ZGeom{}, int *rows_used = nullptr, int rows_stride = 0,
+                        int eft = 0)
 {
     if (how == 1) {
         // WHICH = 3: the two-body (GeomA / GeomR) instance for launches that offer nothing else - the five-body kernel's entry costs 2-3 us
@@ -1332,7 +1418,7 @@ static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const fl
         if (td.blocks_per_pair == 0 && trd.blocks_per_pair == 0 && zg.blocks_per_pair == 0 && rows_stride == 0)
             hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 3>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride);
         else
-            hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride);
+            hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride, eft);
     } else {
         hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 1>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
         hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 2>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, 1);
@@ -1507,7 +1593,7 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
         // rows the F1 pass wrote for this pair: the dual kernel lays a pair's rows out with stride nblk and fills the first
         // blocks_per_pair of the geometry it chose for the pair - it left that count in rows_used[b]
         int rows = nblk;
-        if (rows_used) rows = min(max(rows_used[b], 0), nblk);
+        if (rows_used) rows = min(abs(rows_used[b]), nblk);   // (negative: the pair was left to the exact-footprint kernel, which wrote |rows_used| rows)
         if (ND == 3 && mse_rows) reduce_partials<kNpMse>(partials + (size_t)b * nblk * kNpMse, rows, S);   // rows of the MSE / SSD-only step kernel
         else reduce_partials<NP>(partials + (size_t)b * nblk * NP, rows, S);
     }
@@ -2045,8 +2131,21 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             int *ru = aware ? (int *)((char *)partials + ws.off_rows_used) : nullptr;
             // big batches of the step kernels: a flat grid of persistent blocks over a pair-major work list (no surplus blocks; see the kernel)
             const bool flat = step_kernel && TRX_DEEP_TILE && TRX_FLAT_GRID && vol->B <= 64 && (long)gxx * vol->B >= 2 * TRX_PERSISTENT_BLOCKS;
-            if (flat) launch_dual<MODE>(dim3(TRX_PERSISTENT_BLOCKS, 1), s, v, theta, ta, tr, 1, partials, 1, 0, td, trd, zg, ru, gxx);
-            else launch_dual<MODE>(dim3(gxx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd, zg, ru, 0);
+            // the exact-footprint kernel (rotated pairs that GeomR would take) behind launches that fill the chip: columns of at most 64 of its tiles
+            const TileGeom tef = tile_geom<GeomRD>(*vol);   // (its 16^3 tiling is GeomRD's)
+            const int eft = (TRX_EFT_BODY && step_kernel && TRX_DEEP_TILE && ru && tef.tiles_per_seg <= 64 && !(vol->flags & TRX_FLAG_NO_EFT) &&
+                             (flat || (vol->flags & TRX_FLAG_EFT))) ? tef.blocks_per_pair : 0;   // = the partial rows per pair of that kernel
+            if (eft && tef.blocks_per_pair > gxx) gxx = tef.blocks_per_pair;
+            if constexpr (MODE == 0 || MODE == 4) {
+                if (eft) {   // in front of the step kernel: takes its pairs and marks them rows_used < 0 (none - the usual case next to the identity - costs ~3 us)
+                    const int wd = td.blocks_per_pair > 0, wrd = trd.blocks_per_pair > 0, zp = zg.blocks_per_pair > 0 ? zg.planes_per_seg : 0;
+                    if (flat) hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(TRX_PERSISTENT_BLOCKS, 1), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, gxx, wd, wrd, zp);
+                    else hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(tef.blocks_per_pair, vol->B), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, -gxx, wd, wrd, zp);
+                    TRX_CHECK_LAUNCH();
+                }
+            }
+            if (flat) launch_dual<MODE>(dim3(TRX_PERSISTENT_BLOCKS, 1), s, v, theta, ta, tr, 1, partials, 1, 0, td, trd, zg, ru, gxx, eft);
+            else launch_dual<MODE>(dim3(gxx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd, zg, ru, 0, eft);
             TRX_CHECK_LAUNCH();
             *nblk = gxx;
             if (aware) *rows_used = ru;

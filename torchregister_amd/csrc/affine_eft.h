@@ -111,32 +111,69 @@ __device__ __forceinline__ int ef_row_window(const EfMap &m, int dy, int dz, int
     return (whi - wlo + 4) >> 2;
 }
 
-// Granule count of the plan of this theta, by the whole block (512 threads, two rows each): the per-pair test of dual_choice.
-// `scratch`: 8 ints of LDS.  Ends with a barrier; the result is block-uniform.
-__device__ __forceinline__ int ef_plan_granules(const EfMap &m, const EfDims &d, int tid, int wave, int lane, int *scratch)
+// Granule count of the plan of this theta by ONE WAVE (16 rows per lane, no barrier): the per-pair test of the step kernels, which hand
+// one candidate pair to each of their eight waves.  The result is wave-uniform.
+__device__ __forceinline__ int ef_plan_granules_wave(const EfMap &m, const EfDims &d, int lane)
 {
     int cnt = 0;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int r = tid + h * ECfg::Threads, iy = r & (ECfg::NY - 1), iz = r >> 5;
+    for (int h = 0; h < (ECfg::NY * ECfg::NZ) / 64; h++) {
+        const int r = lane + h * 64, iy = r & (ECfg::NY - 1), iz = r >> 5;
         int wlo;
         if (iy < d.ny && iz < d.nz) cnt += ef_row_window(m, d.dy0 + iy, d.dz0 + iz, wlo);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    __syncthreads();   // (the scratch may still be read from a previous call)
-    if (lane == 0) scratch[wave] = cnt;
-    __syncthreads();
-    int g = 0;
-#pragma unroll
-    for (int w = 0; w < ECfg::Waves; w++) g += scratch[w];
-    return __builtin_amdgcn_readfirstlane(g);
+    return __builtin_amdgcn_readfirstlane(cnt);
 }
 // theta-only part of the offer (cheap, per lane): the plan's table fits and the map is well conditioned
 __device__ __forceinline__ bool ef_candidate(const float *__restrict__ th, float fD, float fH, float fW)
 {
     const EfMap m = ef_map(th, fD, fH, fW);
     return ef_dims(m).ok;
+}
+
+// Closed-form upper estimate of the plan's granule count from theta alone (lane-parallel, no block-wide work): the plan's cells lie in
+// the Minkowski sum of the tile's pre-image (edges E_a = 15 A e_a) and a box (hx, hy, hz) - a zonotope, whose volume is the sum of
+// |det| over the triples of its six generators - and its rows in the projection onto (y, z) (pairs of five generators); granules =
+// (cells + 3 rows) / 4.  Against the exact plan over random rotations x zooms x shears the ratio plan / estimate is 0.79 ... 0.90
+// (tools/eft_plan_check.py): the test below leaves 7 % on top of that, and a plan that still does not fit makes the body gather from
+// global memory (correct, slow).  Products are written with explicit roundings: the same bits wherever the function is inlined.
+__device__ __forceinline__ bool ef_estimate_ok(const float *__restrict__ th, float fD, float fH, float fW)
+{
+    const EfMap m = ef_map(th, fD, fH, fW);
+    const EfDims d = ef_dims(m);
+    if (!d.ok) return false;
+    const float ex = (float)(ECfg::TX - 1), hx = 5.2f, hy = 3.1f, hz = 3.1f;
+    float E[3][3];   // E[a][c]: component c of edge a
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) E[a][c] = __fmul_rn(m.A[c][a], ex);
+    auto det2 = [](float a, float b, float c, float dd) { return __fsub_rn(__fmul_rn(a, dd), __fmul_rn(b, c)); };
+    // volume: (E0, E1, E2)
+    float vol = fabsf(__fadd_rn(__fadd_rn(__fmul_rn(E[0][0], det2(E[1][1], E[1][2], E[2][1], E[2][2])), -__fmul_rn(E[0][1], det2(E[1][0], E[1][2], E[2][0], E[2][2]))),
+                                __fmul_rn(E[0][2], det2(E[1][0], E[1][1], E[2][0], E[2][1]))));
+    const float h[3] = {hx, hy, hz};
+    // (E_a, E_b, h_c e_c): h_c |(E_a x E_b)_c|;  (E_a, h_c e_c, h_d e_d): h_c h_d |E_a,e| with e the third axis
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = a + 1; b < 3; b++) {
+            vol = __fadd_rn(vol, __fmul_rn(h[0], fabsf(det2(E[a][1], E[a][2], E[b][1], E[b][2]))));
+            vol = __fadd_rn(vol, __fmul_rn(h[1], fabsf(det2(E[a][0], E[a][2], E[b][0], E[b][2]))));
+            vol = __fadd_rn(vol, __fmul_rn(h[2], fabsf(det2(E[a][0], E[a][1], E[b][0], E[b][1]))));
+        }
+    float rows = __fmul_rn(hy, hz);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        vol = __fadd_rn(vol, __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn(hy, hz), fabsf(E[a][0])), __fmul_rn(__fmul_rn(hx, hz), fabsf(E[a][1]))), __fmul_rn(__fmul_rn(hx, hy), fabsf(E[a][2]))));
+        rows = __fadd_rn(rows, __fadd_rn(__fmul_rn(hy, fabsf(E[a][2])), __fmul_rn(hz, fabsf(E[a][1]))));
+#pragma unroll
+        for (int b = a + 1; b < 3; b++) rows = __fadd_rn(rows, fabsf(det2(E[a][1], E[a][2], E[b][1], E[b][2])));
+    }
+    vol = __fadd_rn(vol, __fmul_rn(__fmul_rn(hx, hy), hz));
+    const float est = __fmul_rn(0.25f, __fadd_rn(vol, __fmul_rn(3.0f, rows)));
+    return __fmul_rn(est, 0.97f) <= (float)ECfg::GCap;   // NaN compares false
 }
 
 typedef float f4 __attribute__((ext_vector_type(4)));

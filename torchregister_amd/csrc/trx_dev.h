@@ -46,6 +46,9 @@
 #ifndef TRX_ROT_DEEP_TILE
 #define TRX_ROT_DEEP_TILE 1   // the step kernels carry GeomRD as a fourth per-pair choice (0: never - measured alternative)
 #endif
+#ifndef TRX_EFT_BODY
+#define TRX_EFT_BODY 1   // the step kernels carry the exact-footprint body for rotated pairs (0: GeomR as before - measured alternative)
+#endif
 #ifndef TRX_PERSISTENT_BLOCKS
 #define TRX_PERSISTENT_BLOCKS 512   // block slots of one MI355X for the 512-thread step kernels (two per CU): the size of the flat grid
 #endif
