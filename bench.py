@@ -12,6 +12,8 @@ all 8 pairs of a rank: fused warp + NCC + analytic backward (one HIP kernel) + f
 kernel; nothing is skipped and there is no host sync inside the timed region.  Pairs are independent,
 so N GPUs shard with no collective ("weak" scaling: 8 pairs per GPU at every N).
 value = N * 8 * K / max-over-ranks(elapsed)  [pair-iterations / s].
+`--scaling strong [--pairs-total 64]` fixes the TOTAL number of pairs instead (64 pairs over G GPUs, 64 / G each - the
+shard of rank r is sharding.pair_range(r, G, 64)); value = pairs_total * K / max-over-ranks(elapsed), "scaling": "strong".
 
 Extra objects in the JSON line (rank 0, N = 1 only):
   roofline     - dominant kernel (the fused F1 pass) timed in isolation with events on the launch
@@ -52,11 +54,13 @@ def blobs_gpu(shape, seed, device):
     return img.view(1, 1, *shape)
 
 
-def make_batch(rank, device, size=SIZE, pairs=PAIRS_PER_GPU):
+def make_batch(rank, device, size=SIZE, pairs=PAIRS_PER_GPU, pair_ids=None):
     import torchregister_amd as tr
     shape = (size,) * 3
     from torchregister_amd.sharding import weak_pair_ids
-    tgt = torch.cat([blobs_gpu(shape, 1000 + pid, device) for pid in weak_pair_ids(rank, pairs)])
+    ids = list(pair_ids) if pair_ids is not None else weak_pair_ids(rank, pairs)
+    pairs = len(ids)
+    tgt = torch.cat([blobs_gpu(shape, 1000 + pid, device) for pid in ids])
     th = torch.tensor(THETA_STAR, device=device)[None].expand(pairs, 3, 4).contiguous()
     mov = tr.get_affine_warp(th, tgt)
     return mov, tgt
@@ -152,6 +156,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=SIZE, help=argparse.SUPPRESS)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: 8 pairs per GPU at every N (default, what the driver runs); strong: --pairs-total pairs split over the N GPUs")
+    ap.add_argument("--pairs-total", type=int, default=64, help="strong scaling: the total number of pairs (BASELINE configs[3]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pose-legs", action="store_true",
                     help="skip the config.value_* / flow_value legs (profiling runs: every launch of the step kernel is then a headline-pose launch)")
@@ -185,7 +192,16 @@ def main():
             dist.init_process_group(args.backend)
 
     import torchregister_amd as tr
-    mov, tgt = make_batch(rank, device, args.size)
+    from torchregister_amd.sharding import pair_range
+    if args.scaling == "strong":
+        lo, hi = pair_range(rank, world, args.pairs_total)
+        assert hi > lo, f"--pairs-total {args.pairs_total} leaves rank {rank} of {world} without a pair"
+        mov, tgt = make_batch(rank, device, args.size, pair_ids=range(lo, hi))
+        job_pairs = args.pairs_total
+    else:
+        mov, tgt = make_batch(rank, device, args.size)
+        job_pairs = world * PAIRS_PER_GPU
+    my_pairs = mov.shape[0]
     lr = {"adam": 1e-4, "sgd": 1e-6}
 
     def new_solver(optimizer):
@@ -263,17 +279,17 @@ def main():
     extra = {"value_theta_star": None, "value_rot": None, "value_rigid_randinit": None, "flow_value": None}
     # (a) theta* itself - the pose the headline run converges to; (b) R(0.5, 0.4, 0.3) x anisotropic scale; (c) the rigid mode from the
     # reference's own initial pose: torch.manual_seed(0); torch.rand(6) radians / tanh-translations (ref:utils.py:316-321)
-    th_star = torch.tensor(THETA_STAR, device=device)[None].expand(PAIRS_PER_GPU, 3, 4).contiguous()
-    th_rot = pose_rot(device)
+    th_star = torch.tensor(THETA_STAR, device=device)[None].expand(my_pairs, 3, 4).contiguous()
+    th_rot = pose_rot(device, my_pairs)
     for key, th0 in (() if args.no_pose_legs else (("value_theta_star", th_star), ("value_rot", th_rot))):
         sv = tr.AffineSolver(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer=args.optimizer, lr=1e-6, init=th0,
                              capacity=pose_steps + 40)
-        extra[key] = world * PAIRS_PER_GPU * pose_steps / max_over_ranks(timed_run(sv, pose_steps), device)
+        extra[key] = job_pairs * pose_steps / max_over_ranks(timed_run(sv, pose_steps), device)
         del sv
     if not args.no_pose_legs:
         sv = tr.AffineSolver(mov, tgt, mode="rigid", loss=tr.LossSpec(w_ncc=1.0), optimizer=args.optimizer, lr=1e-6,
-                             init=pose_rigid_randinit(device), capacity=pose_steps + 40)
-        extra["value_rigid_randinit"] = world * PAIRS_PER_GPU * pose_steps / max_over_ranks(timed_run(sv, pose_steps), device)
+                             init=pose_rigid_randinit(device, my_pairs), capacity=pose_steps + 40)
+        extra["value_rigid_randinit"] = job_pairs * pose_steps / max_over_ranks(timed_run(sv, pose_steps), device)
         del sv
         # BASELINE.json configs[2]: one 256^3 pair, direct flow field + NCC + smoothness regulariser, Adam, 100 iterations (iterations / s)
         fs = tr.FlowSolver(mov[:1], tgt[:1], loss=tr.LossSpec(w_ncc=1.0), optimizer="adam", lr=0.01, smooth_weight=1.0, capacity=160)
@@ -287,18 +303,20 @@ def main():
 
     out = None
     if rank == 0:
-        total = world * PAIRS_PER_GPU * args.steps
+        total = job_pairs * args.steps
         out = {"metric": "registration iterations/sec (3D 256^3 fp32, affine+NCC)", "value": total / elapsed,
                "unit": "pair-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"3D {args.size}^3 fp32 affine+NCC, {PAIRS_PER_GPU} independent pairs per GPU "
-                                      f"(BASELINE.json configs[3] share of one GPU), {args.optimizer.upper()} on theta",
-                          "pairs_per_gpu": PAIRS_PER_GPU, "volume": [args.size] * 3, "loss": "NCC(alpha=100)", "optimizer": args.optimizer,
+               "config": {"workload": (f"3D {args.size}^3 fp32 affine+NCC, {PAIRS_PER_GPU} independent pairs per GPU "
+                                       f"(BASELINE.json configs[3] share of one GPU), {args.optimizer.upper()} on theta") if args.scaling == "weak" else
+                                      (f"3D {args.size}^3 fp32 affine+NCC, {args.pairs_total} independent pairs split over {world} GPU(s) "
+                                       f"(BASELINE.json configs[3], strong scaling), {args.optimizer.upper()} on theta"),
+                          "pairs_per_gpu": my_pairs if args.scaling == "strong" else PAIRS_PER_GPU, "pairs_total": job_pairs, "volume": [args.size] * 3, "loss": "NCC(alpha=100)", "optimizer": args.optimizer,
                           "preconditioning": f"{PRECONDITION} untimed iterations before the warm-up (clock settling); value_cold has none",
-                          "value_cold": world * PAIRS_PER_GPU * args.steps / elapsed_cold,
+                          "value_cold": job_pairs * args.steps / elapsed_cold,
                           "value_cold_note": f"first {args.steps} iterations of a fresh solver after 2 s of idle GPU, no warm-up",
-                          f"{other}_value": world * PAIRS_PER_GPU * args.steps / elapsed2,
+                          f"{other}_value": job_pairs * args.steps / elapsed2,
                           "value_theta_star": extra["value_theta_star"], "value_rot": extra["value_rot"],
                           "value_rigid_randinit": extra["value_rigid_randinit"],
                           "pose_note": f"pair-iterations/s of {pose_steps} steps at a fixed pose (lr 1e-6), same batch: theta* of the synthetic "
@@ -332,7 +350,7 @@ def main():
             per_it = [e0.elapsed_time(e1) * 1e-3 / REP for e0, e1 in ev]
             k_s = sum(per_it) / len(per_it)
             rows = rep.rows_used().tolist()
-            alg = ALG_BYTES_PER_VOXEL * args.size ** 3 * PAIRS_PER_GPU
+            alg = ALG_BYTES_PER_VOXEL * args.size ** 3 * my_pairs
             # HBM-side traffic and L2 requests come from separate PMC passes of this same command (tools/profile_bench.sh ->
             # tools/summarize_prof.py -> profiles/traffic.json); they are only quoted for the library they were measured on
             traffic, l2req, traffic_note = None, None, "no profiles/traffic.json"
@@ -357,6 +375,74 @@ def main():
                                "partial_rows_per_pair_last": rows[0],
                                "algorithmic_bytes_per_launch": alg,
                                "l2_requests_per_launch": l2req, "l2_request_bytes": 128}
+            if not args.no_pose_legs:
+                # ---- second roofline object: the F1 pass at the rotated pose of config.value_rot (the exact-footprint step kernel takes
+                # every pair there; same algorithmic bytes: each operand once).  Events around REP launches of exactly the step's F1 launches.
+                def traffic_for(tag_file, key):
+                    tfp = os.path.join(ROOT, "profiles", tag_file)
+                    if not os.path.exists(tfp):
+                        return None, f"no profiles/{tag_file}"
+                    import hashlib
+                    tj2 = json.load(open(tfp))
+                    sha2 = hashlib.sha256(open(os.path.join(ROOT, "torchregister_amd", "lib", "libtrx.so"), "rb").read()).hexdigest()
+                    if tj2.get("lib_sha256") != sha2 or args.size != SIZE:
+                        return None, f"profiles/{tag_file} was measured on another build of libtrx.so: not quoted"
+                    return tj2.get(key), f"PMC passes on this library (tag {tj2.get('tag')}, sha256 {sha2[:12]})"
+                sv = tr.AffineSolver(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer=args.optimizer, lr=0.0, init=th_rot, capacity=4)
+                for _ in range(60):
+                    sv.accumulate_only()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(60):
+                    sv.accumulate_only()
+                e1.record()
+                torch.cuda.synchronize()
+                k_rot = e0.elapsed_time(e1) * 1e-3 / 60
+                tr_rot, note_rot = traffic_for("traffic_rot.json", "hbm_bytes_per_launch")
+                out["roofline_rot"] = {"bound": "hbm", "kernel": "affine_eft_step_kernel<0> (exact-footprint body: every pair at theta = R(0.5, 0.4, 0.3) diag(1.05, 0.95, 1.02)) "
+                                                                 "+ the fused step kernel behind it (no pair left for it)",
+                                       "achieved": alg / k_rot / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / k_rot / HBM_PEAK,
+                                       "traffic": tr_rot, "traffic_note": note_rot, "kernel_ms": k_rot * 1e3, "algorithmic_bytes_per_launch": alg}
+                del sv
+                # ---- third: the dense-flow loop of config.flow_value.  Inside trx_flow_run the moments pass is fused into the previous
+                # update, so the bytes that MUST move per iteration are 80 B/voxel with Adam + smoothness (flow r12 w12, m r12 w12, v r12
+                # w12, moving 4 + target 4: DESIGN.md 4.3), not the 100 B/voxel of the two-pass step.
+                fs = tr.FlowSolver(mov[:1], tgt[:1], loss=tr.LossSpec(w_ncc=1.0), optimizer="adam", lr=0.01, smooth_weight=1.0, capacity=200)
+                fs.run(40)
+                torch.cuda.synchronize()
+                e0.record()
+                fs.run(100)
+                e1.record()
+                torch.cuda.synchronize()
+                k_flow = e0.elapsed_time(e1) * 1e-3 / 100
+                alg_flow = 80 * args.size ** 3
+                tr_flow, note_flow = traffic_for("traffic_flow.json", "hbm_bytes_per_iteration")
+                out["roofline_flow"] = {"bound": "hbm", "kernel": "flow_update3_kernel (+ flow_coef_kernel): one iteration of trx_flow_run, 1 x 256^3, Adam + smoothness",
+                                        "achieved": alg_flow / k_flow / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg_flow / k_flow / HBM_PEAK,
+                                        "traffic": tr_flow, "traffic_note": note_flow, "iteration_ms": k_flow * 1e3,
+                                        "algorithmic_bytes_per_iteration": alg_flow, "algorithmic_bytes_per_voxel": 80}
+                del fs
+                # ---- secondary configs the driver should see every round: cfg2 (1 x 128^3 affine + NCC, SGD) per iteration, and the flow +
+                # local-window NCC device loop (1 x 256^3, w = 9, Adam + smoothness) per iteration
+                t128 = blobs_gpu((128,) * 3, 1000, device)
+                m128 = tr.get_affine_warp(torch.tensor(THETA_STAR, device=device)[None], t128)
+                s2 = tr.AffineSolver(m128, t128, mode="affine", loss=tr.LossSpec(w_ncc=1.0), lr=1e-6, capacity=700)
+                s2.run(100)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s2.run(400)
+                torch.cuda.synchronize()
+                out["config"]["cfg2_us_per_it"] = (time.perf_counter() - t0) / 400 * 1e6
+                del s2
+                fl = tr.FlowSolver(mov[:1], tgt[:1], optimizer="adam", lr=0.01, capacity=100, smooth_weight=1.0, lncc=dict(window=9))
+                fl.run(20)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fl.run(50)
+                torch.cuda.synchronize()
+                out["config"]["lncc_loop_us"] = (time.perf_counter() - t0) / 50 * 1e6
+                del fl
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

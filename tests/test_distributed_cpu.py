@@ -109,3 +109,44 @@ def test_slab_neighbours_inside_a_subgroup_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, None, 1, -1.0, 1.0), (1, 0, None, 0.0, -1.0), (2, None, 3, -1.0, 3.0), (3, 2, None, 2.0, -1.0)]
+
+
+def _fallback_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torchregister_amd._engine import SlabPeers
+    out = {}
+    out["all_ok"] = SlabPeers.agree(True)
+    out["one_bad"] = SlabPeers.agree(rank != 1)
+    # the mapping fails on rank 1 only (what a missing peer access or an invisible device looks like): EVERY rank must fall back
+
+    def mapper(box, group=None):
+        if rank == 1:
+            raise RuntimeError("no peer access from device 1 to device 0")
+        raise AssertionError("allocate() needs a GPU; never reached on the CPU")   # (rank 0 fails earlier, in allocate: also a failure)
+    peers, why = SlabPeers.try_exchange(torch.device("cpu"), 8, 8, rank, _mapper=mapper)
+    out["peers_none"], out["why"] = peers is None, why
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_peer_transport_fallback_is_decided_by_all_ranks_together():
+    """when the mailbox mapping fails on ANY rank (IPC import, peer access, device visibility) every rank of the group
+    must fall back to torch.distributed - a MIN all-reduce of the local outcome - and say why (tools/run_slab.py prints the transport
+    that actually ran)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 200
+    ps = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    for r in (0, 1):
+        assert res[r]["all_ok"] is True and res[r]["one_bad"] is False
+        assert res[r]["peers_none"] is True and res[r]["why"]
+    assert "peer access" in res[1]["why"]

@@ -128,6 +128,25 @@ def test_bench_two_ranks_control_flow():
     assert "roofline" not in j and "cpu_baseline" not in j                                   # N = 1 only
 
 
+def test_bench_strong_scaling_two_ranks():
+    """`bench.py --scaling strong --pairs-total P` - the second half of SURVEY 8d's table (64 / G pairs per GPU) - with two
+    ranks on the one GPU over gloo: 5 pairs split 3 + 2 (sharding.pair_range), value = P x K / max-over-ranks(elapsed), "scaling": "strong"."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--size", "64", "--backend", "gloo", "--single-device", "--no-cpu-baseline", "--scaling", "strong", "--pairs-total", "5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["pairs_total"] == 5 and j["config"]["pairs_per_gpu"] == 3   # (rank 0's shard)
+    assert abs(j["value"] - 5 * 6 / (j["ms_per_step"] * 6e-3)) < 1e-6 * j["value"]
+
+
 def test_bench_under_torchrun_nccl_single_rank():
     """The RCCL path on hardware: bench.py under torch.distributed.run with ONE rank and the `nccl` backend (the launcher starts before
     any GPU call) - process-group init on the device, barriers and the MAX all-reduce of the timing run through RCCL exactly as they

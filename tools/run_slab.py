@@ -38,10 +38,12 @@ def main():
     tgt = blobs_gpu(shape, 1000, dev)
     mov = tr.get_affine_warp(torch.tensor(THETA_STAR, device=dev)[None], tgt)
     z0, z1 = slab_range(rank, world, a.size)
-    peers = None
+    peers, transport = None, ("dist" if world > 1 else "none")
     if a.transport == "peer" and world > 1:
-        box = tr.SlabPeers.allocate(dev, a.size, a.size, world)
-        peers = tr.SlabPeers(rank, tr.SlabPeers.exchange(box), a.size, a.size)
+        # mailboxes if EVERY rank can map them (IPC export / import, peer access, device visibility), else torch.distributed - decided
+        # together, and the line below says which transport actually ran
+        peers, why = tr.SlabPeers.try_exchange(dev, a.size, a.size, rank)
+        transport = "peer" if peers is not None else f"dist (peer transport unavailable: {why})"
     s = tr.SlabFlowSolver(mov, tgt[:, :, z0:z1].contiguous(), z0, loss=tr.LossSpec(w_ncc=1.0), optimizer=a.optimizer,
                           lr=0.01 if a.optimizer == "adam" else 1.0, capacity=a.iters + a.warmup, smooth_weight=a.smooth, peers=peers)
     del tgt
@@ -61,7 +63,7 @@ def main():
         ls = s.losses[0, : a.iters + a.warmup]
         print(json.dumps({"config": f"{a.size}^3 direct flow + NCC + {a.optimizer} + smooth {a.smooth}, {world} Z-slab(s)", "iters": a.iters,
                           "ms_per_iter": 1e3 * el / a.iters, "iters_per_s": a.iters / el, "loss_first": ls[0].item(), "loss_last": ls[-1].item(),
-                          "n_gpus": world, "transport": a.transport if world > 1 else "none"}), flush=True)
+                          "n_gpus": world, "transport": transport, "transport_requested": a.transport}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

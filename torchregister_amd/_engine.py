@@ -396,7 +396,7 @@ class SlabPeers:
         solver = SlabFlowSolver(..., peers=SlabPeers(rank, peers, H, W))
     In one process (several slabs driven in lock step on one or several GPUs: run_slabs_lockstep) the mailboxes are passed as they are."""
 
-    TIMEOUT_US = 5_000_000
+    TIMEOUT_US = 5_000_000          # per wait; the FIRST iteration of a transport waits 6 x as long (peers still build their solvers)
 
     @staticmethod
     def layout(H, W, world):
@@ -414,7 +414,8 @@ class SlabPeers:
     @staticmethod
     def exchange(box, group=None):
         """All-gathers the IPC handles of the ranks' mailboxes over `group` and maps them: the list of the N mailboxes (this rank's own
-        entry is `box` itself).  The mailbox must be the only tensor of its storage (allocate() guarantees it)."""
+        entry is `box` itself).  The mailbox must be the only tensor of its storage (allocate() guarantees it).  Every rank must see
+        every GPU of the group (no per-rank HIP_VISIBLE_DEVICES): a handle is re-opened on the SENDER's device index."""
         import torch.distributed as dist
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         handle = box.untyped_storage()._share_cuda_()
@@ -425,9 +426,48 @@ class SlabPeers:
             if r == rank:
                 boxes.append(box)
             else:
+                if int(h[0]) >= torch.cuda.device_count():
+                    raise RuntimeError(f"mailbox of rank {r} lives on device {int(h[0])}, which this process cannot see "
+                                       f"({torch.cuda.device_count()} visible): the peer transport needs every GPU of the node visible in every rank")
                 st = torch.UntypedStorage._new_shared_cuda(*h)
                 boxes.append(torch.empty(0, dtype=torch.uint8, device=st.device).set_(st))
         return boxes
+
+    @staticmethod
+    def agree(ok_local, group=None):
+        """True iff EVERY rank of the group reports success (a MIN all-reduce through the group's own backend): the decision to use a
+        transport must be the same on all ranks - one rank on mailboxes and its neighbour on torch.distributed would dead-lock."""
+        import torch.distributed as dist
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(t.item())
+
+    @staticmethod
+    def try_exchange(device, H, W, rank, group=None, _mapper=None):
+        """Mailbox transport if it can be set up on EVERY rank, else None (the caller keeps torch.distributed): returns (SlabPeers or None,
+        reason).  What can fail: IPC export / import of the mailbox (torch.UntypedStorage._share_cuda_ / _new_shared_cuda), peer access
+        between two devices, a GPU that is not visible in some rank.  `_mapper` replaces SlabPeers.exchange in the tests."""
+        import logging
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        boxes, reason = None, ""
+        try:
+            box = SlabPeers.allocate(device, H, W, world)
+            boxes = (_mapper or SlabPeers.exchange)(box, group)
+            for b in boxes:   # peer access: a cross-device mapping that cannot be read shows here, not in the middle of a run
+                if b.device != box.device:
+                    if not torch.cuda.can_device_access_peer(box.device.index, b.device.index):
+                        raise RuntimeError(f"no peer access from device {box.device.index} to device {b.device.index}")
+                    _ = b[:4].to(box.device)   # (also makes torch enable peer access between the two devices: hipDeviceEnablePeerAccess)
+        except Exception as e:   # noqa: BLE001 - any failure of the mapping means "use the other transport"
+            boxes, reason = None, f"{type(e).__name__}: {e}"
+        ok = SlabPeers.agree(boxes is not None, group)
+        if not ok:
+            why = reason or "another rank could not map the mailboxes"
+            logging.getLogger("torchregister_amd").warning("peer transport unavailable (%s): falling back to torch.distributed", why)
+            return None, why
+        return SlabPeers(rank, boxes, H, W), "peer-mapped mailboxes"
 
     def __init__(self, rank, boxes, H, W):
         self.lib = _lib.load()
@@ -474,11 +514,14 @@ class SlabPeers:
                 self.halo(above, par, "lo").copy_(hi_plane, non_blocking=True)
                 _lib.check(self.lib.trx_peer_signal(self._flag_ptr(above, 0), v, self._stream()), "trx_peer_signal")
 
+    def _timeout(self):
+        return min(self.TIMEOUT_US * (6 if self.t == 0 else 1), 0xFFFFFFFF)
+
     def wait_halo(self, which):
         """Blocks the current stream until the neighbour's plane of this iteration has arrived; returns the plane (a view of the mailbox)."""
         par, v = self.t & 1, self.t + 1
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.trx_peer_wait(self._flag_ptr(self.mine, 0 if which == "lo" else 1), v, self.TIMEOUT_US, _lib.ptr(self.status), self._stream()), "trx_peer_wait")
+            _lib.check(self.lib.trx_peer_wait(self._flag_ptr(self.mine, 0 if which == "lo" else 1), v, self._timeout(), _lib.ptr(self.status), self._stream()), "trx_peer_wait")
         return self.halo(self.mine, par, which)
 
     def publish(self, sums):
@@ -492,7 +535,7 @@ class SlabPeers:
         par, v = self.t & 1, self.t + 1
         slots = self.mine.data_ptr() + par * self.per_parity + 2 * self.plane
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.trx_peer_gather(slots, self.mine.data_ptr() + self.flags_off + 8, self.world, v, self.TIMEOUT_US, _lib.ptr(out), _lib.ptr(self.status),
+            _lib.check(self.lib.trx_peer_gather(slots, self.mine.data_ptr() + self.flags_off + 8, self.world, v, self._timeout(), _lib.ptr(out), _lib.ptr(self.status),
                                                 self._stream()), "trx_peer_gather")
         self.t += 1
 
@@ -670,6 +713,7 @@ class SlabFlowSolver:
                 self.peer_post(last=(it == int(iters) - 1))
                 self.peer_join()
                 self.peer_finish()
+            self.peers.check()   # (host sync at the end of the call: a peer that never wrote is an exception here, not a silent NaN curve)
             return
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         self.enqueued += int(iters)
@@ -774,6 +818,8 @@ def run_slabs_lockstep(solvers, iters):
         for s in solvers:
             with torch.cuda.device(s.device):
                 s.peer_finish()
+    for s in solvers:
+        s.peers.check()
 
 
 def local_ncc_loss_grad(target, warped, window=9, alpha=1.0, eps=1e-5, need_grad=True):

@@ -8,7 +8,9 @@
 //     iteration number and adds the N slots in rank order (trx_peer_gather) - the same order on every rank, so the whole-volume sums,
 //     and with them the loss curve and the early stop, are bit-identical everywhere, which a ring all-reduce does not promise.
 // Waiting is a one-thread kernel that polls with system-scope acquire loads and s_sleep; it gives up after `timeout_us` and sets
-// *status (the host checks it after the run) - a missing peer must not hang the GPU.  Flags only ever increase (iteration numbers),
+// *status (the host checks it after the run) - a missing peer must not hang the GPU.  The failure is STICKY: once *status is non-zero
+// every later wait / gather returns at once (an absent peer costs one time-out, not one per remaining iteration) and the gather writes
+// NaN sums, so the update that follows poisons the flow and the loss curve shows the failure even if the caller never checks.  Flags only ever increase (iteration numbers),
 // so nothing is reset; the caller double-buffers slots and halo planes by the parity of the iteration (a rank can be one iteration
 // ahead of a peer, never two: its next publish needs the peer's previous one).
 #include "trx_common.h"
@@ -36,6 +38,7 @@ __global__ void peer_signal_kernel(unsigned *flag, unsigned value)
 
 __global__ void peer_wait_kernel(const unsigned *flag, unsigned value, unsigned timeout_us, int *status)
 {
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // an earlier wait already gave up
     if (!peer_spin(flag, value, timeout_us)) atomicOr(status, 1);
     __threadfence_system();
 }
@@ -58,13 +61,15 @@ __global__ __launch_bounds__(64) void peer_gather_kernel(const double *slots, co
 {
     __shared__ int bad;
     const int tid = threadIdx.x;
-    if (tid == 0) bad = 0;
+    if (tid == 0) bad = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 2 : 0;   // 2: an earlier wait already gave up
     __syncthreads();
-    for (int r = tid; r < n; r += 64)
-        if (!peer_spin(flags + r, value, timeout_us)) bad = 1;
+    if (bad == 0)
+        for (int r = tid; r < n; r += 64)
+            if (!peer_spin(flags + r, value, timeout_us)) bad = 1;
     __syncthreads();
     if (bad) {
-        if (tid == 0) atomicOr(status, 2);
+        if (tid == 0 && bad == 1) atomicOr(status, 2);
+        if (tid < 8) out[tid] = __builtin_nan("");   // the update that consumes these sums must not look like a step
         return;
     }
     __threadfence_system();
