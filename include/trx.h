@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define TRX_VERSION 200 /* 0.2.0: trx_volumes.flags, early stop in trx_flow_state */
+#define TRX_VERSION 230 /* 0.2.3 (the reference package version whose API the host layer mirrors).  Since 200: TRX_FLAG_SAVE_LAST (slab updates store
+                           * flow_last only on request), TRX_FLAG_EFT / TRX_FLAG_NO_EFT, trx_flow_lncc_run, trx_peer_*, sticky peer time-outs */
 #define TRX_PSTRIDE 12  /* floats per pair in theta / param / adam / best_theta arrays */
 
 typedef enum {

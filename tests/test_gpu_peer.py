@@ -88,9 +88,22 @@ def test_peer_wait_times_out_instead_of_hanging(eng):
     pr.publish(out)                         # rank 1 never publishes
     pr.gather(out)
     torch.cuda.synchronize()
-    assert int(pr.status.item()) == 3
+    # the first time-out is STICKY: the gather behind it returns at once - it does not spin through its own time-out - and
+    # hands NaN sums to the update, so the loss curve shows the failure even if nobody calls check()
+    assert int(pr.status.item()) == 1
+    assert torch.isnan(out).all()
     with pytest.raises(Exception, match="timed out"):
         pr.check()
+    # a gather that times out on its own (no earlier failure) reports 2, also with NaN sums; later waits return immediately
+    pr2 = eng.SlabPeers(0, [eng.SlabPeers.allocate(torch.device("cuda", 0), 8, 8, 2) for _ in range(2)], 8, 8)
+    pr2.TIMEOUT_US = 2000
+    out2 = torch.zeros(1, 8, dtype=torch.float64, device="cuda")
+    pr2.publish(out2)
+    pr2.gather(out2)
+    pr2.TIMEOUT_US = 60_000_000             # (would hang the test for a minute if the failure were not sticky)
+    pr2.wait_halo("lo")
+    torch.cuda.synchronize()
+    assert int(pr2.status.item()) == 2 and torch.isnan(out2).all()
 
 
 def _ipc_worker(rank, world, port, tmp, shape, bounds, iters, kw):
@@ -175,3 +188,22 @@ def test_peer_early_stop_and_single_rank(eng):
     torch.cuda.synchronize()
     one.peers.check()
     assert torch.equal(one.losses, plain.losses) and torch.equal(one.flow, plain.flow)
+
+
+def test_apply_outside_run_keeps_flow_last_current(eng):
+    """a caller that drives the slab building blocks itself (local_moments -> sum -> apply) ends with flow_last = the flow its
+    LAST update started from, without knowing about TRX_FLAG_SAVE_LAST; apply(last=False) opts out."""
+    import phantoms as ph
+    shape = (12, 16, 20)
+    mov, tgt = ph.blobs(shape, 5).cuda(), ph.blobs(shape, 6).cuda()
+    s = eng.SlabFlowSolver(mov, tgt, 0, loss=eng.LossSpec(w_ncc=1.0), optimizer="sgd", lr=0.5, capacity=8, stop_crit=-1.0)   # (stop_crit: allocates flow_last)
+    assert s.flow_last is not None
+    for it in range(3):
+        before = s.flow.clone()
+        s.apply(s.local_moments())
+        torch.cuda.synchronize()
+        assert torch.equal(s.flow_last, before), it
+    keep = s.flow_last.clone()
+    s.apply(s.local_moments(), last=False)
+    torch.cuda.synchronize()
+    assert torch.equal(s.flow_last, keep)

@@ -4,7 +4,7 @@
 gives `tr.Register(mode=...).optim(moving, target, ...)` / `reg(moving)` backed by hand-written
 HIP kernels in lib/libtrx.so (C ABI: include/trx.h).  There is no CPU fallback.
 """
-__version__ = "0.2.0"
+__version__ = "0.2.3"   # = the reference package version this host layer mirrors (ref:src/TorchRegister/__init__.py:4); C ABI: trx_version()
 
 from ._engine import AffineSolver, FlowSolver, LossSpec, SlabFlowSolver, SlabPeers, run_slabs_lockstep  # noqa: F401
 from .sharding import register_sharded  # noqa: F401

@@ -661,9 +661,15 @@ class SlabFlowSolver:
         _lib.check(rc, "trx_flow_slab_moments")
         return self.moments
 
-    def apply(self, global_moments):
-        """Pass B with the whole-volume sums ([1,8] fp64 on this device)."""
+    def apply(self, global_moments, last=None):
+        """Pass B with the whole-volume sums ([1,8] fp64 on this device).  `last`: also store the flow this update starts from into
+        flow_last (TRX_FLAG_SAVE_LAST, +12 B/voxel of stores).  run() / the peer steps ask for it on their last iteration only; a caller
+        that drives the building blocks itself (local_moments -> all-reduce -> apply) gets it on EVERY call unless it says last=False,
+        so that flow_last is never stale (the flag-less default used to leave it uninitialised)."""
         gm = global_moments.contiguous()
+        if self.flow_last is not None and not getattr(self, "_driven", False):
+            want = True if last is None else bool(last)
+            self.vol.flags = (int(self.vol.flags) & ~_lib.FLAG_SAVE_LAST) | (_lib.FLAG_SAVE_LAST if want else 0)
         st = self._state()
         if not self.smooth and self._fuse:   # one pass: the update also produces the partials of the updated flow
             with torch.cuda.device(self.device):
@@ -722,7 +728,8 @@ class SlabFlowSolver:
             self._side = torch.cuda.Stream(device=self.device)
             self._edge = torch.zeros(1, 8, dtype=torch.float64, device=self.device)
         main = torch.cuda.current_stream(self.device)
-        base_flags = int(self.vol.flags)
+        base_flags = int(self.vol.flags) & ~_lib.FLAG_SAVE_LAST
+        self._driven = True   # (apply() leaves the SAVE_LAST bit to this loop)
         for it in range(int(iters)):
             # flow_last (the flow of the last forward) is written by the iteration that meets stop_crit, or by the last one of the run:
             # only that one pays the extra 12 B/voxel of stores
@@ -744,6 +751,7 @@ class SlabFlowSolver:
                 dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.group)   # 64 bytes per iteration
             self.apply(m)
         self.vol.flags = base_flags
+        self._driven = False
 
     # -- one iteration over the peer-mapped transport, in three steps so that ONE process can drive several slabs in lock step
     # (run_slabs_lockstep: every slab posts, then every slab joins, then every slab finishes - no wait is enqueued before the write it
@@ -751,7 +759,8 @@ class SlabFlowSolver:
     def peer_post(self, last=False, side_stream=True):
         """Sends the boundary planes (their copies and flags on a side stream, so they travel while pass A runs) and runs pass A."""
         pr = self.peers
-        self._base_flags = getattr(self, "_base_flags", int(self.vol.flags))
+        self._base_flags = getattr(self, "_base_flags", int(self.vol.flags) & ~_lib.FLAG_SAVE_LAST)
+        self._driven = True
         self.vol.flags = self._base_flags | (_lib.FLAG_SAVE_LAST if (self.flow_last is not None and last) else 0)
         if not self.smooth:
             self._m = self.local_moments()
@@ -798,6 +807,7 @@ class SlabFlowSolver:
         self.peers.gather(self._m)
         self.apply(self._m)
         self.vol.flags = self._base_flags
+        self._driven = False
 
 
 def run_slabs_lockstep(solvers, iters):

@@ -1994,6 +1994,16 @@ static int use_dual(const trx_volumes *vol)
 
 // Does a launch of the step kernels offer the z-streaming body to its pairs?  Sizes only (the theta part is zs_fits on the device):
 // the shape must tile, and the launch must fill the chip with blocks of useful length (small problems stay with the tile kernels).
+// Block slots of the device for the 512-thread step kernels: two per CU (LDS and registers allow exactly two) - 512 on MI355X (256 CUs).
+// The size of the flat grid and the yardstick of the offer rules below; queried per launch (the runtime caches device attributes).
+static int persistent_blocks()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return TRX_PERSISTENT_BLOCKS;
+    return 2 * cus;
+}
+
 static ZGeom zs_launch_geom(const trx_volumes &v)
 {
     ZGeom none = ZGeom{};
@@ -2004,7 +2014,8 @@ static ZGeom zs_launch_geom(const trx_volumes &v)
     if (zb < TRX_ZS_MIN_BLOCKS || g.planes_per_seg < TRX_ZS_MIN_PLANES) return none;
     // between one block per CU and a full round the streaming blocks share CUs unevenly; where the tile kernels fit ONE round of block
     // slots they win that case (3 x 192^3: 62 us against 69), everywhere else measured the streaming body is ahead
-    if (zb > TRX_PERSISTENT_BLOCKS / 2 && zb < TRX_PERSISTENT_BLOCKS && (long)tile_geom<GeomA>(v).blocks_per_pair * v.B <= TRX_PERSISTENT_BLOCKS) return none;
+    const int slots = persistent_blocks();
+    if (zb > slots / 2 && zb < slots && (long)tile_geom<GeomA>(v).blocks_per_pair * v.B <= slots) return none;
     return g;
 }
 
@@ -2130,7 +2141,9 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             if (zg.blocks_per_pair > gxx) gxx = zg.blocks_per_pair;
             int *ru = aware ? (int *)((char *)partials + ws.off_rows_used) : nullptr;
             // big batches of the step kernels: a flat grid of persistent blocks over a pair-major work list (no surplus blocks; see the kernel)
-            const bool flat = step_kernel && TRX_DEEP_TILE && TRX_FLAT_GRID && vol->B <= 64 && (long)gxx * vol->B >= 2 * TRX_PERSISTENT_BLOCKS;
+            const int slots = persistent_blocks();
+            // (B <= 64: the flat grid keeps one pair's state per lane)
+            const bool flat = step_kernel && TRX_DEEP_TILE && TRX_FLAT_GRID && vol->B <= 64 && (long)gxx * vol->B >= 2 * slots;
             // the exact-footprint kernel (rotated pairs that GeomR would take) behind launches that fill the chip: columns of at most 64 of its tiles
             const TileGeom tef = tile_geom<GeomRD>(*vol);   // (its 16^3 tiling is GeomRD's)
             const int eft = (TRX_EFT_BODY && step_kernel && TRX_DEEP_TILE && ru && tef.tiles_per_seg <= 64 && !(vol->flags & TRX_FLAG_NO_EFT) &&
@@ -2139,12 +2152,12 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             if constexpr (MODE == 0 || MODE == 4) {
                 if (eft) {   // in front of the step kernel: takes its pairs and marks them rows_used < 0 (none - the usual case next to the identity - costs ~3 us)
                     const int wd = td.blocks_per_pair > 0, wrd = trd.blocks_per_pair > 0, zp = zg.blocks_per_pair > 0 ? zg.planes_per_seg : 0;
-                    if (flat) hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(TRX_PERSISTENT_BLOCKS, 1), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, gxx, wd, wrd, zp);
+                    if (flat) hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(slots, 1), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, gxx, wd, wrd, zp);
                     else hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(tef.blocks_per_pair, vol->B), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, -gxx, wd, wrd, zp);
                     TRX_CHECK_LAUNCH();
                 }
             }
-            if (flat) launch_dual<MODE>(dim3(TRX_PERSISTENT_BLOCKS, 1), s, v, theta, ta, tr, 1, partials, 1, 0, td, trd, zg, ru, gxx, eft);
+            if (flat) launch_dual<MODE>(dim3(slots, 1), s, v, theta, ta, tr, 1, partials, 1, 0, td, trd, zg, ru, gxx, eft);
             else launch_dual<MODE>(dim3(gxx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd, zg, ru, 0, eft);
             TRX_CHECK_LAUNCH();
             *nblk = gxx;

@@ -12,12 +12,15 @@
 //     row table E[(y, z)] = byte address of x = 0 of that row turns the gather's address into  E + 4 floor(x)  - two more LDS reads and two
 //     more vector instructions per voxel than a dense box, for a third of its bytes;
 //   * ~33 KB per tile instead of 78.6 KB, so a block holds TWO buffers: the granules of tile t + 1 travel global -> VGPR -> the other buffer
-//     while tile t is gathered (two batches per tile, 20 staging registers), one barrier per tile.
+//     while tile t is gathered - by LDS-DMA straight into the other buffer, a whole tile ahead - one wait and one barrier per tile.
 // Per-voxel arithmetic is tile_body's (same coordinates up to the rounding of the origin shift, same accumulators, same partial-row layout
 // as GeomRD: 16 x 16 x 16 tiles, column (x-tile, z-tile) walking y), so the finalise kernel and the tests see another choice of the same pass.
 
 #ifndef TRX_EF_DBG
 #define TRX_EF_DBG 0   // development ablation (tools/ebench.hip): bits: 1 = no staging loads, 2 = no target loads, 4 = no gather
+#endif
+#ifndef TRX_EF_STAGES
+#define TRX_EF_STAGES 2   // rows in flight in the gather (3: also the table reads of row j + 2 - measured alternative)
 #endif
 #ifndef TRX_EF_EPS
 #define TRX_EF_EPS 0.05f   // slack of every window bound: fp32 rounding of the coordinates + non-uniformity of ATen's coordinate tables
@@ -26,7 +29,6 @@
 struct ECfg {
     static constexpr int TX = 16, TY = 16, TZ = 16, Threads = 512, Waves = 8, NH = 2, Rows = 8;
     static constexpr int K = 5;              // granule slots (16 B) a thread fetches per tile
-    static constexpr int KA = 3;             // ... of which the first batch
     static constexpr int NY = 32, NZ = 32;   // rows of the plan: at most NY x NZ (any rotation of the tile with a zoom up to ~1.1)
     static constexpr int TP = 40;            // row table: entry (dy - dy0) + TP (dz - dz0).  The pitch is 8 mod 32 banks: the rows a half-wave
                                              // looks up lie in a patch of a few y by a few z, which a pitch of 32 would fold onto one bank each
@@ -191,7 +193,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     constexpr int NQ = (MODE == 0) ? 3 : (MODE == 4 ? 1 : 0);
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 4 ? kNpMse : 5);
     constexpr bool kGrad = MODE != 1;
-    constexpr int kRows = C::Rows, K = C::K, KA = C::KA;
+    constexpr int kRows = C::Rows, K = C::K;
     const int b = by;
     const int D = vol.D, H = vol.H, W = vol.W;
     const float *__restrict__ th = uni_ptr(theta + (size_t)b * TRX_PSTRIDE);
@@ -286,6 +288,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         const int g = tid + k * C::Threads;
         geo[k] = (plan_ok && g < G) ? desc[g] : 0;
     }
+    // (the DMA staging needs no vector registers for the data, so the byte offsets are kept per granule instead of being re-formed per tile)
     int w4_s, hw4_s;   // row / plane pitch of the volume in bytes, pinned in SGPRs (v_mad_u32_u24 operands)
     asm("s_mov_b32 %0, %1" : "=s"(w4_s) : "s"(W * 4));
     asm("s_mov_b32 %0, %1" : "=s"(hw4_s) : "s"(H * W * 4));
@@ -298,6 +301,9 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t0) : "v"(t1), "s"(hw4_s), "v"(t2));
         return t0;
     };
+    unsigned goff[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) goff[k] = goff_of(geo[k]);
     __syncthreads();   // desc (buffer 1) is consumed
 
     F1Acc acc;
@@ -348,58 +354,57 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             o.base = reinterpret_cast<const char *>(mov) + (o.interior ? (long long)o.dP : 0ll);
             return o;
         };
-        // ---- granule loads of one batch: ONE unconditional load per granule (a lane with nothing to fetch reads offset 0 of `mov`)
-        f4 stg[K];
-        unsigned fullmask = 0;   // boundary tiles: bit k = granule k lies wholly inside the volume, bit 8 + k = it straddles a face in x
-        auto issue_batch = [&](const TileOrg &o, int k0, int k1) {
+        // ---- the granules of a tile -> buffer `buf`, by LDS-DMA (global_load_lds_dwordx4: no staging registers).  Granule slot g = tid + 512 k
+        // sits at byte 16 g of the buffer: the 64 lanes of a wave write 1 KB of consecutive LDS per k, which is exactly what the DMA does
+        // (LDS address = M0 + 16 lane), while every lane brings its own global address (any 4-byte alignment).  All K pieces of a tile are
+        // issued at once, a whole tile ahead of their use.  Boundary tiles: granules outside the volume are not fetched (exec mask) but
+        // zero-filled with ds_write here and now - the target buffer is idle; one that straddles a face in x is patched element by element
+        // (rare, behind a wave-uniform test).
+        auto issue_tile = [&](const TileOrg &o, int buf) {
             const char *bs = uni_ptr(o.base);
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                if (k < k0 || k >= k1) continue;
-                int pk = geo[k];
-                asm volatile("" : "+v"(pk));   // (opaque: what is derived from it is re-formed per tile, not hoisted into registers that live across the walk)
-                unsigned off = goff_of(pk);
+                int pk = geo[k], tt = tid;
+                asm volatile("" : "+v"(pk), "+v"(tt));   // (opaque: what is derived from them is re-formed per tile, not hoisted into registers that live across the walk)
+                const int g = tt + k * C::Threads;
+                unsigned off = goff[k];
+                bool fetch = g < G;
                 if (!o.interior) {
                     const int gz = o.rz + dm.dz0 + (pk >> 20), gy = o.ry + dm.dy0 + ((pk >> 12) & 0xff), gx = o.rx + dm.xmin + ((pk & 0xfff) >> 2);
                     const bool rowin = ((unsigned)gz < (unsigned)D) && ((unsigned)gy < (unsigned)H);
                     const bool full = rowin && (gx >= 0) && (gx + 3 < W);
                     const bool part = rowin && !full && (gx + 3 >= 0) && (gx < W);
-                    off = full ? (unsigned)((int)off + o.dP) : 0u;
-                    fullmask = (fullmask & ~(0x101u << k)) | (full ? (1u << k) : 0u) | (part ? (0x100u << k) : 0u);
-                }
-                if (TRX_EF_DBG & 1) { stg[k] = (f4)(0.5f); continue; }
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(stg[k]) : "v"(off), "s"(bs) : "memory");
-            }
-        };
-        // ---- after landing: boundary tiles zero what lies outside the volume (a granule that straddles a face in x is patched element by
-        // element: rare, behind a wave-uniform test); then the granules go to buffer `buf`
-        auto commit_batch = [&](const TileOrg &o, int buf, int k0, int k1) {
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                if (k < k0 || k >= k1) continue;
-                asm volatile("" : "+v"(stg[k]));
-                int tt = tid;
-                asm volatile("" : "+v"(tt));   // (opaque, as above)
-                const int g = tt + k * C::Threads;
-                if (!o.interior) {
-                    if (!((fullmask >> k) & 1u)) stg[k] = (f4)(0.f);
-                    const bool part = (fullmask >> (8 + k)) & 1u;
-                    if (__builtin_amdgcn_ballot_w64(part)) {
+                    off = (unsigned)((int)off + o.dP);
+                    if (fetch && !full) {
+                        f4 v = (f4)(0.f);
                         if (part) {
-                            int pk = geo[k];
-                            asm volatile("" : "+v"(pk));
-                            const int gz = o.rz + dm.dz0 + (pk >> 20), gy = o.ry + dm.dy0 + ((pk >> 12) & 0xff), gx = o.rx + dm.xmin + ((pk & 0xfff) >> 2);
                             const float *row = mov + ((size_t)gz * H + gy) * W;
-                            f4 v;
                             v.x = ((unsigned)(gx + 0) < (unsigned)W) ? row[gx + 0] : 0.f;
                             v.y = ((unsigned)(gx + 1) < (unsigned)W) ? row[gx + 1] : 0.f;
                             v.z = ((unsigned)(gx + 2) < (unsigned)W) ? row[gx + 2] : 0.f;
                             v.w = ((unsigned)(gx + 3) < (unsigned)W) ? row[gx + 3] : 0.f;
-                            stg[k] = v;
                         }
+                        *reinterpret_cast<f4 *>(lds + buf * C::BufFloats + g * 4) = v;
                     }
+                    fetch = fetch && full;
                 }
-                if (g < G) *reinterpret_cast<f4 *>(lds + buf * C::BufFloats + g * 4) = stg[k];
+                if (TRX_EF_DBG & 1) continue;
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(fetch);
+                const unsigned ldsa = lds0 + (unsigned)(buf * C::BufFloats * 4) + (unsigned)((wave * 64 + k * C::Threads) * 16);
+                unsigned long long sv;
+                unsigned m0s;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_mov_b32 %[m0s], m0\n\t"
+                             "s_mov_b32 m0, %[l0]\n\t"
+                             "s_mov_b64 exec, %[k0]\n\t"
+                             "s_cbranch_execz 1f\n\t"
+                             "global_load_lds_dwordx4 %[o0], %[b0]\n\t"
+                             "1:\n\t"
+                             "s_mov_b64 exec, %[sv]\n\t"
+                             "s_mov_b32 m0, %[m0s]"
+                             : [sv] "=&s"(sv), [m0s] "=&s"(m0s)
+                             : [l0] "s"(ldsa), [b0] "s"(bs), [o0] "v"(off), [k0] "s"(mk)
+                             : "memory");
             }
         };
         // ---- targets: ONE register per row, refilled in place - once row j of tile t is accumulated, tv[j] receives row j of tile t + 1 -
@@ -464,7 +469,20 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
                 if (more) issue_target(ty + 1, j, tv[j]);
             };
             static_assert(kRows / 2 == 4, "four rows per call");
-            // (a third row in flight - table reads of row j + 2 - was measured: 473 against 471 us per 8 x 256^3 launch, for 4 more registers)
+#if TRX_EF_STAGES == 3
+            S1 ta = stage1(ja);
+            S1 tb = stage1(ja + 1);
+            S2 fa = stage2(ta);
+            ta = stage1(ja + 2);
+            S2 fb = stage2(tb);
+            consume(fa, ja);
+            tb = stage1(ja + 3);
+            fa = stage2(ta);
+            consume(fb, ja + 1);
+            fb = stage2(tb);
+            consume(fa, ja + 2);
+            consume(fb, ja + 3);
+#else
             S2 fa = stage2(stage1(ja));
             S2 fb = stage2(stage1(ja + 1));
             consume(fa, ja);
@@ -473,6 +491,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             fb = stage2(stage1(ja + 3));
             consume(fa, ja + 2);
             consume(fb, ja + 3);
+#endif
         };
 
         // ---------------- the column walk: tile t gathered from buffer t & 1 while tile t + 1 lands in the other one ----------------
@@ -495,8 +514,8 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             }
         };
         target_only(ty_begin, t0);
-        // Vector-memory operations of a wave per tile, in program order:  YN' A0 A1 A2 | T'0 T'1 T'2 T'3 | B0 B1 | T'4 T'5 T'6 T'7  (' = of
-        // the next tile); the counted waits below rely on that order (every target load is issued, also for rows past the volume).
+        // Vector-memory operations of a wave per tile, in program order:  YN' D0 .. D4 | T'0 .. T'7  (' = of the next tile; D = the DMA pieces,
+        // T = the targets, refilled in place row by row): everything a tile needs is requested one tile ahead, one wait + one barrier per tile.
         float tv[kRows], yn_cur = 0.f, yn_nxt = 0.f;
 #pragma unroll
         for (int j = 0; j < kRows; j++) tv[j] = 0.f;
@@ -505,9 +524,8 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             issue_yn(t0, yn_cur);
 #pragma unroll
             for (int j = 0; j < kRows; j++) issue_target(t0, j, tv[j]);
-            issue_batch(cur, 0, K);
+            issue_tile(cur, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            commit_batch(cur, 0, 0, K);
 #pragma unroll
             for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tv[j]));
             asm volatile("" : "+v"(yn_cur));
@@ -525,19 +543,12 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
                 }
                 nxt = tile_org(ty + 1);
                 issue_yn(ty + 1, yn_nxt);
-                issue_batch(nxt, 0, KA);
+                issue_tile(nxt, par ^ 1);
             }
             gather_rows(ty, cur, par, yn_cur, tv, 0, kRows / 2, more);
-            if (more) {
-                if (TRX_EF_DBG & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // batch A has landed (the four targets behind it may still fly)
-                commit_batch(nxt, par ^ 1, 0, KA);
-                issue_batch(nxt, KA, K);
-            }
             gather_rows(ty, cur, par, yn_cur, tv, kRows / 2, kRows, more);
             if (more) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                commit_batch(nxt, par ^ 1, KA, K);
 #pragma unroll
                 for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tv[j]));
                 asm volatile("" : "+v"(yn_nxt));

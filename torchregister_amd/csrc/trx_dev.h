@@ -1,5 +1,8 @@
-// Development instrumentation of the tile kernels (tools/kbench.hip builds with -DTRX_DEV -DTRX_TIMING=1 / -DTRX_LDS_PAD=n).
-// In the product library every macro below expands to nothing, so the kernels in affine.hip read without #if blocks.
+// Two kinds of macros of the tile kernels live here:
+//  * compile-time ALTERNATIVES and tuning constants (first block): their defaults ARE the product; the other values are the measured
+//    alternatives DESIGN.md quotes (tools/kbench.hip, tools/lib_variants.sh build them with -D...);
+//  * development INSTRUMENTATION (second block: TRX_DEV builds of tools/kbench.hip, -DTRX_TIMING=1 / -DTRX_LDS_PAD=n): in the product
+//    library every one of those expands to nothing, so the kernels in affine.hip read without #if blocks.
 #pragma once
 
 // ---- compile-time alternatives of the tile kernels: the defaults ARE the product; the others are the measured alternatives DESIGN.md
@@ -50,7 +53,7 @@
 #define TRX_EFT_BODY 1   // the step kernels carry the exact-footprint body for rotated pairs (0: GeomR as before - measured alternative)
 #endif
 #ifndef TRX_PERSISTENT_BLOCKS
-#define TRX_PERSISTENT_BLOCKS 512   // block slots of one MI355X for the 512-thread step kernels (two per CU): the size of the flat grid
+#define TRX_PERSISTENT_BLOCKS 512   // block slots for the 512-thread step kernels if the device cannot be queried (MI355X: 2 x 256 CUs); persistent_blocks() asks the device
 #endif
 #ifndef TRX_FLAT_GRID
 #define TRX_FLAT_GRID 1             // 0: big batches launch (largest geometry) x (pairs) blocks like the small ones (measured alternative)
