@@ -1330,13 +1330,25 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
 }
 
 // The exact-footprint kernel of a step, launched IN FRONT of affine_tile_dual_kernel.  It decides which pairs are its own - those that
-// kernel would give to GeomR (dual_choice, same arguments) and whose plan fits its buffers (counted exactly, one pair per wave) - leaves
+// kernel would give to GeomR or (eft_wants) GeomRD (dual_choice, same arguments) and whose plan fits its buffers (counted exactly, one pair per wave) - leaves
 // rows_used[b] = -(partial rows it writes) for them and 0 for the others (the step kernel behind it skips the negative ones; so does the
 // finalise kernel's reading of the count: |rows_used|), and runs them.  Why a kernel of its own: inlined into affine_tile_dual_kernel as a
 // sixth body - or called from it, or with only this decision in its prologue - it changed the code the compiler makes of the z-streaming
 // loop (a reload and a vmcnt(0) per step): the headline lost 7-12 % (profiles/r04c_eft_placement_ab.txt).
 // stride > 0: FLAT grid of persistent blocks over the pair-major list of those pairs' blocks (partial rows of stride `stride` per pair);
 // stride < 0: block (x, pair) of a (blocks_per_pair, pairs) grid, rows of stride -stride.  No pair of its own: every block leaves at once.
+// Which of the fused kernel's choices this kernel takes over: GeomR's pairs (2) always; GeomRD's (3) unless the rotation is mostly about z -
+// the pre-image of a 16^3 tile then spans ~15 source planes and GeomRD's rows stay long (measured, 8 x 256^3, us per pair-iteration,
+// GeomRD -> this kernel: R_x(0.6) 63.7 -> 47.6, R(.2,.2,.2) 58.7 -> 52.3, R(.3,.3,.3) 63.8 -> 53.3, but R_z(0.6) 50.3 -> 54.5, R_z(1.0) 50.7 -> 56.2;
+// profiles/r04g_rotation_sweep.txt).
+__device__ __forceinline__ bool eft_wants(int choice, const float *__restrict__ th, float fD, float fH, float fW)
+{
+    if (choice == 2) return true;
+    if (choice != 3) return false;
+    const float zspan = (fabsf(th[8] * fD / fW) + fabsf(th[9] * fD / fH) + fabsf(th[10])) * (float)(ECfg::TZ - 1);
+    return zspan > 17.0f;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tg, float *__restrict__ partials,
                                                                            int *__restrict__ rows_used, int stride, int with_d, int with_rd, int zs_planes)
@@ -1349,7 +1361,7 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
         if ((int)blockIdx.x >= tg.blocks_per_pair) return;
         const int b = blockIdx.y;
         const float *th = theta + (size_t)b * TRX_PSTRIDE;
-        bool take = __builtin_amdgcn_readfirstlane(dual_choice(th, fD, fH, fW, with_d != 0, with_rd != 0, zs_planes)) == 2 &&
+        bool take = __builtin_amdgcn_readfirstlane((int)eft_wants(dual_choice(th, fD, fH, fW, with_d != 0, with_rd != 0, zs_planes), th, fD, fH, fW)) &&
                     __builtin_amdgcn_readfirstlane((int)ef_candidate(th, fD, fH, fW));
         if (take) {
             const EfMap m = ef_map(th, fD, fH, fW);
@@ -1363,7 +1375,8 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
         return;
     }
     // flat: per pair (lane) the decision, one candidate pair per wave and round
-    const bool cand_l = lane < vol.B && dual_choice(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, with_d != 0, with_rd != 0, zs_planes) == 2 &&
+    const bool cand_l = lane < vol.B && eft_wants(dual_choice(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, with_d != 0, with_rd != 0, zs_planes),
+                                                  theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW) &&
                         ef_candidate(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW);
     const unsigned long long cand = __builtin_amdgcn_ballot_w64(cand_l);
     unsigned long long fit = 0;
