@@ -74,6 +74,8 @@ def run(n, seed, grad_bar=2e-4, verbose=True, only=None):
         if only is not None and it != only:
             continue
         deep = 8 if (it % 2) else 0    # TRX_FLAG_DEEP_TILE on every other case: GeomD / GeomRD wherever they fit, also on these small volumes
+        if it % 4 == 1:
+            deep |= 1024               # ... and TRX_FLAG_EFT on every fourth: the exact-footprint kernel takes every rotated pair whose plan fits
         s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=deep)
         s.run(1)
         wrp_t = eng.affine_warp(th.cuda(), mov.cuda())

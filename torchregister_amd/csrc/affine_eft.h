@@ -514,25 +514,26 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             }
         };
         target_only(ty_begin, t0);
-        // Vector-memory operations of a wave per tile, in program order:  YN' D0 .. D4 | T'0 .. T'7  (' = of the next tile; D = the DMA pieces,
-        // T = the targets, refilled in place row by row): everything a tile needs is requested one tile ahead, one wait + one barrier per tile.
-        float tv[kRows], yn_cur = 0.f, yn_nxt = 0.f;
+        // Vector-memory operations of a wave per tile, in program order:  YN' T'0 .. T'7 D0 .. D4  (' = of the next tile; T = the targets, into
+        // the OTHER of two register sets, D = the DMA pieces): everything a tile needs is requested at the START of the tile before it, so the
+        // one wait per tile finds it landed.  (Refilling the targets in place, row by row, left the last target load a few hundred cycles
+        // old at the wait: the waves of a block were parked there half of their time - SQ_WAIT_ANY 49 %.)
+        float tvA[kRows], tvB[kRows], ynA = 0.f, ynB = 0.f;
 #pragma unroll
-        for (int j = 0; j < kRows; j++) tv[j] = 0.f;
+        for (int j = 0; j < kRows; j++) tvA[j] = tvB[j] = 0.f;
         TileOrg cur = tile_org(min(t0, ty_end - 1));
         if (t0 < t1) {
-            issue_yn(t0, yn_cur);
+            issue_yn(t0, ynA);
 #pragma unroll
-            for (int j = 0; j < kRows; j++) issue_target(t0, j, tv[j]);
+            for (int j = 0; j < kRows; j++) issue_target(t0, j, tvA[j]);
             issue_tile(cur, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tv[j]));
-            asm volatile("" : "+v"(yn_cur));
+            for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tvA[j]));
+            asm volatile("" : "+v"(ynA));
         }
         __syncthreads();
-        for (int ty = t0; ty < t1; ty++) {
-            const int par = (ty - t0) & 1;
+        auto tile_step = [&](int ty, int par, float (&use)[kRows], float &yn_use, float (&load)[kRows], float &yn_load) {
             const bool more = ty + 1 < t1;
             TileOrg nxt = cur;
             if (more) {
@@ -542,20 +543,31 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
                     __syncthreads();
                 }
                 nxt = tile_org(ty + 1);
-                issue_yn(ty + 1, yn_nxt);
+                issue_yn(ty + 1, yn_load);
+#pragma unroll
+                for (int j = 0; j < kRows; j++) issue_target(ty + 1, j, load[j]);
                 issue_tile(nxt, par ^ 1);
             }
-            gather_rows(ty, cur, par, yn_cur, tv, 0, kRows / 2, more);
-            gather_rows(ty, cur, par, yn_cur, tv, kRows / 2, kRows, more);
+            gather_rows(ty, cur, par, yn_use, use, 0, kRows / 2, false);
+            gather_rows(ty, cur, par, yn_use, use, kRows / 2, kRows, false);
             if (more) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tv[j]));
-                asm volatile("" : "+v"(yn_nxt));
+                for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(load[j]));
+                asm volatile("" : "+v"(yn_load));
             }
             cur = nxt;
-            yn_cur = yn_nxt;
             __syncthreads();
+        };
+        {
+            int ty = t0;
+            while (ty < t1) {
+                tile_step(ty, 0, tvA, ynA, tvB, ynB);
+                ty++;
+                if (ty >= t1) break;
+                tile_step(ty, 1, tvB, ynB, tvA, ynA);
+                ty++;
+            }
         }
         target_only(t1, ty_end);
     } else {
