@@ -180,3 +180,35 @@ def test_rotated_trajectory_through_the_body(eng):
     assert torch.max(torch.abs(out[0][0] - out[1][0])).item() <= 1e-4 * lmax
     assert torch.max(torch.abs(out[0][1] - out[1][1])).item() <= 1e-4
     assert (out[0][0][:, -1] < out[0][0][:, 0]).all()
+
+
+def test_flat_grid_mixed_batch_against_oracle(eng):
+    """A launch that runs the FLAT grid (8 x 128^3) whose pairs alternate between poses next to the identity (z-streaming body / GeomD in the
+    fused kernel) and rotated ones (exact-footprint kernel in front of it): the two kernels share one partial-row workspace and one
+    rows_used array.  Three pairs against the C oracle, every pair against its single-pair launch, rows_used < 0 exactly for the rotated pairs."""
+    shape, B = (128, 128, 128), 8
+    mats = [np.eye(3), rot(0.5, 0.4, 0.3), np.eye(3) + 0.01 * np.sin(np.arange(9)).reshape(3, 3), rot(0.45, 0.75, 0.1), rot(0, 0, 0.5), rot(0.7, 0.8, 0.6) * 1.03,
+            np.eye(3) * 1.6, rot(0.3, 0.3, 0.3)]
+    th = torch.tensor(np.stack([np.concatenate([m, 0.01 * np.ones((3, 1))], axis=1) + 1e-3 * np.cos(np.arange(12) + i).reshape(3, 4) for i, m in enumerate(mats)]), dtype=torch.float32)
+    tgt = torch.cat([ph.blobs(shape, 900 + b) for b in range(B)]).cuda()
+    mov = torch.cat([ph.blobs(shape, 950 + b) for b in range(B)]).cuda()
+    kw = dict(w_ncc=1.0)
+    s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
+    s.run(1)
+    torch.cuda.synchronize()
+    rows = s.rows_used().tolist()
+    assert [r < 0 for r in rows] == [False, True, False, True, False, True, False, True], rows
+    t64, t32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)
+    for b in (1, 2, 5):
+        m, t = mov[b, 0].cpu().numpy(), tgt[b, 0].cpu().numpy()
+        total, _, dth, _ = oracle.c_affine_loss_grad(m.astype(np.float64), t.astype(np.float64), th[b].double().numpy(), oracle.wts(**kw), t64)
+        _, _, dth32, _ = oracle.c_affine_loss_grad(m, t, th[b].numpy(), oracle.wts(**kw), t32)
+        assert abs(s.losses[b, 0].item() - total) <= 2e-5 * max(1.0, abs(total)), b
+        assert np.max(np.abs(s.grad[b, :12].cpu().numpy().reshape(3, 4) - dth)) <= max(2e-4 * np.max(np.abs(dth)), 2.0 * np.max(np.abs(dth32 - dth))), b
+    for b in range(B):
+        s1 = eng.AffineSolver(mov[b:b + 1], tgt[b:b + 1], mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th[b:b + 1], capacity=1)
+        s1.run(1)
+        torch.cuda.synchronize()
+        assert abs(s1.losses[0, 0].item() - s.losses[b, 0].item()) <= 2e-5 * max(1.0, abs(s.losses[b, 0].item())), b
+        gb = s.grad[b, :12]
+        assert torch.max(torch.abs(s1.grad[0, :12] - gb)).item() <= 2e-4 * gb.abs().max().item(), b

@@ -2159,7 +2159,9 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             const bool flat = step_kernel && TRX_DEEP_TILE && TRX_FLAT_GRID && vol->B <= 64 && (long)gxx * vol->B >= 2 * slots;
             // the exact-footprint kernel (rotated pairs that GeomR would take) behind launches that fill the chip: columns of at most 64 of its tiles
             const TileGeom tef = tile_geom<GeomRD>(*vol);   // (its 16^3 tiling is GeomRD's)
-            const int eft = (TRX_EFT_BODY && step_kernel && TRX_DEEP_TILE && ru && tef.tiles_per_seg <= 64 && !(vol->flags & TRX_FLAG_NO_EFT) &&
+            // (sizes: its row / plane pitches are 24-bit multiplier operands, its byte offsets 32-bit)
+            const bool eft_sizes = (long)vol->H * vol->W * 4 < (1l << 24) && (size_t)vol->D * vol->H * vol->W < ((size_t)1 << 29);
+            const int eft = (TRX_EFT_BODY && step_kernel && TRX_DEEP_TILE && ru && tef.tiles_per_seg <= 64 && eft_sizes && !(vol->flags & TRX_FLAG_NO_EFT) &&
                              (flat || (vol->flags & TRX_FLAG_EFT))) ? tef.blocks_per_pair : 0;   // = the partial rows per pair of that kernel
             if (eft && tef.blocks_per_pair > gxx) gxx = tef.blocks_per_pair;
             if constexpr (MODE == 0 || MODE == 4) {
