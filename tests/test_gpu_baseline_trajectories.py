@@ -5,7 +5,8 @@
   cfg3  3-D 256^3, one pair, direct flow field + NCC + smoothness regulariser, 10 iterations of Adam (and SGD at 128^3): loss curve and
         final flow;
   cfg4  the per-GPU share of config 4 - ONE launch of 8 pairs of 256^3, affine + NCC, Adam, 20 iterations (the headline workload: the
-        z-streaming body with its flat grid): one of the eight pairs against the arbiter, loss curve and theta.
+        z-streaming body with its flat grid): three of the eight pairs against the arbiter, loss curve and theta; and the same launch in
+        RIGID mode from the reference's random initial pose (the exact-footprint kernel at every step): one pair against the arbiter.
 
 Arbiter: oracle/compose.py (the reference's loop re-composed from the ATen CPU ops at the reference's call sites,
 ref:warpings.py:67-93 / :208-233) run in fp32 AND fp64 on the host; bar = max(stated floor, 2 x the arbiter's own fp32-vs-fp64 gap)
@@ -27,7 +28,8 @@ pytestmark = pytest.mark.gpu
 S128, S256 = (128, 128, 128), (256, 256, 256)
 CFG2 = {"sgd": 2e-6, "adam": 5e-4}
 CFG3 = [("adam", 0.01, S256), ("sgd", 1.0, S128)]      # (the SGD variant of the flow loop at 128^3: the arbiter needs 9 s per 256^3 iteration)
-CFG4_LR, CFG4_PAIR = 1e-3, 5
+CFG4_LR, CFG4_PAIRS = 1e-3, (0, 5, 7)
+CFG4R_PAIR = 3
 JOBS = {}
 for _opt, _lr in CFG2.items():
     for _dt in ("float32", "float64"):
@@ -36,7 +38,9 @@ for _opt, _lr, _shape in CFG3:
     for _dt in ("float32", "float64"):
         JOBS[("cfg3", _opt, _dt)] = ("flow", _shape, 1000, _dt, _opt, _lr, 10, 1.0)
 for _dt in ("float32", "float64"):
-    JOBS[("cfg4", "adam", _dt)] = ("affine", S256, 1000 + CFG4_PAIR, _dt, "adam", CFG4_LR, 20, CFG4_PAIR)
+    for _p in CFG4_PAIRS:
+        JOBS[("cfg4", _p, _dt)] = ("affine", S256, 1000 + _p, _dt, "adam", CFG4_LR, 20, _p)
+    JOBS[("cfg4r", "adam", _dt)] = ("rigid", S256, 1000 + CFG4R_PAIR, _dt, "adam", CFG4_LR, 20, CFG4R_PAIR)
 
 
 @pytest.fixture(scope="module")
@@ -111,6 +115,24 @@ def test_cfg4_share_of_one_gpu_8x256_20_iterations(eng, refs):
     torch.cuda.synchronize()
     rows = s.rows_used().tolist()
     assert len(set(rows)) == 1 and rows[0] == 64, rows            # the z-streaming body (64 blocks per 256^3 pair) served all eight pairs
-    i = CFG4_PAIR
-    check_affine(s.losses[i].cpu().numpy().astype(np.float64), s.theta[i, :12].cpu().numpy().reshape(3, 4), refs[("cfg4", "adam", "float32")],
-                 refs[("cfg4", "adam", "float64")], ("pair", i))
+    for i in CFG4_PAIRS:   # (round 4: three of the eight pairs instead of one)
+        check_affine(s.losses[i].cpu().numpy().astype(np.float64), s.theta[i, :12].cpu().numpy().reshape(3, 4), refs[("cfg4", i, "float32")],
+                     refs[("cfg4", i, "float64")], ("pair", i))
+
+
+def test_cfg4_rigid_from_the_reference_initial_pose_8x256_20_iterations(eng, refs):
+    """Round 4: the rotated path at the headline's size as a TRAJECTORY - ONE launch of 8 x 256^3, rigid mode + NCC, Adam, 20 iterations from
+    the reference's initial pose (torch.manual_seed(0); torch.rand(6), ref:utils.py:316-321: ~0.5 / 0.77 / 0.09 rad), which the
+    exact-footprint kernel runs at every step; pair 3 against the arbiter (loss curve and theta after the last step)."""
+    iters, B = 20, 8
+    pairs = [tw.pair(S256, 1000 + i) for i in range(B)]
+    pose0 = torch.stack([tw.rigid_pose0(i) for i in range(B)])
+    s = eng.AffineSolver(torch.cat([p[0] for p in pairs]).cuda(), torch.cat([p[1] for p in pairs]).cuda(), mode="rigid", loss=eng.LossSpec(w_ncc=1.0),
+                         optimizer="adam", lr=CFG4_LR, init=pose0, capacity=iters)
+    s.run(iters)
+    torch.cuda.synchronize()
+    rows = s.rows_used().tolist()
+    assert all(r < 0 for r in rows), rows            # every pair of the last step ran the exact-footprint kernel
+    i = CFG4R_PAIR
+    check_affine(s.losses[i].cpu().numpy().astype(np.float64), s.theta[i, :12].cpu().numpy().reshape(3, 4), refs[("cfg4r", "adam", "float32")],
+                 refs[("cfg4r", "adam", "float64")], ("rigid pair", i))

@@ -14,6 +14,12 @@ def theta0_np(eps=2.5e-3, seed=0):
     return (np.eye(3, 4) + eps * np.sin(1.2345 * (k + 1.0) + 0.77 * seed)).astype(np.float32)
 
 
+def rigid_pose0(i):
+    import torch
+    torch.manual_seed(0)
+    return (torch.rand(6) + 1e-3 * torch.sin(0.7 * torch.arange(6) + i)).float()
+
+
 def smooth_flow0(shape):
     import torch
     ax = [torch.arange(n, dtype=torch.float64) for n in shape]
@@ -37,6 +43,9 @@ def run(job):
     kind, shape, seed, dtn, optimizer, lr, iters, extra = job
     dt = getattr(torch, dtn)
     mov, tgt = pair(shape, seed)
+    if kind == "rigid":   # extra = the pair's index: the reference's initial pose (torch.manual_seed(0); torch.rand(6)) + a pair-dependent nudge
+        r = compose.affine_loop(mov.to(dt), tgt.to(dt), lr, iters, optimizer=optimizer, pose0=rigid_pose0(extra), w_ncc=1.0)
+        return dict(losses=r["losses"].numpy(), thetas=r["thetas"].double().numpy(), best_idx=r["best_idx"])
     if kind == "affine":
         r = compose.affine_loop(mov.to(dt), tgt.to(dt), lr, iters, optimizer=optimizer, theta0=torch.from_numpy(theta0_np(seed=extra)), w_ncc=1.0)
         return dict(losses=r["losses"].numpy(), thetas=r["thetas"].double().numpy(), best_idx=r["best_idx"])
