@@ -134,50 +134,6 @@ __device__ __forceinline__ bool ef_candidate(const float *__restrict__ th, float
     return ef_dims(m).ok;
 }
 
-// Closed-form upper estimate of the plan's granule count from theta alone (lane-parallel, no block-wide work): the plan's cells lie in
-// the Minkowski sum of the tile's pre-image (edges E_a = 15 A e_a) and a box (hx, hy, hz) - a zonotope, whose volume is the sum of
-// |det| over the triples of its six generators - and its rows in the projection onto (y, z) (pairs of five generators); granules =
-// (cells + 3 rows) / 4.  Against the exact plan over random rotations x zooms x shears the ratio plan / estimate is 0.79 ... 0.90
-// (tools/eft_plan_check.py): the test below leaves 7 % on top of that, and a plan that still does not fit makes the body gather from
-// global memory (correct, slow).  Products are written with explicit roundings: the same bits wherever the function is inlined.
-__device__ __forceinline__ bool ef_estimate_ok(const float *__restrict__ th, float fD, float fH, float fW)
-{
-    const EfMap m = ef_map(th, fD, fH, fW);
-    const EfDims d = ef_dims(m);
-    if (!d.ok) return false;
-    const float ex = (float)(ECfg::TX - 1), hx = 5.2f, hy = 3.1f, hz = 3.1f;
-    float E[3][3];   // E[a][c]: component c of edge a
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) E[a][c] = __fmul_rn(m.A[c][a], ex);
-    auto det2 = [](float a, float b, float c, float dd) { return __fsub_rn(__fmul_rn(a, dd), __fmul_rn(b, c)); };
-    // volume: (E0, E1, E2)
-    float vol = fabsf(__fadd_rn(__fadd_rn(__fmul_rn(E[0][0], det2(E[1][1], E[1][2], E[2][1], E[2][2])), -__fmul_rn(E[0][1], det2(E[1][0], E[1][2], E[2][0], E[2][2]))),
-                                __fmul_rn(E[0][2], det2(E[1][0], E[1][1], E[2][0], E[2][1]))));
-    const float h[3] = {hx, hy, hz};
-    // (E_a, E_b, h_c e_c): h_c |(E_a x E_b)_c|;  (E_a, h_c e_c, h_d e_d): h_c h_d |E_a,e| with e the third axis
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b = a + 1; b < 3; b++) {
-            vol = __fadd_rn(vol, __fmul_rn(h[0], fabsf(det2(E[a][1], E[a][2], E[b][1], E[b][2]))));
-            vol = __fadd_rn(vol, __fmul_rn(h[1], fabsf(det2(E[a][0], E[a][2], E[b][0], E[b][2]))));
-            vol = __fadd_rn(vol, __fmul_rn(h[2], fabsf(det2(E[a][0], E[a][1], E[b][0], E[b][1]))));
-        }
-    float rows = __fmul_rn(hy, hz);
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        vol = __fadd_rn(vol, __fadd_rn(__fadd_rn(__fmul_rn(__fmul_rn(hy, hz), fabsf(E[a][0])), __fmul_rn(__fmul_rn(hx, hz), fabsf(E[a][1]))), __fmul_rn(__fmul_rn(hx, hy), fabsf(E[a][2]))));
-        rows = __fadd_rn(rows, __fadd_rn(__fmul_rn(hy, fabsf(E[a][2])), __fmul_rn(hz, fabsf(E[a][1]))));
-#pragma unroll
-        for (int b = a + 1; b < 3; b++) rows = __fadd_rn(rows, fabsf(det2(E[a][1], E[a][2], E[b][1], E[b][2])));
-    }
-    vol = __fadd_rn(vol, __fmul_rn(__fmul_rn(hx, hy), hz));
-    const float est = __fmul_rn(0.25f, __fadd_rn(vol, __fmul_rn(3.0f, rows)));
-    return __fmul_rn(est, 0.97f) <= (float)ECfg::GCap;   // NaN compares false
-}
-
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));
 
@@ -417,7 +373,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             const int Y0 = ty * C::TY;
             const float *trow = tgt + (size_t)min(Y0 + j, H - 1 - j0) * W;   // (a row past the volume: any valid address; never accumulated)
             if (TRX_EF_DBG & 2) { tvj = 1.f; return; }
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(tvj) : "v"(toffb), "s"(trow) : "memory");
+            asm volatile("global_load_dword %0, %1, %2" TRX_TGT_POLICY : "=v"(tvj) : "v"(toffb), "s"(trow) : "memory");
         };
         // ---- gather of rows [ja, jb) of tile `ty` from buffer `buf`
         auto gather_rows = [&](int ty, const TileOrg &o, int buf, float yn_l, float (&tv)[kRows], int ja, int jb, bool more) {

@@ -274,7 +274,7 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 if (TRX_ZS_DBG & 2) { tv[j] = 1.f; continue; }
-                asm volatile("global_load_dword %0, %1, %2" : "=v"(tv[j]) : "v"(toffb), "s"(trow + (size_t)j * W) : "memory");
+                asm volatile("global_load_dword %0, %1, %2" TRX_ZS_TGT_POLICY : "=v"(tv[j]) : "v"(toffb), "s"(trow + (size_t)j * W) : "memory");
             }
         };
         const int bpb = (int)ring_lds - (oy * C::BW + ox) * 4;   // LDS byte address of (x = 0, y = 0) of ring slot 0

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(TRX_BLOCK) void flow_update_kernel(trx_volumes vol,
 // ---------------------------------------------------------------------------------------------------
 struct ColGeom {
     int ntx, nty, nzseg, planes_per_seg, nblk;
+    int colw_log2;   // a block covers 2^colw_log2 (x) by TRX_BLOCK >> colw_log2 (y) columns: 64 x 4, 128 x 2 or 256 x 1
 };
 
 // The eight corners of a trilinear sample, fetched now and interpolated later (the column walk requests the corners of trip z + 1 while
@@ -446,14 +447,35 @@ __device__ __forceinline__ float lerp_corners3(const Corners3 &c, float *d)
     d[0] = s.dz; d[1] = s.dy; d[2] = s.dx;
     return s.v;
 }
-constexpr int kColRows = TRX_BLOCK / 64;
+// Streams of the update pass that are touched once per iteration - the optimiser state (read, written), the updated flow (written), the
+// target (read) - carry the non-temporal hint: they are 1.3 GB a pass, nothing of them survives in the caches until the next pass, and
+// without the hint they evict the moving volume and the flow planes that the gathers and the regulariser's neighbours DO re-read
+// (256^3 Adam 310 -> 247 us per iteration, Adam + smoothness 338 -> 303; profiles/r04h_flow_variants.txt).
+#ifndef TRX_FLOW_NT
+#define TRX_FLOW_NT 7      // bit 0: stores of flow / m / v, bit 1: loads of m / v, bit 2: loads of the target (0: development baseline)
+#endif
+template <typename T> __device__ __forceinline__ void st_stream(T *p, T v) { if constexpr (TRX_FLOW_NT & 1) __builtin_nontemporal_store(v, p); else *p = v; }
+template <typename T> __device__ __forceinline__ T ld_stream(const T *p) { if constexpr (TRX_FLOW_NT & 2) return __builtin_nontemporal_load(p); else return *p; }
+template <typename T> __device__ __forceinline__ T ld_stream4(const T *p) { if constexpr (TRX_FLOW_NT & 4) return __builtin_nontemporal_load(p); else return *p; }
 
+// Block shape: as wide in x as the rows allow without idle lanes - every stream then moves 1 KB of one row per block and trip (64 x 4
+// blocks moved four 256-byte pieces of four rows: 5 % slower at W = 256) - falling back to narrower blocks when W is not a multiple.
+#ifndef TRX_FLOW_BLOCKS
+#define TRX_FLOW_BLOCKS 2048
+#endif
 static ColGeom flow_col_geom(const trx_volumes &v)
 {
     ColGeom g;
-    g.ntx = (v.W + 63) / 64; g.nty = (v.H + kColRows - 1) / kColRows;
+    g.colw_log2 = 6;
+    long best = ((long)v.W + 63) / 64 * 64;
+    for (int l2 = 7; l2 <= 8; l2++) {
+        const long w = 1L << l2, padded = ((long)v.W + w - 1) / w * w;
+        if (padded <= best && (TRX_BLOCK >> l2) >= 1) { best = padded; g.colw_log2 = l2; }
+    }
+    const int colw = 1 << g.colw_log2, rows = TRX_BLOCK >> g.colw_log2;
+    g.ntx = (v.W + colw - 1) / colw; g.nty = (v.H + rows - 1) / rows;
     const long cols = (long)g.ntx * g.nty * v.B;
-    long want = (2048 + cols - 1) / cols;            // ~2048 blocks in flight (8 per CU at the kernels' 7-8 waves per SIMD)
+    long want = (TRX_FLOW_BLOCKS + cols - 1) / cols; // ~2048 blocks in flight (8 per CU at the kernels' 7-8 waves per SIMD)
     if (want > v.D / 8) want = v.D / 8;              // a segment start costs one extra plane of flow loads
     if (want < 1) want = 1;
     g.planes_per_seg = (int)((v.D + want - 1) / want);
@@ -471,7 +493,8 @@ struct ColWalk {
         int l = blockIdx.x;
         if ((g.nblk & 7) == 0) l = (l & 7) * (g.nblk >> 3) + (l >> 3);   // blocks b, b + 8, ... share an XCD: give it a contiguous run of columns
         const int ncol = g.ntx * g.nty, zs = l / ncol, c = l - zs * ncol, ty = c / g.ntx, tx = c - ty * g.ntx;
-        x = tx * 64 + (threadIdx.x & 63); y = ty * kColRows + (threadIdx.x >> 6);
+        const int cl2 = g.colw_log2;
+        x = (tx << cl2) + (int)(threadIdx.x & ((1u << cl2) - 1u)); y = ty * (TRX_BLOCK >> cl2) + (int)(threadIdx.x >> cl2);
         z0 = zs * g.planes_per_seg; z1 = min(z0 + g.planes_per_seg, D);
         active = (x < W) && (y < H) && (z0 < z1);
         i = active ? (unsigned)((z0 * H + y) * W + x) : 0u;
@@ -573,7 +596,7 @@ __global__ __launch_bounds__(TRX_BLOCK, SMOOTH ? 4 : 5) void flow_update3_kernel
         const unsigned dyl = y > 0 ? (unsigned)W : 0u, dyh = y + 1 < H ? (unsigned)W : 0u, dxl = x > 0 ? 1u : 0u, dxh = x + 1 < W ? 1u : 0u;
         const size_t hidx = (size_t)y * W + x;
         unsigned i = cw.i;
-        float fc[3], fm[3] = {0.f, 0.f, 0.f}, tc = tgt[i];
+        float fc[3], fm[3] = {0.f, 0.f, 0.f}, tc = ld_stream4(tgt + i);
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) fc[ch] = fl[ch * (size_t)nvox + i];
         if constexpr (SMOOTH) {   // the plane below the segment's first: the flow itself, the lower slab's plane, or (first plane of the volume) the voxel itself
@@ -590,10 +613,11 @@ __global__ __launch_bounds__(TRX_BLOCK, SMOOTH ? 4 : 5) void flow_update3_kernel
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 sd.m[ch] = sd.v[ch] = sd.yl[ch] = sd.yh[ch] = sd.xl[ch] = sd.xh[ch] = 0.f;
-                if (adam) { sd.m[ch] = am[ch * (size_t)nvox + iv]; sd.v[ch] = av[ch * (size_t)nvox + iv]; }
+                if (adam) { sd.m[ch] = ld_stream(am + ch * (size_t)nvox + iv); sd.v[ch] = ld_stream(av + ch * (size_t)nvox + iv); }
                 if constexpr (SMOOTH) {
                     const float *fch = fl + ch * (size_t)nvox;
-                    sd.yl[ch] = fch[iv - dyl]; sd.yh[ch] = fch[iv + dyh]; sd.xl[ch] = fch[iv - dxl]; sd.xh[ch] = fch[iv + dxh];
+                    sd.yl[ch] = fch[iv - dyl]; sd.yh[ch] = fch[iv + dyh];
+                    sd.xl[ch] = fch[iv - dxl]; sd.xh[ch] = fch[iv + dxh];
                 }
             }
             return sd;
@@ -618,8 +642,11 @@ __global__ __launch_bounds__(TRX_BLOCK, SMOOTH ? 4 : 5) void flow_update3_kernel
             const unsigned in = i + (z_hi ? HW : 0u);
             float fn[3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) fn[ch] = fl[ch * (size_t)nvox + in];
-            const float tn = tgt[in];
+            for (int ch = 0; ch < 3; ch++) {
+                if constexpr ((TRX_FLOW_NT & 8) && !SMOOTH) fn[ch] = __builtin_nontemporal_load(fl + ch * (size_t)nvox + in);
+                else fn[ch] = fl[ch * (size_t)nvox + in];
+            }
+            const float tn = ld_stream4(tgt + in);
             const Side nxt = load_side(in);   // (the last trip of the volume re-reads its own voxel: harmless, discarded)
             float d[3];
             const float w = lerp_corners3(gc, d);
@@ -651,13 +678,13 @@ __global__ __launch_bounds__(TRX_BLOCK, SMOOTH ? 4 : 5) void flow_update3_kernel
                         const float m0 = cur.m[ch], v0 = cur.v[ch];
                         const float mi = m0 + (g - m0) * (1.0f - oc.beta1);
                         const float vi = oc.beta2 * v0 + (1.0f - oc.beta2) * g * g;
-                        am[ch * (size_t)nvox + i] = mi; av[ch * (size_t)nvox + i] = vi;
+                        st_stream(am + ch * (size_t)nvox + i, mi); st_stream(av + ch * (size_t)nvox + i, vi);
                         const float denom = sqrtf(vi) * c.inv_sqrt_bc2 + oc.eps;
                         p = p - c.step_size * (mi / denom);
                     } else {
                         p = p - c.step_size * g;
                     }
-                    fo[ch * (size_t)nvox + i] = p;
+                    st_stream(fo + ch * (size_t)nvox + i, p);
                     if (fkeep) fkeep[ch * (size_t)nvox + i] = f0;
                     if constexpr (NEXT) pnew[ch] = p;
                 }
