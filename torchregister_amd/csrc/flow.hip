@@ -450,7 +450,7 @@ __device__ __forceinline__ float lerp_corners3(const Corners3 &c, float *d)
 // Streams of the update pass that are touched once per iteration - the optimiser state (read, written), the updated flow (written), the
 // target (read) - carry the non-temporal hint: they are 1.3 GB a pass, nothing of them survives in the caches until the next pass, and
 // without the hint they evict the moving volume and the flow planes that the gathers and the regulariser's neighbours DO re-read
-// (256^3 Adam 310 -> 247 us per iteration, Adam + smoothness 338 -> 303; profiles/r04h_flow_variants.txt).
+// (256^3, with the row-wide blocks below: Adam 310 -> 247 ... 265 us per iteration depending on the box, Adam + smoothness 338 -> 303; profiles/r04h_flow_variants.txt).
 #ifndef TRX_FLOW_NT
 #define TRX_FLOW_NT 7      // bit 0: stores of flow / m / v, bit 1: loads of m / v, bit 2: loads of the target (0: development baseline)
 #endif

@@ -194,6 +194,12 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
     }
 }
 
+#ifndef TRX_LNCC_NT
+#define TRX_LNCC_NT 7   // non-temporal hints - bit 0 stores of the fields, bit 1 store of the gradient, bit 2 loads of I, J at the emit of the gradient kernel
+                        // (8 x 256^3: w = 5 1890 -> 1826 us, w = 9 2323 -> 2278; one pair within the noise; profiles/r04h_lncc_variants.txt)
+#endif
+template <int BIT> __device__ __forceinline__ void st_nt(float *p, float v) { if constexpr ((TRX_LNCC_NT >> BIT) & 1) __builtin_nontemporal_store(v, p); else *p = v; }
+template <int BIT> __device__ __forceinline__ float ld_nt(const float *p) { if constexpr ((TRX_LNCC_NT >> BIT) & 1) return __builtin_nontemporal_load(p); else return *p; }
 template <int R, int MW>
 __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_fields_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
                                                                int W, int zsplit, float eps, float *__restrict__ fields, float *__restrict__ partials)
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_fields_kernel(const float 
         const float Pq = 2.0f * c * rden, Qq = Pq * c * a * rden;
         lsum += c * c * rden;
         const size_t off = ((size_t)z * H + y + o) * W + x;
-        F[off] = Pq; F[n + off] = Qq; F[2 * n + off] = (Qq * Js - Pq * Is) * inv_n;
+        st_nt<0>(F + off, Pq); st_nt<0>(F + n + off, Qq); st_nt<0>(F + 2 * n + off, (Qq * Js - Pq * Is) * inv_n);
     };
     column_walk<R, 5, 2>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, pre, emit, raw, xs);
     // block sum of the cc partials in a fixed order: butterfly inside each wave, then the 4 wave sums through LDS
@@ -270,14 +276,14 @@ __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_grad_kernel(const float *_
         IJ v = {0.f, 0.f};
         if (x < W && y + o < H) {
             const size_t off = ((size_t)z * H + y + o) * W + x;
-            v.i = I[off]; v.j = J[off];
+            v.i = ld_nt<2>(I + off); v.j = ld_nt<2>(J + off);
         }
         return v;
     };
     auto emit = [&](int z, const float (&Z)[3], int o, const IJ &v) {
         if (x >= W || y + o >= H) return;
         const size_t off = ((size_t)z * H + y + o) * W + x;
-        G[off] = scale * (v.i * Z[0] - v.j * Z[1] + Z[2]);
+        st_nt<1>(G + off, scale * (v.i * Z[0] - v.j * Z[1] + Z[2]));
     };
     column_walk<R, 3, 3>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, pre, emit, raw, xs);
 }
