@@ -134,6 +134,9 @@ __device__ __forceinline__ bool ef_candidate(const float *__restrict__ th, float
     return ef_dims(m).ok;
 }
 
+#ifndef TRX_EF_PATCH
+#define TRX_EF_PATCH 1   // an XCD's columns form 8 x 4 patches of the (x, z) tile grid (0: slabs of whole x rows, as the tile kernels; 8 x 256^3 rotated: 412 -> 405 us)
+#endif
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));
 
@@ -172,7 +175,18 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     const int yseg = bx / ncol, cb = bx - yseg * ncol;
     int col = cb;
     if ((ncol & 7) == 0) col = (cb & 7) * (ncol >> 3) + (cb >> 3);
-    const int X0 = (col % tg.ntx) * C::TX, Z0 = (col / tg.ntx) * C::TZ;
+    int colx = col % tg.ntx, colz = col / tg.ntx;
+#if TRX_EF_PATCH
+    // an XCD's columns as a compact patch of the (x, z) tile grid instead of a slab of whole x rows: the tiles its blocks work on at the
+    // same time share more of their footprints' faces (and of the 128-byte lines both touch) inside one L2
+    if ((tg.ntx & 7) == 0 && (tg.ntz & 3) == 0 && (ncol & 7) == 0 && ((ncol >> 3) & 31) == 0) {
+        const int per = ncol >> 3, k = cb & 7, i = cb >> 3;                    // XCD k, its i-th column
+        const int npx = tg.ntx >> 3, patches = per >> 5;                       // 8 x 4 patches: `patches` of them per XCD
+        const int pi = k * patches + (i >> 5), ii = i & 31;
+        colx = (pi % npx) * 8 + (ii & 7); colz = (pi / npx) * 4 + (ii >> 3);
+    }
+#endif
+    const int X0 = colx * C::TX, Z0 = colz * C::TZ;
     const int nx = min(C::TX, W - X0), nz = min(C::TZ, D - Z0);
     const bool act = (lx < nx) && (lz < nz);
     const int x = X0 + (act ? lx : 0), z = Z0 + (act ? lz : 0);
