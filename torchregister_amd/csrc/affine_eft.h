@@ -135,7 +135,8 @@ __device__ __forceinline__ bool ef_candidate(const float *__restrict__ th, float
 }
 
 #ifndef TRX_EF_PATCH
-#define TRX_EF_PATCH 1   // an XCD's columns form 8 x 4 patches of the (x, z) tile grid (0: slabs of whole x rows, as the tile kernels; 8 x 256^3 rotated: 412 -> 405 us)
+#define TRX_EF_PATCH 0   // 1: an XCD's columns form 8 x 4 patches of the (x, z) tile grid instead of slabs of whole x rows - measured alternative: the kernel alone on a
+                         // classic grid -2 % (412 -> 405 us), inside the step's flat grid +1 ... +8 % (the per-pair column rotation balances slabs, not patches)
 #endif
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));
