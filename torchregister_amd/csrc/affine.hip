@@ -1346,6 +1346,9 @@ __device__ __forceinline__ bool eft_wants(int choice, const float *__restrict__ 
     if (choice == 2) return true;
     if (choice != 3) return false;
     const float zspan = (fabsf(th[8] * fD / fW) + fabsf(th[9] * fD / fH) + fabsf(th[10])) * (float)(ECfg::TZ - 1);
+#ifdef TRX_EF_ZSPAN
+    return zspan > TRX_EF_ZSPAN;   // development
+#endif
     return zspan > 17.0f;
 }
 
