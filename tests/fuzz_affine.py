@@ -37,7 +37,8 @@ KINK_SHIFT = 2.5e-7   # normalised units = S/2 * 2.5e-7 voxels: ~1 fp32 ulp of a
 
 
 def kink_variants(theta):
-    """theta with all three translations nudged by +/- KINK_SHIFT.  At integer sample coordinates (including -1 and S, where
+    """theta with the translations nudged by +/- KINK_SHIFT - all three together and each axis on its own (a sample can sit on a lattice
+    plane of one axis only, and the joint nudge then moves it along that plane's normal by the same amount but mixes in the other two).  At integer sample coordinates (including -1 and S, where
     the zero padding starts) the trilinear value is continuous but its derivative jumps by up to a full voxel value: when a
     sample lies within fp32 rounding of such a coordinate, an fp32 evaluation may legitimately land on the other side.  How
     much that can matter for THIS theta is measured on the oracle itself: its fp64 gradient at the nudged thetas."""
@@ -46,6 +47,9 @@ def kink_variants(theta):
     for sgn in (+1.0, -1.0):
         t = th.copy(); t[:, 3] += sgn * KINK_SHIFT
         out.append(t.reshape(np.asarray(theta).shape))
+        for ax in range(3):
+            t = th.copy(); t[ax, 3] += sgn * KINK_SHIFT
+            out.append(t.reshape(np.asarray(theta).shape))
     return out
 
 
