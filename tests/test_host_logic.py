@@ -230,3 +230,26 @@ def test_compose_theta_is_the_chain_of_the_two_grids():
     assert out.shape == (4, 3, 4) and out.dtype == torch.float32 and torch.equal(out, b2)
     with pytest.raises(ValueError):
         tr.compose_theta(torch.eye(2, 3), torch.eye(3, 4))
+
+
+def test_exact_footprint_plan_model_never_misses_a_cell():
+    """The position-independent plan of the exact-footprint kernel (csrc/affine_eft.h: ef_row_window / ef_dims), in its numpy restatement
+    (tools/eft_plan_check.py): for rotated / zoomed / sheared maps the per-row x-windows cover every cell the 2 x 2 x 2 neighbourhoods of a
+    16^3 tile touch, whatever the fractional origin, and the granule count of the two bench poses fits one LDS buffer (2304 granules).  The
+    kernel itself is checked against the oracle on the GPU (tests/test_gpu_eft.py); this keeps the geometry argument honest on the CPU."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("eft_plan_check", os.path.join(ROOT, "tools", "eft_plan_check.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    rng = np.random.default_rng(3)
+    poses = [m.rot(.5, .4, .3) @ np.diag([1.05, .95, 1.02]), m.rot(0.4963, 0.7682, 0.0885), np.eye(3)]
+    for _ in range(3):
+        a = rng.random(3) * 1.2 * rng.choice([-1, 1], 3)
+        poses.append(m.rot(*a) @ np.diag(0.9 + 0.2 * rng.random(3)) + 0.05 * (rng.random((3, 3)) - 0.5))
+    for i, A in enumerate(poses):
+        rows, G, dims = m.plan(A)
+        missed, exact = m.check(A, rows, n=4, seed=i)
+        assert missed == 0
+        assert G >= exact
+        if i < 2:
+            assert G <= 2304 and dims[0] <= 32 and dims[1] <= 32

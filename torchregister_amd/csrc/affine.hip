@@ -1366,11 +1366,26 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
         const float *th = theta + (size_t)b * TRX_PSTRIDE;
         bool take = __builtin_amdgcn_readfirstlane((int)eft_wants(dual_choice(th, fD, fH, fW, with_d != 0, with_rd != 0, zs_planes), th, fD, fH, fW)) &&
                     __builtin_amdgcn_readfirstlane((int)ef_candidate(th, fD, fH, fW));
-        if (take) {
+        if (take) {   // (block-uniform) the plan's granules, counted by the whole block: two rows per thread
             const EfMap m = ef_map(th, fD, fH, fW);
             const EfDims d = ef_dims(m);
-            const int g = ef_plan_granules_wave(m, d, lane);   // (every wave counts: no barrier)
+            int cnt = 0;
+#pragma unroll
+            for (int h = 0; h < (ECfg::NY * ECfg::NZ) / ECfg::Threads; h++) {
+                const int r = wave * 64 + lane + h * ECfg::Threads, iy = r & (ECfg::NY - 1), iz = r >> 5;
+                int wlo;
+                if (iy < d.ny && iz < d.nz) cnt += ef_row_window(m, d.dy0 + iy, d.dz0 + iz, wlo);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            if (lane == 0) s_ef[wave] = cnt;
+            __syncthreads();
+            int g = 0;
+#pragma unroll
+            for (int w = 0; w < ECfg::Waves; w++) g += s_ef[w];
+            g = __builtin_amdgcn_readfirstlane(g);
             take = d.ok && g > 0 && g <= ECfg::GCap;
+            __syncthreads();   // s_ef is not touched again, but the body's prologue reuses LDS right away: keep the phases apart
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) rows_used[b] = take ? -tg.blocks_per_pair : 0;
         if (!take) return;
