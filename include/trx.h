@@ -243,6 +243,21 @@ int trx_peer_signal(unsigned *flag, unsigned value, void *stream);
 int trx_peer_wait(const unsigned *flag, unsigned value, unsigned timeout_us, int *status, void *stream);
 int trx_peer_publish(const double *sums, const void *slot_ptrs, const void *flag_ptrs, int n, unsigned value, void *stream);
 int trx_peer_gather(const double *slots, const unsigned *flags, int n, unsigned value, unsigned timeout_us, double *out, int *status, void *stream);
+/* Mailbox memory.  A flag that a RUNNING kernel polls while another device (or process) writes it must live in memory whose remote
+ * writes become visible without a kernel boundary: fine-grained device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained)), not
+ * the coarse-grained memory of an ordinary hipMalloc / caching allocator.
+ *   trx_peer_alloc  : `bytes` of zeroed fine-grained memory on the CURRENT device;          trx_peer_free releases it;
+ *   trx_peer_export : the 64-byte HIP IPC handle of such an allocation (hipIpcGetMemHandle) - to be sent to the peers by any channel;
+ *   trx_peer_import : maps a peer's handle into this process (hipIpcOpenMemHandle with hipIpcMemLazyEnablePeerAccess: enables peer
+ *                     access between the current device and the allocation's device); trx_peer_close unmaps it.
+ * They return TRX_ERR_HIP when the runtime refuses (IPC unavailable, device not visible, no peer access): the caller then keeps
+ * torch.distributed (SlabPeers.try_exchange decides that on all ranks together). */
+#define TRX_PEER_HANDLE_BYTES 64
+int trx_peer_alloc(size_t bytes, void **ptr);
+int trx_peer_free(void *ptr);
+int trx_peer_export(void *ptr, void *handle);
+int trx_peer_import(const void *handle, void **ptr);
+int trx_peer_close(void *ptr);
 /* Without the smoothness term (3-D): the update that also leaves the slab's block partials of the UPDATED flow in the workspace, and the
  * reduction of those partials to the 8 sums - together they replace trx_flow_slab_moments from the second iteration on (one pass over
  * the slab per iteration instead of two; same numbers). */

@@ -125,8 +125,9 @@ def _fallback_worker(rank, world, port, q):
     def mapper(box, group=None):
         if rank == 1:
             raise RuntimeError("no peer access from device 1 to device 0")
-        raise AssertionError("allocate() needs a GPU; never reached on the CPU")   # (rank 0 fails earlier, in allocate: also a failure)
-    peers, why = SlabPeers.try_exchange(torch.device("cpu"), 8, 8, rank, _mapper=mapper)
+        return [box, box]   # rank 0 maps fine - and must still fall back because rank 1 could not
+    cpu_box = lambda d, H, W, n: torch.zeros(SlabPeers.layout(H, W, n)[4], dtype=torch.uint8)   # (the real allocate() is fine-grained GPU memory)
+    peers, why = SlabPeers.try_exchange(torch.device("cpu"), 8, 8, rank, _mapper=mapper, _alloc=cpu_box)
     out["peers_none"], out["why"] = peers is None, why
     q.put((rank, out))
     dist.destroy_process_group()

@@ -106,7 +106,7 @@ def test_peer_wait_times_out_instead_of_hanging(eng):
     assert int(pr2.status.item()) == 2 and torch.isnan(out2).all()
 
 
-def _ipc_worker(rank, world, port, tmp, shape, bounds, iters, kw):
+def _ipc_worker(rank, world, port, tmp, shape, bounds, iters, kw, finegrained=True):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
@@ -117,7 +117,8 @@ def _ipc_worker(rank, world, port, tmp, shape, bounds, iters, kw):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     tgt, mov = ph2.blobs(shape, 1021).cuda(), ph2.blobs(shape, 1022).cuda()
-    box = e.SlabPeers.allocate(mov.device, shape[1], shape[2], world)
+    box = e.SlabPeers.allocate(mov.device, shape[1], shape[2], world, finegrained=finegrained)
+    assert (getattr(box, "_trx_mem", None) is not None) == finegrained
     boxes = e.SlabPeers.exchange(box)
     a, b = bounds[rank], bounds[rank + 1]
     s = e.SlabFlowSolver(mov, tgt[:, :, a:b].contiguous(), a, peers=e.SlabPeers(rank, boxes, shape[1], shape[2]), **kw)
@@ -129,8 +130,10 @@ def _ipc_worker(rank, world, port, tmp, shape, bounds, iters, kw):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("optimizer,lr,smooth", [("sgd", 1.0, 4.0), ("adam", 0.05, 0.0)])
-def test_two_processes_ipc_mailboxes_equal_whole_volume(eng, optimizer, lr, smooth):
+@pytest.mark.parametrize("optimizer,lr,smooth,finegrained", [("sgd", 1.0, 4.0, True), ("adam", 0.05, 0.0, True), ("sgd", 1.0, 4.0, False)])
+def test_two_processes_ipc_mailboxes_equal_whole_volume(eng, optimizer, lr, smooth, finegrained):
+    """finegrained: mailboxes from trx_peer_alloc (hipExtMallocWithFlags, fine-grained) shared by their raw HIP IPC handles - the default;
+    False: torch caching-allocator tensors shared through torch's storage IPC (round 3's path, kept for comparison)."""
     import torch.multiprocessing as mp
     shape, bounds, iters = (36, 28, 40), [0, 14, 36], 6
     kw = dict(loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), optimizer=optimizer, lr=lr, capacity=iters, smooth_weight=smooth)
@@ -140,7 +143,7 @@ def test_two_processes_ipc_mailboxes_equal_whole_volume(eng, optimizer, lr, smoo
     torch.cuda.synchronize()
     with tempfile.TemporaryDirectory() as tmp:
         port = 29300 + (os.getpid() % 250)
-        mp.spawn(_ipc_worker, args=(2, port, tmp, shape, bounds, iters, kw), nprocs=2, join=True)
+        mp.spawn(_ipc_worker, args=(2, port, tmp, shape, bounds, iters, kw, finegrained), nprocs=2, join=True)
         parts = [torch.load(os.path.join(tmp, f"rank{r}.pt")) for r in range(2)]
     flow = torch.cat([p["flow"] for p in parts], dim=2)
     for p in parts:
@@ -207,3 +210,26 @@ def test_apply_outside_run_keeps_flow_last_current(eng):
     s.apply(s.local_moments(), last=False)
     torch.cuda.synchronize()
     assert torch.equal(s.flow_last, keep)
+
+
+def test_finegrained_mailbox_is_wrapped_in_place_and_freed(eng):
+    """SlabPeers.allocate: fine-grained memory from trx_peer_alloc, zeroed, seen by torch at the same address (no copy), exportable as a
+    64-byte HIP IPC handle; the allocation is released when the last tensor on it goes away."""
+    box = eng.SlabPeers.allocate(torch.device("cuda", 0), 8, 8, 2)
+    mem = box._trx_mem
+    assert box.dtype == torch.uint8 and box.is_cuda and box.data_ptr() == mem.ptr and box.numel() == eng.SlabPeers.layout(8, 8, 2)[4]
+    assert int(box.sum().item()) == 0
+    box[:16] = 7
+    torch.cuda.synchronize()
+    assert int(box[:32].sum().item()) == 7 * 16
+    h = mem.export()
+    assert isinstance(h, bytes) and len(h) == 64 and any(h)
+    view = box[4:12].view(torch.float32)
+    del box
+    assert view.is_cuda and mem.ptr != 0          # a view keeps the memory
+    del view
+    import gc
+    gc.collect()
+    assert mem.ptr != 0                           # ... and so does our own reference to the holder
+    mem.close()
+    assert mem.ptr == 0

@@ -385,6 +385,57 @@ def flow_loss_grad(moving, target, flow, loss, need_grad=True):
     return terms, dfl
 
 
+class _PeerMemory:
+    """Fine-grained device memory of the peer transport: an allocation of this process (trx_peer_alloc) or the mapping of a peer's
+    (trx_peer_import), handed to torch through __cuda_array_interface__ (no copy; the tensor keeps this object alive)."""
+
+    def __init__(self, ptr, nbytes, owned):
+        self.lib = _lib.load()
+        self.ptr, self.nbytes, self.owned = int(ptr), int(nbytes), bool(owned)
+
+    @staticmethod
+    def allocate(nbytes):
+        lib = _lib.load()
+        p = ctypes.c_void_p()
+        _lib.check(lib.trx_peer_alloc(int(nbytes), ctypes.byref(p)), "trx_peer_alloc")
+        return _PeerMemory(p.value, nbytes, True)
+
+    @staticmethod
+    def open(handle, nbytes):
+        lib = _lib.load()
+        buf = ctypes.create_string_buffer(bytes(handle), 64)
+        p = ctypes.c_void_p()
+        _lib.check(lib.trx_peer_import(buf, ctypes.byref(p)), "trx_peer_import")
+        return _PeerMemory(p.value, nbytes, False)
+
+    def export(self):
+        buf = ctypes.create_string_buffer(64)
+        _lib.check(self.lib.trx_peer_export(self.ptr, buf), "trx_peer_export")
+        return bytes(buf.raw)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def tensor(self):
+        t = torch.as_tensor(self)   # (no device argument: a mapping of a peer's memory must stay where it is, not be copied here)
+        if t.data_ptr() != self.ptr or t.numel() != self.nbytes or t.dtype != torch.uint8:
+            raise RuntimeError("torch did not wrap the peer memory in place")
+        t._trx_mem = self
+        return t
+
+    def close(self):
+        if self.ptr:
+            (self.lib.trx_peer_free if self.owned else self.lib.trx_peer_close)(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 class SlabPeers:
     """Peer-mapped transport for SlabFlowSolver (include/trx.h: trx_peer_*): one MAILBOX per rank - device memory that the other ranks
     of the node write into directly (HIP IPC / peer access; xGMI between GPUs) - instead of torch.distributed P2P and all_reduce.
@@ -408,8 +459,17 @@ class SlabPeers:
         return plane, slots, per_parity, flags_off, (total + 255) // 256 * 256
 
     @staticmethod
-    def allocate(device, H, W, world):
-        return torch.zeros(SlabPeers.layout(H, W, world)[4], dtype=torch.uint8, device=device)
+    def allocate(device, H, W, world, finegrained=True):
+        """This rank's mailbox as a uint8 tensor.  finegrained (default): memory from trx_peer_alloc - hipExtMallocWithFlags(
+        hipDeviceMallocFinegrained) - whose remote writes a polling kernel sees without a kernel boundary, shared with the peers by its raw
+        HIP IPC handle; False: a tensor of torch's caching allocator (coarse-grained: only for slabs driven from ONE process)."""
+        nbytes = SlabPeers.layout(H, W, world)[4]
+        if not finegrained:
+            return torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        device = torch.device(device)
+        with torch.cuda.device(device):
+            mem = _PeerMemory.allocate(nbytes)
+        return mem.tensor()
 
     @staticmethod
     def exchange(box, group=None):
@@ -418,6 +478,15 @@ class SlabPeers:
         every GPU of the group (no per-rank HIP_VISIBLE_DEVICES): a handle is re-opened on the SENDER's device index."""
         import torch.distributed as dist
         world, rank = dist.get_world_size(group), dist.get_rank(group)
+        mem = getattr(box, "_trx_mem", None)
+        if mem is not None:   # fine-grained mailbox: its raw HIP IPC handle (no dependence on the sender's device numbering)
+            handles = [None] * world
+            dist.all_gather_object(handles, (mem.export(), box.numel()), group=group)
+            boxes = []
+            with torch.cuda.device(box.device):
+                for r, (h, n) in enumerate(handles):
+                    boxes.append(box if r == rank else _PeerMemory.open(h, n).tensor())
+            return boxes
         handle = box.untyped_storage()._share_cuda_()
         handles = [None] * world
         dist.all_gather_object(handles, handle, group=group)
@@ -444,16 +513,16 @@ class SlabPeers:
         return bool(t.item())
 
     @staticmethod
-    def try_exchange(device, H, W, rank, group=None, _mapper=None):
+    def try_exchange(device, H, W, rank, group=None, _mapper=None, _alloc=None):
         """Mailbox transport if it can be set up on EVERY rank, else None (the caller keeps torch.distributed): returns (SlabPeers or None,
         reason).  What can fail: IPC export / import of the mailbox (torch.UntypedStorage._share_cuda_ / _new_shared_cuda), peer access
-        between two devices, a GPU that is not visible in some rank.  `_mapper` replaces SlabPeers.exchange in the tests."""
+        between two devices, a GPU that is not visible in some rank.  `_mapper` / `_alloc` replace SlabPeers.exchange / allocate in the tests."""
         import logging
         import torch.distributed as dist
         world = dist.get_world_size(group)
         boxes, reason = None, ""
         try:
-            box = SlabPeers.allocate(device, H, W, world)
+            box = (_alloc or SlabPeers.allocate)(device, H, W, world)
             boxes = (_mapper or SlabPeers.exchange)(box, group)
             for b in boxes:   # peer access: a cross-device mapping that cannot be read shows here, not in the middle of a run
                 if b.device != box.device:

@@ -90,6 +90,11 @@ SIGNATURES = {
     "trx_peer_wait": (ctypes.c_int, [_P, ctypes.c_uint, ctypes.c_uint, _P, _P]),
     "trx_peer_publish": (ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_uint, _P]),
     "trx_peer_gather": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_uint, ctypes.c_uint, _P, _P, _P]),
+    "trx_peer_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "trx_peer_free": (ctypes.c_int, [_P]),
+    "trx_peer_export": (ctypes.c_int, [_P, _P]),
+    "trx_peer_import": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_void_p)]),
+    "trx_peer_close": (ctypes.c_int, [_P]),
     "trx_flow_slab_update": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, ctypes.POINTER(LossCfg),
                                             ctypes.POINTER(OptCfg), ctypes.POINTER(FlowState), _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "trx_flow_slab_update_fused": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.c_int, ctypes.c_int, ctypes.POINTER(LossCfg),

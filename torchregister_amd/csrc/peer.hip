@@ -13,6 +13,7 @@
 // NaN sums, so the update that follows poisons the flow and the loss curve shows the failure even if the caller never checks.  Flags only ever increase (iteration numbers),
 // so nothing is reset; the caller double-buffers slots and halo planes by the parity of the iteration (a rank can be one iteration
 // ahead of a peer, never two: its next publish needs the peer's previous one).
+#include <cstring>
 #include "trx_common.h"
 
 namespace trx {
@@ -113,5 +114,49 @@ extern "C" int trx_peer_gather(const double *slots, const unsigned *flags, int n
     if (!slots || !flags || !out || !status || n < 1 || n > 4096) return TRX_ERR_ARG;
     hipLaunchKernelGGL(peer_gather_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slots, flags, n, value, timeout_us, out, status);
     TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
+// ---- mailbox memory: fine-grained (remote writes visible to a running kernel), shared through HIP IPC handles
+extern "C" int trx_peer_alloc(size_t bytes, void **ptr)
+{
+    if (!ptr || bytes == 0) return TRX_ERR_ARG;
+    *ptr = nullptr;
+    if (hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return TRX_ERR_HIP; }
+    if (hipMemset(*ptr, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(*ptr); *ptr = nullptr; return TRX_ERR_HIP; }
+    return TRX_OK;
+}
+
+extern "C" int trx_peer_free(void *ptr)
+{
+    if (!ptr) return TRX_ERR_ARG;
+    if (hipFree(ptr) != hipSuccess) { (void)hipGetLastError(); return TRX_ERR_HIP; }
+    return TRX_OK;
+}
+
+extern "C" int trx_peer_export(void *ptr, void *handle)
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == TRX_PEER_HANDLE_BYTES, "handle size of the header");
+    if (!ptr || !handle) return TRX_ERR_ARG;
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, ptr) != hipSuccess) { (void)hipGetLastError(); return TRX_ERR_HIP; }
+    memcpy(handle, &h, sizeof(h));
+    return TRX_OK;
+}
+
+extern "C" int trx_peer_import(const void *handle, void **ptr)
+{
+    if (!handle || !ptr) return TRX_ERR_ARG;
+    *ptr = nullptr;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    if (hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); *ptr = nullptr; return TRX_ERR_HIP; }
+    return TRX_OK;
+}
+
+extern "C" int trx_peer_close(void *ptr)
+{
+    if (!ptr) return TRX_ERR_ARG;
+    if (hipIpcCloseMemHandle(ptr) != hipSuccess) { (void)hipGetLastError(); return TRX_ERR_HIP; }
     return TRX_OK;
 }
