@@ -24,6 +24,9 @@
 
 namespace trx {
 
+#ifndef TRX_LNCC_PREFETCH
+#define TRX_LNCC_PREFETCH 1   // planes of the tile in flight ahead of the window passes (2: measured alternative - +20 registers, 8 x 256^3 w = 5 1818 -> 1932 us, w = 9 2274 -> 2251)
+#endif
 #ifndef TRX_LNCC_TWO_ROWS
 #define TRX_LNCC_TWO_ROWS 1   // 1: a thread owns two y-adjacent outputs (32 x 16 tile per plane); 0: one output (32 x 8 tile) - measured alternative
 #endif
@@ -150,6 +153,10 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
         for (int f = 0; f < NF; f++) Z[o][f] = 0.f;
     }
     plane_fetch<NL>(z0 - R, D, H, W, X0, Y0, fetch, regs);
+#if TRX_LNCC_PREFETCH == 2
+    PlaneRegs<NL> regs2;
+    plane_fetch<NL>(z0 - R + 1, D, H, W, X0, Y0, fetch, regs2);
+#endif
     for (int base = z0 - R; base < z1 + R; base += WN) {
 #pragma unroll
         for (int k = 0; k < WN; k++) {
@@ -163,10 +170,20 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
                 }
                 if (zin >= 0 && zin < D) {   // uniform
                     PlaneRegs<NL> cur = regs;
+#if TRX_LNCC_PREFETCH == 2
+                    regs = regs2;
+                    plane_fetch<NL>(zin + 2, D, H, W, X0, Y0, fetch, regs2);   // two planes in flight during this plane's passes
+#else
                     plane_fetch<NL>(zin + 1, D, H, W, X0, Y0, fetch, regs);   // next plane in flight during this plane's passes
+#endif
                     plane_window_sums<R, NF, NL>(cur, expand, raw, xs, P);
                 } else {                     // planes outside the volume are zero padding
+#if TRX_LNCC_PREFETCH == 2
+                    regs = regs2;
+                    plane_fetch<NL>(zin + 2, D, H, W, X0, Y0, fetch, regs2);
+#else
                     plane_fetch<NL>(zin + 1, D, H, W, X0, Y0, fetch, regs);
+#endif
 #pragma unroll
                     for (int o = 0; o < kLO; o++)
 #pragma unroll
