@@ -369,7 +369,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
                              "s_mov_b32 m0, %[l0]\n\t"
                              "s_mov_b64 exec, %[k0]\n\t"
                              "s_cbranch_execz 1f\n\t"
-                             "global_load_lds_dwordx4 %[o0], %[b0]\n\t"
+                             "global_load_lds_dwordx4 %[o0], %[b0]" TRX_EF_DMA_POLICY "\n\t"
                              "1:\n\t"
                              "s_mov_b64 exec, %[sv]\n\t"
                              "s_mov_b32 m0, %[m0s]"

@@ -243,10 +243,10 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
                          "s_mov_b32 %[m0s], m0\n\t"
                          "s_mov_b32 m0, %[l0]\n\t"
                          "s_mov_b64 exec, %[k0]\n\t"
-                         "global_load_lds_dwordx4 %[o0], %[b0]\n\t"
+                         "global_load_lds_dwordx4 %[o0], %[b0]" TRX_ZS_RING_POLICY "\n\t"
                          "s_mov_b32 m0, %[l1]\n\t"
                          "s_mov_b64 exec, %[k1]\n\t"
-                         "global_load_lds_dwordx4 %[o1], %[b1]\n\t"
+                         "global_load_lds_dwordx4 %[o1], %[b1]" TRX_ZS_RING_POLICY "\n\t"
                          "s_mov_b64 exec, %[sv]\n\t"
                          "s_mov_b32 m0, %[m0s]"
                          : [sv] "=&s"(sv), [m0s] "=&s"(m0s)

@@ -34,6 +34,12 @@
 #ifndef TRX_ZS_TGT_POLICY
 #define TRX_ZS_TGT_POLICY " nt"   // the z-streaming body's target loads: read once per launch, kept out of the moving planes' way (+1 % on the headline; the same hint on the exact-footprint body costs 6 %, on the tile kernels nothing)
 #endif
+#ifndef TRX_ZS_RING_POLICY
+#define TRX_ZS_RING_POLICY ""    // cache policy suffix of the z-streaming body's ring DMA (development: " nt", " sc1")
+#endif
+#ifndef TRX_EF_DMA_POLICY
+#define TRX_EF_DMA_POLICY ""     // ... of the exact-footprint kernel's granule DMA
+#endif
 #ifndef TRX_BOX_POLICY
 #define TRX_BOX_POLICY ""   // cache policy suffix of the box DMA (development: " nt", " sc1")
 #endif
