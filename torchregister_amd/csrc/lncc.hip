@@ -24,6 +24,12 @@
 
 namespace trx {
 
+#ifndef TRX_LNCC_SHARE
+#define TRX_LNCC_SHARE 0
+#endif
+#ifndef TRX_LNCC_RCP
+#define TRX_LNCC_RCP 0
+#endif
 #ifndef TRX_LNCC_PREFETCH
 #define TRX_LNCC_PREFETCH 1   // planes of the tile in flight ahead of the window passes (2: measured alternative - +20 registers, 8 x 256^3 w = 5 1818 -> 1932 us, w = 9 2274 -> 2251)
 #endif
@@ -111,6 +117,16 @@ __device__ __forceinline__ void plane_window_sums(const PlaneRegs<NL> &r, Expand
         float v[2 * R + kLO];
 #pragma unroll
         for (int k = 0; k < 2 * R + kLO; k++) v[k] = xs[f][ox][oy + 4 - R + k];
+#if TRX_LNCC_SHARE
+        {   // measured alternative: the second output's window from the first's (two adds instead of 2R + 1; no longer its own fixed-order sum)
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * R; k++) s += v[k];
+            P[0][f] = s;
+#pragma unroll
+            for (int o = 1; o < kLO; o++) { s += v[2 * R + o] - v[o - 1]; P[o][f] = s; }
+        }
+#else
 #pragma unroll
         for (int o = 0; o < kLO; o++) {
             float s = 0.f;
@@ -118,6 +134,7 @@ __device__ __forceinline__ void plane_window_sums(const PlaneRegs<NL> &r, Expand
             for (int k = 0; k <= 2 * R; k++) s += v[o + k];
             P[o][f] = s;
         }
+#endif
     }
 }
 
@@ -247,7 +264,13 @@ __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_fields_kernel(const float 
         if (x >= W || y + o >= H) return;
         const float Is = Z[0], Js = Z[1];
         const float c = Z[4] - Is * Js * inv_n, a = Z[2] - Is * Is * inv_n, bv = Z[3] - Js * Js * inv_n;
-        const float den = a * bv + eps, rden = 1.0f / den;
+        const float den = a * bv + eps;
+#if TRX_LNCC_RCP
+        float rden = __builtin_amdgcn_rcpf(den);           // v_rcp_f32 (1 ulp) + one Newton step instead of the ten-instruction IEEE division
+        rden = fmaf(fmaf(-den, rden, 1.0f), rden, rden);
+#else
+        const float rden = 1.0f / den;
+#endif
         const float Pq = 2.0f * c * rden, Qq = Pq * c * a * rden;
         lsum += c * c * rden;
         const size_t off = ((size_t)z * H + y + o) * W + x;
