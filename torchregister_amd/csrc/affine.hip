@@ -1337,19 +1337,30 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
 // loop (a reload and a vmcnt(0) per step): the headline lost 7-12 % (profiles/r04c_eft_placement_ab.txt).
 // stride > 0: FLAT grid of persistent blocks over the pair-major list of those pairs' blocks (partial rows of stride `stride` per pair);
 // stride < 0: block (x, pair) of a (blocks_per_pair, pairs) grid, rows of stride -stride.  No pair of its own: every block leaves at once.
-// Which of the fused kernel's choices this kernel takes over: GeomR's pairs (2) always; GeomRD's (3) unless the rotation is mostly about z -
-// the pre-image of a 16^3 tile then spans ~15 source planes and GeomRD's rows stay long (measured, 8 x 256^3, us per pair-iteration,
-// GeomRD -> this kernel: R_x(0.6) 63.7 -> 47.6, R(.2,.2,.2) 58.7 -> 52.3, R(.3,.3,.3) 63.8 -> 53.3, but R_z(0.6) 50.3 -> 54.5, R_z(1.0) 50.7 -> 56.2;
-// profiles/r04g_rotation_sweep.txt).
+// Which of the fused kernel's choices this kernel takes over: GeomR's pairs (2) always; GeomRD's (3) when the tile's pre-image leans out of its z
+// planes (zspan > 17 source planes per 16^3 tile, or a tilt of more than 0.07 voxels per voxel: GeomRD's rows get long), or when the in-plane rotation
+// lies between the end of GeomD's window and a sine of 0.37 - pure rotations about z beyond that stay with GeomRD.  Measured, 8 x 256^3, us per
+// pair-iteration, GeomRD -> this kernel: R_x(0.6) 63.7 -> 47.6, R(.3,.3,.3) 63.8 -> 53.3, R_z(0.25) 54.3 -> 48.6, R(.1,0,.3) 55.5 -> 48.1, but
+// R_z(0.6) 50.3 -> 54.5, R_z(1.0) 50.7 -> 56.2 (profiles/r04g_rotation_sweep.txt, profiles/r04h_eft_offer_rule.txt).
+#ifndef TRX_EF_RULE
+#define TRX_EF_RULE 1   // 0: round 4's first rule (GeomRD keeps every pair whose rotation is mostly about z)
+#endif
 __device__ __forceinline__ bool eft_wants(int choice, const float *__restrict__ th, float fD, float fH, float fW)
 {
     if (choice == 2) return true;
     if (choice != 3) return false;
-    const float zspan = (fabsf(th[8] * fD / fW) + fabsf(th[9] * fD / fH) + fabsf(th[10])) * (float)(ECfg::TZ - 1);
+    const float tilt = fabsf(th[8] * fD / fW) + fabsf(th[9] * fD / fH);                 // how far the tile's pre-image leans out of its z planes
+    const float zspan = (tilt + fabsf(th[10])) * (float)(ECfg::TZ - 1);
 #ifdef TRX_EF_ZSPAN
     return zspan > TRX_EF_ZSPAN;   // development
 #endif
+#if TRX_EF_RULE == 0
     return zspan > 17.0f;
+#else
+    if (zspan > 17.0f || tilt > 0.07f) return true;
+    const float s = fmaxf(fabsf(th[1] * fW / fH), fabsf(th[4] * fH / fW));              // in-plane rotation (its sine, in voxels)
+    return s > 0.15f && s < 0.37f;   // GeomRD's rows are at their longest just past GeomD's window (NaN compares false: GeomRD)
+#endif
 }
 
 template <int MODE>
