@@ -121,14 +121,34 @@ def _fallback_worker(rank, world, port, q):
     out["all_ok"] = SlabPeers.agree(True)
     out["one_bad"] = SlabPeers.agree(rank != 1)
     # the mapping fails on rank 1 only (what a missing peer access or an invisible device looks like): EVERY rank must fall back
+    cpu_box = lambda d, H, W, n: torch.zeros(SlabPeers.layout(H, W, n)[4], dtype=torch.uint8)   # (the real allocate() is fine-grained GPU memory)
+    export = lambda box: ("cpu", rank, box.numel())
 
-    def mapper(box, group=None):
+    def opener(box, handles, r):
+        assert [h[1] for h in handles] == list(range(world))   # the handles really travelled through all_gather_object
         if rank == 1:
             raise RuntimeError("no peer access from device 1 to device 0")
-        return [box, box]   # rank 0 maps fine - and must still fall back because rank 1 could not
-    cpu_box = lambda d, H, W, n: torch.zeros(SlabPeers.layout(H, W, n)[4], dtype=torch.uint8)   # (the real allocate() is fine-grained GPU memory)
-    peers, why = SlabPeers.try_exchange(torch.device("cpu"), 8, 8, rank, _mapper=mapper, _alloc=cpu_box)
+        return [box] * world   # rank 0 maps fine - and must still fall back because rank 1 could not
+    peers, why = SlabPeers.try_exchange(torch.device("cpu"), 8, 8, rank, _alloc=cpu_box, _export=export, _open=opener)
     out["peers_none"], out["why"] = peers is None, why
+    # the ALLOCATION fails on rank 0 only, before any collective of the exchange: rank 0 must not run ahead into the final
+    # agree() while rank 1 sits in all_gather_object - both fall back, nobody hangs, and the next collective still lines up
+    def bad_alloc(d, H, W, n):
+        if rank == 0:
+            raise MemoryError("hipExtMallocWithFlags: out of memory")
+        return cpu_box(d, H, W, n)
+    peers2, why2 = SlabPeers.try_exchange(torch.device("cpu"), 8, 8, rank, _alloc=bad_alloc, _export=export, _open=lambda box, h, r: [box] * world)
+    out["alloc_none"], out["alloc_why"] = peers2 is None, why2
+    # the export fails on rank 1 only
+    def bad_export(box):
+        if rank == 1:
+            raise RuntimeError("hipIpcGetMemHandle: invalid argument")
+        return export(box)
+    peers3, why3 = SlabPeers.try_exchange(torch.device("cpu"), 8, 8, rank, _alloc=cpu_box, _export=bad_export, _open=lambda box, h, r: [box] * world)
+    out["export_none"], out["export_why"] = peers3 is None, why3
+    t = torch.tensor([rank + 1.0])
+    dist.all_reduce(t)   # the group is still in step after three failed set-ups
+    out["sum"] = float(t.item())
     q.put((rank, out))
     dist.destroy_process_group()
 
@@ -150,4 +170,8 @@ def test_peer_transport_fallback_is_decided_by_all_ranks_together():
     for r in (0, 1):
         assert res[r]["all_ok"] is True and res[r]["one_bad"] is False
         assert res[r]["peers_none"] is True and res[r]["why"]
+        assert res[r]["alloc_none"] is True and res[r]["export_none"] is True
+        assert res[r]["sum"] == 3.0
     assert "peer access" in res[1]["why"]
+    assert "out of memory" in res[0]["alloc_why"] and "another rank" in res[1]["alloc_why"]
+    assert "hipIpcGetMemHandle" in res[1]["export_why"] and "another rank" in res[0]["export_why"]

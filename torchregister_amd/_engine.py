@@ -447,7 +447,8 @@ class SlabPeers:
         solver = SlabFlowSolver(..., peers=SlabPeers(rank, peers, H, W))
     In one process (several slabs driven in lock step on one or several GPUs: run_slabs_lockstep) the mailboxes are passed as they are."""
 
-    TIMEOUT_US = 5_000_000          # per wait; the FIRST iteration of a transport waits 6 x as long (peers still build their solvers)
+    TIMEOUT_US = 5_000_000          # per wait
+    FIRST_WAIT_FACTOR = 6           # the FIRST iteration of a transport waits this many times as long (peers still build their solvers)
 
     @staticmethod
     def layout(H, W, world):
@@ -472,35 +473,47 @@ class SlabPeers:
         return mem.tensor()
 
     @staticmethod
-    def exchange(box, group=None):
-        """All-gathers the IPC handles of the ranks' mailboxes over `group` and maps them: the list of the N mailboxes (this rank's own
-        entry is `box` itself).  The mailbox must be the only tensor of its storage (allocate() guarantees it).  Every rank must see
-        every GPU of the group (no per-rank HIP_VISIBLE_DEVICES): a handle is re-opened on the SENDER's device index."""
-        import torch.distributed as dist
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    def export_handle(box):
+        """LOCAL half of exchange(): what this rank sends to its peers so that they can map `box` (no collective inside).  Fine-grained
+        mailbox: its raw HIP IPC handle (no dependence on the sender's device numbering); torch tensor: torch's CUDA-IPC tuple."""
         mem = getattr(box, "_trx_mem", None)
-        if mem is not None:   # fine-grained mailbox: its raw HIP IPC handle (no dependence on the sender's device numbering)
-            handles = [None] * world
-            dist.all_gather_object(handles, (mem.export(), box.numel()), group=group)
-            boxes = []
-            with torch.cuda.device(box.device):
-                for r, (h, n) in enumerate(handles):
-                    boxes.append(box if r == rank else _PeerMemory.open(h, n).tensor())
-            return boxes
-        handle = box.untyped_storage()._share_cuda_()
-        handles = [None] * world
-        dist.all_gather_object(handles, handle, group=group)
+        if mem is not None:
+            return ("raw", mem.export(), box.numel())
+        return ("torch", box.untyped_storage()._share_cuda_(), box.numel())
+
+    @staticmethod
+    def open_handles(box, handles, rank):
+        """LOCAL half of exchange(): maps the peers' mailboxes from the gathered handles (this rank's own entry is `box` itself)."""
         boxes = []
         for r, h in enumerate(handles):
             if r == rank:
                 boxes.append(box)
+                continue
+            if h is None:
+                raise RuntimeError(f"rank {r} sent no mailbox handle")
+            kind, payload, n = h
+            if kind == "raw":
+                with torch.cuda.device(box.device):
+                    boxes.append(_PeerMemory.open(payload, n).tensor())
             else:
-                if int(h[0]) >= torch.cuda.device_count():
-                    raise RuntimeError(f"mailbox of rank {r} lives on device {int(h[0])}, which this process cannot see "
+                if int(payload[0]) >= torch.cuda.device_count():
+                    raise RuntimeError(f"mailbox of rank {r} lives on device {int(payload[0])}, which this process cannot see "
                                        f"({torch.cuda.device_count()} visible): the peer transport needs every GPU of the node visible in every rank")
-                st = torch.UntypedStorage._new_shared_cuda(*h)
+                st = torch.UntypedStorage._new_shared_cuda(*payload)
                 boxes.append(torch.empty(0, dtype=torch.uint8, device=st.device).set_(st))
         return boxes
+
+    @staticmethod
+    def exchange(box, group=None):
+        """All-gathers the IPC handles of the ranks' mailboxes over `group` and maps them: the list of the N mailboxes (this rank's own
+        entry is `box` itself).  The mailbox must be the only tensor of its storage (allocate() guarantees it).  Every rank must see
+        every GPU of the group (no per-rank HIP_VISIBLE_DEVICES): a handle is re-opened on the SENDER's device index.  A local failure
+        raises on that rank only - use try_exchange() where the ranks must reach one decision."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        handles = [None] * world
+        dist.all_gather_object(handles, SlabPeers.export_handle(box), group=group)
+        return SlabPeers.open_handles(box, handles, rank)
 
     @staticmethod
     def agree(ok_local, group=None):
@@ -513,29 +526,45 @@ class SlabPeers:
         return bool(t.item())
 
     @staticmethod
-    def try_exchange(device, H, W, rank, group=None, _mapper=None, _alloc=None):
+    def try_exchange(device, H, W, rank, group=None, _alloc=None, _export=None, _open=None):
         """Mailbox transport if it can be set up on EVERY rank, else None (the caller keeps torch.distributed): returns (SlabPeers or None,
-        reason).  What can fail: IPC export / import of the mailbox (torch.UntypedStorage._share_cuda_ / _new_shared_cuda), peer access
-        between two devices, a GPU that is not visible in some rank.  `_mapper` / `_alloc` replace SlabPeers.exchange / allocate in the tests."""
+        reason).  What can fail: the allocation or the IPC export of the mailbox, the IPC import of a peer's, peer access between two
+        devices, a GPU that is not visible in some rank.  Every rank runs the SAME sequence of collectives whatever fails locally
+        (ADVICE r4): [local] allocate + export -> agree -> all-gather of the handles -> [local] import + peer-access probe -> agree;
+        the local steps contain no collective, so a rank that fails in one still meets the others in the next.  `_alloc` / `_export` /
+        `_open` replace allocate / export_handle / open_handles in the tests."""
         import logging
         import torch.distributed as dist
         world = dist.get_world_size(group)
-        boxes, reason = None, ""
-        try:
+        log = logging.getLogger("torchregister_amd")
+
+        def give_up(reason):
+            why = reason or "another rank could not set up its mailbox"
+            log.warning("peer transport unavailable (%s): falling back to torch.distributed", why)
+            return None, why
+
+        box, payload, reason = None, None, ""
+        try:   # local: this rank's mailbox and its handle
             box = (_alloc or SlabPeers.allocate)(device, H, W, world)
-            boxes = (_mapper or SlabPeers.exchange)(box, group)
-            for b in boxes:   # peer access: a cross-device mapping that cannot be read shows here, not in the middle of a run
+            payload = (_export or SlabPeers.export_handle)(box)
+        except Exception as e:   # noqa: BLE001 - any failure means "use the other transport"
+            box, reason = None, f"{type(e).__name__}: {e}"
+        if not SlabPeers.agree(box is not None, group):
+            return give_up(reason)
+        handles = [None] * world
+        dist.all_gather_object(handles, payload, group=group)
+        boxes = None
+        try:   # local: map the peers' mailboxes; a cross-device mapping that cannot be read shows here, not in the middle of a run
+            boxes = (_open or SlabPeers.open_handles)(box, handles, dist.get_rank(group))
+            for b in boxes:
                 if b.device != box.device:
                     if not torch.cuda.can_device_access_peer(box.device.index, b.device.index):
                         raise RuntimeError(f"no peer access from device {box.device.index} to device {b.device.index}")
                     _ = b[:4].to(box.device)   # (also makes torch enable peer access between the two devices: hipDeviceEnablePeerAccess)
-        except Exception as e:   # noqa: BLE001 - any failure of the mapping means "use the other transport"
+        except Exception as e:   # noqa: BLE001
             boxes, reason = None, f"{type(e).__name__}: {e}"
-        ok = SlabPeers.agree(boxes is not None, group)
-        if not ok:
-            why = reason or "another rank could not map the mailboxes"
-            logging.getLogger("torchregister_amd").warning("peer transport unavailable (%s): falling back to torch.distributed", why)
-            return None, why
+        if not SlabPeers.agree(boxes is not None, group):
+            return give_up(reason)
         return SlabPeers(rank, boxes, H, W), "peer-mapped mailboxes"
 
     def __init__(self, rank, boxes, H, W):
@@ -584,7 +613,7 @@ class SlabPeers:
                 _lib.check(self.lib.trx_peer_signal(self._flag_ptr(above, 0), v, self._stream()), "trx_peer_signal")
 
     def _timeout(self):
-        return min(self.TIMEOUT_US * (6 if self.t == 0 else 1), 0xFFFFFFFF)
+        return min(int(self.TIMEOUT_US * (self.FIRST_WAIT_FACTOR if self.t == 0 else 1)), 0xFFFFFFFF)
 
     def wait_halo(self, which):
         """Blocks the current stream until the neighbour's plane of this iteration has arrived; returns the plane (a view of the mailbox)."""
@@ -609,10 +638,18 @@ class SlabPeers:
         self.t += 1
 
     def check(self):
-        """Host sync: raises when a wait timed out (a peer never wrote)."""
+        """Host sync: raises when a wait timed out (a peer never wrote).  The time-out is STICKY on the device (every later wait of this
+        transport returns at once and the sums are NaN) until reset()."""
         st = int(self.status.item())
         if st:
-            raise _lib.TrxError(f"peer transport timed out (status {st}: 1 = halo plane, 2 = sums)")
+            raise _lib.TrxError(f"peer transport timed out (status {st}: 1 = halo plane, 2 = sums); the transport stays disabled until SlabPeers.reset()")
+
+    def reset(self):
+        """Clears a sticky time-out so that the transport can be used again.  The iteration counter is NOT rewound: flag
+        values only ever rise, so every rank of the transport must call reset() after the same number of iterations - e.g. all of them
+        after a run() that raised - and the flows they continue from must be the ones they agree on (a timed-out iteration has
+        produced NaN sums on this rank)."""
+        self.status.zero_()
 
 
 class SlabFlowSolver:
@@ -784,10 +821,13 @@ class SlabFlowSolver:
             raise _lib.TrxError(f"loss-curve capacity exceeded: {self.enqueued} + {int(iters)} > {self.capacity}")
         if self.peers is not None:
             self.enqueued += int(iters)
-            for it in range(int(iters)):
-                self.peer_post(last=(it == int(iters) - 1))
-                self.peer_join()
-                self.peer_finish()
+            try:
+                for it in range(int(iters)):
+                    self.peer_post(last=(it == int(iters) - 1))
+                    self.peer_join()
+                    self.peer_finish()
+            finally:   # an exception between peer_post and peer_finish must not leave the SAVE_LAST handling to a loop that is gone
+                self._peer_restore()
             self.peers.check()   # (host sync at the end of the call: a peer that never wrote is an exception here, not a silent NaN curve)
             return
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -799,27 +839,37 @@ class SlabFlowSolver:
         main = torch.cuda.current_stream(self.device)
         base_flags = int(self.vol.flags) & ~_lib.FLAG_SAVE_LAST
         self._driven = True   # (apply() leaves the SAVE_LAST bit to this loop)
-        for it in range(int(iters)):
-            # flow_last (the flow of the last forward) is written by the iteration that meets stop_crit, or by the last one of the run:
-            # only that one pays the extra 12 B/voxel of stores
-            self.vol.flags = base_flags | (_lib.FLAG_SAVE_LAST if (self.flow_last is not None and it == int(iters) - 1) else 0)
-            if overlap:
-                self._side.wait_stream(main)                 # the previous update has produced the planes to send
-                with torch.cuda.stream(self._side):
-                    self.exchange_halos()
-                    self._edge.zero_()
-                    self.add_boundary_smooth(self._edge)
-                m = self.local_moments_without_halo()        # main stream: the whole slab, no halo needed
-                main.wait_stream(self._side)
-                m += self._edge
-            else:
+        try:
+            for it in range(int(iters)):
+                # flow_last (the flow of the last forward) is written by the iteration that meets stop_crit, or by the last one of the run:
+                # only that one pays the extra 12 B/voxel of stores
+                self.vol.flags = base_flags | (_lib.FLAG_SAVE_LAST if (self.flow_last is not None and it == int(iters) - 1) else 0)
+                if overlap:
+                    self._side.wait_stream(main)                 # the previous update has produced the planes to send
+                    with torch.cuda.stream(self._side):
+                        self.exchange_halos()
+                        self._edge.zero_()
+                        self.add_boundary_smooth(self._edge)
+                    m = self.local_moments_without_halo()        # main stream: the whole slab, no halo needed
+                    main.wait_stream(self._side)
+                    m += self._edge
+                else:
+                    if multi:
+                        self.exchange_halos()
+                    m = self.local_moments()
                 if multi:
-                    self.exchange_halos()
-                m = self.local_moments()
-            if multi:
-                dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.group)   # 64 bytes per iteration
-            self.apply(m)
-        self.vol.flags = base_flags
+                    dist.all_reduce(m, op=dist.ReduceOp.SUM, group=self.group)   # 64 bytes per iteration
+                self.apply(m)
+        finally:
+            self.vol.flags = base_flags
+            self._driven = False
+
+    def _peer_restore(self):
+        """Ends a peer-driven iteration: the flags the caller set are back and apply() handles SAVE_LAST itself again."""
+        base = getattr(self, "_base_flags", None)
+        if base is not None:
+            self.vol.flags = base
+        self._base_flags = None
         self._driven = False
 
     # -- one iteration over the peer-mapped transport, in three steps so that ONE process can drive several slabs in lock step
@@ -828,7 +878,8 @@ class SlabFlowSolver:
     def peer_post(self, last=False, side_stream=True):
         """Sends the boundary planes (their copies and flags on a side stream, so they travel while pass A runs) and runs pass A."""
         pr = self.peers
-        self._base_flags = getattr(self, "_base_flags", int(self.vol.flags) & ~_lib.FLAG_SAVE_LAST)
+        if getattr(self, "_base_flags", None) is None:   # (per iteration: peer_finish / _peer_restore clear it, so a change of vol.flags between runs is seen)
+            self._base_flags = int(self.vol.flags) & ~_lib.FLAG_SAVE_LAST
         self._driven = True
         self.vol.flags = self._base_flags | (_lib.FLAG_SAVE_LAST if (self.flow_last is not None and last) else 0)
         if not self.smooth:
@@ -873,10 +924,11 @@ class SlabFlowSolver:
 
     def peer_finish(self):
         """Whole-volume sums (every rank adds the N slots in rank order) and pass B."""
-        self.peers.gather(self._m)
-        self.apply(self._m)
-        self.vol.flags = self._base_flags
-        self._driven = False
+        try:
+            self.peers.gather(self._m)
+            self.apply(self._m)
+        finally:
+            self._peer_restore()
 
 
 def run_slabs_lockstep(solvers, iters):
