@@ -56,6 +56,8 @@ typedef enum {
 #define TRX_FLAG_ZSTREAM 64u        /* affine steps: offer the z-streaming body whatever the batch size (by default only to launches that fill the chip) */
 #define TRX_FLAG_NO_EFT 512u        /* affine steps: never use the exact-footprint body (rotated pairs run GeomR as before) */
 #define TRX_FLAG_EFT 1024u          /* affine steps: offer the exact-footprint body whatever the batch size (by default only to launches that fill the chip) */
+#define TRX_FLAG_ZS_FUSED 2048u      /* affine steps on launches that fill the chip: keep the z-streaming body inside the tile kernel (the round 3-4 form) instead of
+                                      * running it as a kernel of its own in front (measured alternative; tests compare the two) */
 #define TRX_FLAG_NO_ROT_DEEP_TILE 16u /* affine steps: never use GeomRD (the 16 x 16 x 16 tile in GeomR's box) - rotated pairs all run GeomR */
 
 /* A batch of B independent (moving, target) pairs. */

@@ -62,11 +62,11 @@ __global__ __launch_bounds__(1024) void coissue(unsigned long long *out, int ite
 }
 
 enum Op { ADD, SUB, MUL, FMAC, FMA, PKFMA, PKADD, PKMUL, FLOOR, FRACT, CVTFLR, CVTI, CVTU, PERM, MADU24, MADI24, MULU24, ADDU, AND, LSHL, LSHLADD, ADDLSHL, ADD3, MOV, CNDMASK, BFE,
-          READLANE, DPPADD, MFMA4, DSR32, DSR2, DSR2ST64, DSR64, DSR128, NOPS };
+          READLANE, DPPADD, MFMA4, ADDS, FMAS, FMAK, FMACS, PKFMAB, PKMULS, FMA3, DSR32, DSR2, DSR2ST64, DSR64, DSR128, NOPS };
 static const char *opname[] = {"v_add_f32", "v_sub_f32", "v_mul_f32", "v_fmac_f32", "v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_floor_f32", "v_fract_f32",
                                "v_cvt_flr_i32_f32", "v_cvt_i32_f32", "v_cvt_u32_f32", "v_perm_b32 (s, v, v)", "v_mad_u32_u24", "v_mad_i32_i24", "v_mul_u32_u24", "v_add_u32", "v_and_b32",
                                "v_lshlrev_b32", "v_lshl_add_u32", "v_add_lshl_u32", "v_add3_u32", "v_mov_b32", "v_cndmask_b32", "v_bfe_u32", "v_readlane_b32", "v_add_f32 dpp quad_perm",
-                               "v_mfma_f32_4x4x1_16b_f32", "ds_read_b32", "ds_read2_b32 off 0,1", "ds_read2st64_b32 off 0,45", "ds_read_b64", "ds_read_b128"};
+                               "v_mfma_f32_4x4x1_16b_f32", "v_add_f32 v,s,v", "v_fma_f32 v,v,s,v", "v_fma_f32 v,v,2.0,v", "v_fmac_f32 v,s,v", "v_pk_fma_f32 a,a,b,a", "v_pk_mul_f32 v,v,s", "v_fma_f32 d,a,b,c (4 regs)", "ds_read_b32", "ds_read2_b32 off 0,1", "ds_read2st64_b32 off 0,45", "ds_read_b64", "ds_read_b128"};
 
 template <int OP>
 __global__ __launch_bounds__(1024) void opcost(unsigned long long *out, int iters, float seed)
@@ -84,6 +84,8 @@ __global__ __launch_bounds__(1024) void opcost(unsigned long long *out, int iter
     const f2 pb = {b, c};
     int s1;
     asm volatile("s_mov_b32 %0, 0x07060504" : "=s"(s1));
+    unsigned long long s64;
+    asm volatile("s_mov_b64 %0, 0x3f800000" : "=s"(s64));
     const unsigned la = (unsigned)(uintptr_t)lds + (threadIdx.x & 63) * 4 + (threadIdx.x >> 6) * 288;   // consecutive floats per lane: the gather's pattern at theta = I
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -121,6 +123,13 @@ __global__ __launch_bounds__(1024) void opcost(unsigned long long *out, int iter
                 if constexpr (OP == READLANE) { int s; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s) : "v"(n[i])); asm volatile("" :: "s"(s)); }
                 if constexpr (OP == DPPADD) asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
                 if constexpr (OP == MFMA4) MFMA(q[i], b, c);
+                if constexpr (OP == ADDS) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[i]) : "s"(s1));
+                if constexpr (OP == FMAS) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(s1), "v"(c));
+                if constexpr (OP == FMAK) asm volatile("v_fma_f32 %0, %0, 2.0, %1" : "+v"(a[i]) : "v"(c));
+                if constexpr (OP == FMACS) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(s1), "v"(c));
+                if constexpr (OP == PKFMAB) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p[i]) : "v"(pb));
+                if constexpr (OP == PKMULS) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "s"(s64));
+                if constexpr (OP == FMA3) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(b), "v"(c));
                 if constexpr (OP == DSR32) asm volatile("ds_read_b32 %0, %1" : "=v"(a[i]) : "v"(la));
                 if constexpr (OP == DSR2) asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(p[i]) : "v"(la));
                 if constexpr (OP == DSR2ST64) asm volatile("ds_read2st64_b32 %0, %1 offset1:45" : "=v"(p[i]) : "v"(la));
@@ -181,7 +190,8 @@ static void oc(unsigned long long *out)
     printf("%-26s", opname[OP]);
     for (int wps : {1, 2, 4}) {
         const Res r = launch(opcost<OP>, out, wps, iters);
-        printf("  %dw: %6.3f ns/instr/SIMD (%5.2f tick/ns)", wps, r.real_us * 1e3 / (iters * 32.0 * wps), r.ticks / (r.real_us * 1e3));
+        const double ns = (r.wall_us - 6.0) * 1e3 / (iters * 32.0 * wps);   // wall clock (- ~6 us of launch): thread 0's own stamps only time the OLDEST wave, which the arbiter favours
+        printf("  %dw: %6.3f ns = %5.2f cyc", wps, ns, ns * r.ticks / (r.real_us * 1e3));
     }
     printf("\n");
 }
@@ -212,6 +222,6 @@ int main()
     co<0, 0, 18>(out, "mfma only");
     printf("# part 2: one instruction kind, 32 independent instances per iteration\n");
     oc_all<ADD, SUB, MUL, FMAC, FMA, PKFMA, PKADD, PKMUL, FLOOR, FRACT, CVTFLR, CVTI, CVTU, PERM, MADU24, MADI24, MULU24, ADDU, AND, LSHL, LSHLADD, ADDLSHL, ADD3, MOV, CNDMASK, BFE, READLANE, DPPADD, MFMA4,
-           DSR32, DSR2, DSR2ST64, DSR64, DSR128>(out);
+           ADDS, FMAS, FMAK, FMACS, PKFMAB, PKMULS, FMA3, DSR32, DSR2, DSR2ST64, DSR64, DSR128>(out);
     return 0;
 }

@@ -94,6 +94,34 @@ int main(int argc, char **argv)
         CK(hipDeviceSynchronize());
         check(name, zg.blocks_per_pair);
         rep(name, time_it([&] { hipLaunchKernelGGL((trx::affine_zstream_kernel<0, C>), dim3(zg.blocks_per_pair, B), dim3(C::Threads), 0, 0, vol, theta, zg, partials, zg.blocks_per_pair); }, reps));
+#if TRX_ZS_STAMP
+        {   // phases of a step, per wave (s_memtime ticks = shader cycles), and the blocks' start / end in real time (100 MHz)
+            std::vector<unsigned long long> st(512 * 8 * 8);
+            CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(trx::trx_zs_stamps), st.size() * 8));
+            double sum[6] = {0, 0, 0, 0, 0, 0};
+            unsigned long long r0min = ~0ull, r0max = 0, r1min = ~0ull, r1max = 0;
+            const int nb = std::min(512, zg.blocks_per_pair * B);
+            for (int b = 0; b < nb; b++)
+                for (int w = 0; w < 8; w++) {
+                    const unsigned long long *o = &st[((size_t)b * 8 + w) * 8];
+                    for (int k = 0; k < 5; k++) sum[k] += (double)o[k];
+                    sum[5] += (double)(o[5] & 0xffff);
+                    r0min = std::min(r0min, o[6]); r0max = std::max(r0max, o[6]); r1min = std::min(r1min, o[7]); r1max = std::max(r1max, o[7]);
+                }
+            const double nw = nb * 8.0, steps = sum[5] / nw;
+            printf("   stamps: %.0f steps per wave; per step (cycles): wait %.0f  barrier %.0f  issue %.0f  gather %.0f  = %.0f;  wave lifetime %.0f cycles\n", steps, sum[0] / sum[5], sum[1] / sum[5],
+                   sum[2] / sum[5], sum[3] / sum[5], (sum[0] + sum[1] + sum[2] + sum[3]) / sum[5], sum[4] / nw);
+            if (getenv("ZS_DUMP")) {   // per block: CU (xcc, se, sh, cu), start and end in us after the first start, wave 0's phase sums
+                for (int b = 0; b < nb; b++) {
+                    const unsigned long long *o = &st[(size_t)b * 8 * 8];
+                    const unsigned hw = (unsigned)(o[5] >> 16) & 0xffff, xcc = (unsigned)(o[5] >> 32) & 0xf;
+                    printf("   blk %3d xcc %u se %u sh %u cu %2u  start %7.2f end %7.2f  wait %6.0f bar %6.0f issue %6.0f gather %6.0f\n", b, xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15,
+                           (o[6] - r0min) / 100.0, (o[7] - r0min) / 100.0, (double)o[0] / 128, (double)o[1] / 128, (double)o[2] / 128, (double)o[3] / 128);
+                }
+            }
+            printf("   blocks: first start -> last start %.2f us, first end -> last end %.2f us, first start -> last end %.2f us\n", (r0max - r0min) / 100.0, (r1max - r1min) / 100.0, (r1max - r0min) / 100.0);
+        }
+#endif
     };
     printf("B=%d S=%d eps=%g\n", B, S, eps);
     run_zs(trx::ZS64{}, "zstream 64x32");

@@ -1188,10 +1188,12 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     static_assert(GeomA::Threads == 512 && GeomR::Threads == 512 && GeomD::Threads == 512 && GeomRD::Threads == 512, "every geometry runs 512-thread blocks");
     static_assert(GeomRD::BoxAlloc <= GeomR::BoxAlloc, "GeomRD lives in GeomR's box");
     // the step kernels (MODE 0 / 4) of the one-launch form also carry the deep tile for transforms next to the identity
-    constexpr bool kDeep = (WHICH == 0) && (MODE == 0 || MODE == 4) && (TRX_TILE_CFG == 0) && (TRX_DEEP_TILE != 0);
+    // WHICH = 4: the same without the z-streaming body - behind affine_zs_step_kernel, which has taken the pairs next to the identity
+    constexpr bool kDeep = (WHICH == 0 || WHICH == 4) && (MODE == 0 || MODE == 4) && (TRX_TILE_CFG == 0) && (TRX_DEEP_TILE != 0);
+    constexpr bool kZs = kDeep && WHICH == 0;
     constexpr int kAllocAR = GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc;
     constexpr int kAllocD = WHICH == 1 ? GeomA::BoxAlloc : (WHICH == 2 ? GeomR::BoxAlloc : ((kDeep && GeomD::BoxAlloc > kAllocAR) ? GeomD::BoxAlloc : kAllocAR));
-    constexpr int kAlloc = (kDeep && ZS64::Alloc > kAllocD) ? ZS64::Alloc : kAllocD;
+    constexpr int kAlloc = (kZs && ZS64::Alloc > kAllocD) ? ZS64::Alloc : kAllocD;
     __shared__ __attribute__((aligned(16))) float box[kAlloc];
     constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : (MODE == 4 ? kNpMse : 5));
@@ -1214,10 +1216,14 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         fD = (float)a->vol.D; fH = (float)a->vol.H; fW = (float)a->vol.W;
         nA = a->tgA.blocks_per_pair; nR = a->tgR.blocks_per_pair; nD = a->tgD.blocks_per_pair; nRD = a->tgRD.blocks_per_pair; nZ = a->zg.blocks_per_pair;
         with_d = kDeep && nD > 0; with_rd = kDeep && nRD > 0;
-        zs_planes = kDeep && nZ > 0 ? a->zg.planes_per_seg : 0;
+        zs_planes = kZs && nZ > 0 ? a->zg.planes_per_seg : 0;   // (WHICH = 4: the z-streaming test is the kernel's in front - never repeated here, where it could round differently)
         rows_stride = a->rows_stride;
         theta = a->theta;
-        with_ef = kDeep && (TRX_EFT_BODY != 0) && a->eft != 0 && a->rows_used != nullptr;
+        with_ef = kDeep && a->rows_used != nullptr && (((TRX_EFT_BODY != 0) && a->eft != 0) || WHICH == 4);   // pairs with rows_used < 0 belong to a kernel that ran in front
+        if constexpr (WHICH == 4) {   // the kernels in front left the number of pairs they did NOT take: none - the usual case next to the identity - and this launch is over
+            const int *plan = a->rows_used + a->vol.B;
+            if (__builtin_amdgcn_readfirstlane(*plan) == 0) return;
+        }
     }
     // 6 = taken by the exact-footprint kernel (affine_eft_step_kernel, launched IN FRONT of this one: it left rows_used[b] = -(its row
     // count) for the pairs it took - rotated pairs that GeomR would run and whose plan fits its buffers): no block here
@@ -1298,12 +1304,15 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
                                  a->vol.xn, a->vol.yn, a->vol.zn, a->vol.flags};
         float *partials = a->partials;
         const int channels = a->channels;
-        if constexpr (kDeep) {
+        if constexpr (kZs) {
             if (choice == 4) {
                 const ZGeom zg = {a->zg.ntx, a->zg.nty, a->zg.nzseg, a->zg.planes_per_seg, a->zg.blocks_per_pair};
-                zstream_body<MODE, ZS64>(vol, theta, zg, partials, box, v, by, stride, wave_idx);
+                zstream_body<MODE, ZS64>(vol, theta, zg, partials, box, v, by, stride, wave_idx,
+                                         (int)((blockIdx.y * gridDim.x + blockIdx.x) * 2 >= gridDim.x * gridDim.y));   // (second half of the grid = the later block of its CU)
                 continue;
             }
+        }
+        if constexpr (kDeep) {
             if (choice == 0) {
                 const TileGeom t = tile_of(&a->tgD);
                 tile_body<MODE, GeomD>(vol, theta, t, channels, partials, box, v, by, stride, wave_idx);
@@ -1342,6 +1351,48 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
 // lies between the end of GeomD's window and a sine of 0.37 - pure rotations about z beyond that stay with GeomRD.  Measured, 8 x 256^3, us per
 // pair-iteration, GeomRD -> this kernel: R_x(0.6) 63.7 -> 47.6, R(.3,.3,.3) 63.8 -> 53.3, R_z(0.25) 54.3 -> 48.6, R(.1,0,.3) 55.5 -> 48.1, but
 // R_z(0.6) 50.3 -> 54.5, R_z(1.0) 50.7 -> 56.2 (profiles/r04g_rotation_sweep.txt, profiles/r04h_eft_offer_rule.txt).
+// The z-streaming body as a kernel of its OWN for launches that fill the chip (flat grid), IN FRONT of the exact-footprint kernel and the
+// tile kernel (round 5).  Inside affine_tile_dual_kernel its loop shared the register allocation of four other bodies: the same source
+// measured 253-262 us stand-alone and 261-318 us fused, by which way the allocator fell (profiles/r05a_zstream_fused_vs_alone.txt).  This
+// kernel takes every pair whose theta passes zs_nsub - the ONLY place that test is evaluated for such a launch -, leaves
+// rows_used[b] = -(its rows) for them and 0 for the rest, the number of pairs it did NOT take in rows_used[B] and the bit mask of those it
+// took in rows_used[B + 1, B + 2]: the two kernels behind it return at once when the count is zero (a launch boundary each, ~1.5 us), and
+// otherwise skip the pairs of the mask.
+template <int MODE>
+__global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_step_kernel(trx_volumes vol, const float *__restrict__ theta, ZGeom zg, float *__restrict__ partials,
+                                                                                         int *__restrict__ rows_used, int stride)
+{
+    __shared__ __attribute__((aligned(16))) float ring[ZS64::Alloc];
+    const int wave = trx_wave_index(), lane = trx_lane_id();
+    const float fD = (float)vol.D, fH = (float)vol.H, fW = (float)vol.W;
+    const bool take_l = lane < vol.B && zs_nsub<ZS64>(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, zg.planes_per_seg) > 0;
+    const unsigned long long take = __builtin_amdgcn_ballot_w64(take_l);
+    const int mine = take_l ? zg.blocks_per_pair : 0;
+    if (blockIdx.x == 0 && wave == 0) {
+        if (lane < vol.B) rows_used[lane] = -mine;
+        if (lane == 0) {
+            rows_used[vol.B] = vol.B - __builtin_popcountll(take);
+            rows_used[vol.B + 1] = (int)(unsigned)take; rows_used[vol.B + 2] = (int)(unsigned)(take >> 32);   // which pairs: nobody rewrites this
+        }
+    }
+    if (take == 0) return;
+    int pre = mine;   // inclusive prefix sum over the lanes (pairs)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(pre, d, 64);
+        if (lane >= d) pre += t;
+    }
+    const int total = __builtin_amdgcn_readlane(pre, 63);
+    const int second = (int)(blockIdx.x * 2 >= gridDim.x);   // the later of the two blocks of a CU (TRX_ZS_PRIO)
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const int pair = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= item)));
+        const int off = pair > 0 ? __builtin_amdgcn_readlane(pre, pair - 1) : 0;
+        const int v = __builtin_amdgcn_readfirstlane(item - off);
+        if (item != (int)blockIdx.x) __syncthreads();   // the previous item's reduction scratch aliases the ring
+        zstream_body<MODE, ZS64>(vol, theta, zg, partials, ring, v, pair, stride, wave, second);
+    }
+}
+
 #ifndef TRX_EF_RULE
 #define TRX_EF_RULE 1   // 0: round 4's first rule (GeomRD keeps every pair whose rotation is mostly about z)
 #endif
@@ -1365,11 +1416,13 @@ __device__ __forceinline__ bool eft_wants(int choice, const float *__restrict__ 
 
 template <int MODE>
 __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tg, float *__restrict__ partials,
-                                                                           int *__restrict__ rows_used, int stride, int with_d, int with_rd, int zs_planes)
+                                                                           int *__restrict__ rows_used, int stride, int with_d, int with_rd, int zs_planes, int zs_first = 0)
 {
     __shared__ __attribute__((aligned(16))) float lds[ECfg::Alloc];
     __shared__ int s_ef[64];
     const int wave = trx_wave_index(), lane = trx_lane_id();
+    // zs_first (flat launches): affine_zs_step_kernel ran in front - no pair left (rows_used[B] = 0): done; else its pairs are marked rows_used < 0
+    if (zs_first && __builtin_amdgcn_readfirstlane(rows_used[vol.B]) == 0) return;
     const float fD = (float)vol.D, fH = (float)vol.H, fW = (float)vol.W;
     if (stride < 0) {   // (small launches: the body is offered by TRX_FLAG_EFT only)
         if ((int)blockIdx.x >= tg.blocks_per_pair) return;
@@ -1404,7 +1457,10 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
         return;
     }
     // flat: per pair (lane) the decision, one candidate pair per wave and round
-    const bool cand_l = lane < vol.B && eft_wants(dual_choice(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, with_d != 0, with_rd != 0, zs_planes),
+    unsigned long long zs_mask = 0;   // pairs of the kernel in front (its mask is not rewritten by anybody: block 0 of THIS kernel rewrites rows_used[b] of the free pairs)
+    if (zs_first) zs_mask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(rows_used[vol.B + 1]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(rows_used[vol.B + 2]) << 32);
+    const bool free_l = lane < vol.B && !((zs_mask >> lane) & 1ull);
+    const bool cand_l = free_l && eft_wants(dual_choice(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, with_d != 0, with_rd != 0, zs_planes),
                                                   theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW) &&
                         ef_candidate(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW);
     const unsigned long long cand = __builtin_amdgcn_ballot_w64(cand_l);
@@ -1426,7 +1482,7 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
         fit = __builtin_amdgcn_ballot_w64(s_ef[lane] != 0) & cand;
     }
     const int mine = ((fit >> lane) & 1ull) ? tg.blocks_per_pair : 0;
-    if (blockIdx.x == 0 && wave == 0 && lane < vol.B) rows_used[lane] = -mine;
+    if (blockIdx.x == 0 && wave == 0 && free_l) rows_used[lane] = -mine;
     if (fit == 0) return;
     int pre = mine;   // inclusive prefix sum over the lanes (pairs)
 #pragma unroll
@@ -2076,7 +2132,7 @@ static size_t tile_rows_per_pair(const trx_volumes &v)
     return n;
 }
 
-// Workspace of the affine entry points: [B][rows][41] partial sums | coordinate tables (callers that pass none) | rows_used[B]
+// Workspace of the affine entry points: [B][rows][41] partial sums | coordinate tables (callers that pass none) | rows_used[B + 3]
 struct AffineWs {
     size_t rows, off_tab, off_rows_used, bytes;
 };
@@ -2091,7 +2147,7 @@ static AffineWs affine_ws(const trx_volumes &v)
     }
     w.off_tab = ((size_t)v.B * w.rows * np_full(3) * sizeof(float) + 255) & ~(size_t)255;
     w.off_rows_used = w.off_tab + (((size_t)(v.W + v.H + v.D) * sizeof(float) + 255) & ~(size_t)255);
-    w.bytes = w.off_rows_used + (((size_t)v.B * sizeof(int) + 255) & ~(size_t)255);
+    w.bytes = w.off_rows_used + (((size_t)(v.B + 3) * sizeof(int) + 255) & ~(size_t)255);   // rows_used[B] | pairs left by the z-streaming kernel | its pair mask (2)
     return w;
 }
 
@@ -2193,15 +2249,23 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             const int eft = (TRX_EFT_BODY && step_kernel && TRX_DEEP_TILE && ru && tef.tiles_per_seg <= 64 && eft_sizes && !(vol->flags & TRX_FLAG_NO_EFT) &&
                              (flat || (vol->flags & TRX_FLAG_EFT))) ? tef.blocks_per_pair : 0;   // = the partial rows per pair of that kernel
             if (eft && tef.blocks_per_pair > gxx) gxx = tef.blocks_per_pair;
+            // flat launches that offer the z-streaming body run it as a kernel of its own, FIRST (affine_zs_step_kernel): it alone evaluates the
+            // test, the kernels behind it skip its pairs and return at once when it has taken them all
+            const bool zs_first = flat && zg.blocks_per_pair > 0 && ru != nullptr && !(vol->flags & TRX_FLAG_ZS_FUSED);
             if constexpr (MODE == 0 || MODE == 4) {
-                if (eft) {   // in front of the step kernel: takes its pairs and marks them rows_used < 0 (none - the usual case next to the identity - costs ~3 us)
-                    const int wd = td.blocks_per_pair > 0, wrd = trd.blocks_per_pair > 0, zp = zg.blocks_per_pair > 0 ? zg.planes_per_seg : 0;
-                    if (flat) hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(slots, 1), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, gxx, wd, wrd, zp);
+                if (zs_first) {
+                    hipLaunchKernelGGL((affine_zs_step_kernel<MODE>), dim3(slots, 1), dim3(ZS64::Threads), 0, s, v, theta, zg, partials, ru, gxx);
+                    TRX_CHECK_LAUNCH();
+                }
+                if (eft) {   // in front of the tile kernel: takes its pairs and marks them rows_used < 0 (none - the usual case next to the identity - costs ~3 us, ~1.5 behind the z-streaming kernel)
+                    const int wd = td.blocks_per_pair > 0, wrd = trd.blocks_per_pair > 0, zp = (zg.blocks_per_pair > 0 && !zs_first) ? zg.planes_per_seg : 0;
+                    if (flat) hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(slots, 1), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, gxx, wd, wrd, zp, zs_first ? 1 : 0);
                     else hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(tef.blocks_per_pair, vol->B), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, -gxx, wd, wrd, zp);
                     TRX_CHECK_LAUNCH();
                 }
             }
-            if (flat) launch_dual<MODE>(dim3(slots, 1), s, v, theta, ta, tr, 1, partials, 1, 0, td, trd, zg, ru, gxx, eft);
+            if (zs_first) hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 4>), dim3(slots, 1), dim3(512), 0, s, v, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gxx, eft);
+            else if (flat) launch_dual<MODE>(dim3(slots, 1), s, v, theta, ta, tr, 1, partials, 1, 0, td, trd, zg, ru, gxx, eft);
             else launch_dual<MODE>(dim3(gxx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd, zg, ru, 0, eft);
             TRX_CHECK_LAUNCH();
             *nblk = gxx;

@@ -18,14 +18,73 @@
 // the pass is bound by its vector instructions at the clock the chip holds under this load.
 
 #ifndef TRX_ZS_DBG
-#define TRX_ZS_DBG 0   // development ablation (tools/zbench.hip): bits: 1 = no ring DMA, 2 = no target loads, 4 = no gather, 8 = no barrier (racy), 16 = no counted wait (racy)
+#define TRX_ZS_DBG 0   // development ablation (tools/zbench.hip): bits: 1 = no ring DMA, 2 = no target loads, 4 = no gather, 8 = no barrier (racy), 16 = no counted wait (racy), 32 = no LDS reads (fake corners), 64 = no accumulation of the pose sums
 #endif
 #ifndef TRX_ZS_MIN_WAVES
 #define TRX_ZS_MIN_WAVES 4
 #endif
+#ifndef TRX_ZS_V2
+#define TRX_ZS_V2 1   // step kernels: row coordinates and yn products on SGPR PAIRS (one packed instruction per two rows / two components), accumulators
+                      // as (x, y) pairs - an instruction with a scalar-register operand costs a SIMD 4.3 cycles where an all-VGPR one costs 2.5
+                      // (profiles/r05a_mfma_coissue_and_op_costs.txt), so the scalar operand should serve two results; 0 = the round-3 form
+#endif
+#ifndef TRX_ZS_PRIO
+#define TRX_ZS_PRIO 2   // Fair sharing of a CU between its two resident blocks.  The SIMD arbiter serves the OLDER wave first: of the two blocks of a
+                        // CU the one dispatched first ran its 128 steps in 172 us, the other one needed 262 us and spent the last 90 us alone on the
+                        // CU at 2 waves per SIMD (profiles/r05a_zstream_block_timeline.txt).  2 = the block of the launch's second half of the grid
+                        // raises its priority in alternate time slices of 2^TRX_ZS_PRIO_BIT shader cycles (s_memtime), the other one in the
+                        // slices between: end skew 112 -> 44 us, launch -1.5 ... -2 %; 1 = by step parity (measured alternative); 0 = off
+#endif
+#ifndef TRX_ZS_PRIO_BIT
+#define TRX_ZS_PRIO_BIT 14
+#endif
+#ifndef TRX_ZS_STAMP
+#define TRX_ZS_STAMP 0   // development (tools/zbench.hip): per-wave s_memtime sums of the four phases of a step -> trx_zs_stamps
+#endif
+#if TRX_ZS_STAMP
+__device__ unsigned long long trx_zs_stamps[512 * 8 * 8];   // [block][wave][wait, barrier, issue, gather, total ticks, steps, realtime start, realtime end]
+#endif
 #ifndef TRX_ZS_LEAD
 #define TRX_ZS_LEAD 1   // steps between the issue of a ring plane and the first step that may touch it (1: one more resident plane, Span = NZ - 1)
 #endif
+
+// Running sums of the z-streaming step body (TRX_ZS_V2): for the weightings q = 1, y, w: Axy = (sum q gx, sum q gy), Bxy = the same times yn,
+// ABz = (sum q gz, sum q gz yn); M01 = (Sy, Sw), M23 = (Syy, Sww), M4 = Syw.
+struct ZAcc {
+    f2 Axy[3], Bxy[3], ABz[3], M01, M23;
+    float M4;
+};
+__device__ __forceinline__ unsigned long long sgpr_pair(float lo, float hi)   // two wave-uniform floats as one 64-bit scalar operand
+{
+    const unsigned l = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(lo)), h = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(hi));
+    return ((unsigned long long)h << 32) | l;
+}
+// Trilinear sample + gradient from the four x-pairs, results where the accumulation wants them: yw = (target value, warped value),
+// gxy = (d/dx, d/dy), gz.  The three x-stage results are written by NON-destructive v_fma_f32 straight into the halves of their pairs (the
+// compiler's v_fmac_f32 accumulates in place and then needs a v_mov per pair).
+__device__ __forceinline__ void zs_lerp_accumulate(f2 r00, f2 r01, f2 r10, f2 r11, float tx, float ty, float tz, float yv, float yn, unsigned long long yn2, ZAcc &a)
+{
+    const f2 dz0 = r10 - r00, dz1 = r11 - r01;
+    const f2 z0 = dz0 * tz + r00, z1 = dz1 * tz + r01;
+    const f2 dy = z1 - z0;
+    const f2 vv = dy * ty + z0;
+    const f2 dzy = (dz1 - dz0) * ty + dz0;
+    f2 yw, gxy, gz2;
+    yw.x = yv;
+    gxy.x = vv.y - vv.x;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(yw.y) : "v"(tx), "v"(gxy.x), "v"(vv.x));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(gxy.y) : "v"(tx), "v"(dy.y - dy.x), "v"(dy.x));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(gz2.x) : "v"(tx), "v"(dzy.y - dzy.x), "v"(dzy.x));
+    gz2.y = yn * gz2.x;
+    f2 ygxy;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(ygxy) : "v"(gxy), "s"(yn2));
+    a.M01 += yw;
+    a.M23 = yw * yw + a.M23;
+    a.M4 = fmaf(yw.x, yw.y, a.M4);
+    a.Axy[0] += gxy; a.Bxy[0] += ygxy; a.ABz[0] += gz2;
+    a.Axy[1] = gxy * yw.x + a.Axy[1]; a.Bxy[1] = ygxy * yw.x + a.Bxy[1]; a.ABz[1] = gz2 * yw.x + a.ABz[1];
+    a.Axy[2] = gxy * yw.y + a.Axy[2]; a.Bxy[2] = ygxy * yw.y + a.Bxy[2]; a.ABz[2] = gz2 * yw.y + a.ABz[2];
+}
 
 template <int TX_, int TY_, int NZ_, int BW_, int BH_>
 struct ZCfg {
@@ -101,7 +160,7 @@ __device__ __forceinline__ int zs_nsub(const float *__restrict__ th, float fD, f
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 template <int MODE, class C>
 __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float *__restrict__ theta, const ZGeom &zg, float *__restrict__ partials,
-                                             float *ring, const int bx, const int by, int rows_per_pair, const int wave_in)
+                                             float *ring, const int bx, const int by, int rows_per_pair, const int wave_in, const int second_slot = 0)
 {
     static_assert(MODE == 0 || MODE == 1 || MODE == 4, "step kernels and the moments pass");
     constexpr int NQ = (MODE == 0) ? 3 : (MODE == 4 ? 1 : 0);
@@ -152,6 +211,18 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
         ey_r[j] = uni(unnorm<3>(yn, fH) + (hH * (t11 - 1.0f)) * yn);
         sz_r[j] = uni((hD * t21) * yn);
     }
+    constexpr bool kV2 = (TRX_ZS_V2 != 0) && MODE == 0 && (R % 2 == 0);
+    unsigned long long sx2[(R + 1) / 2], ey2[(R + 1) / 2], sz2[(R + 1) / 2], yn2[R];   // scalar-register pairs: rows (2k, 2k + 1) of sx / ey / sz, (yn, yn) per row
+    if constexpr (kV2) {
+#pragma unroll
+        for (int k = 0; k < R / 2; k++) {
+            sx2[k] = sgpr_pair(sx_r[2 * k], sx_r[2 * k + 1]);
+            ey2[k] = sgpr_pair(ey_r[2 * k], ey_r[2 * k + 1]);
+            sz2[k] = sgpr_pair(sz_r[2 * k], sz_r[2 * k + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++) yn2[j] = sgpr_pair(yn_r[j], yn_r[j]);
+    }
     auto coord = [&](int xi, int yi, int zi, float &ix, float &iy, float &iz) {
         const float a = xtab[xi], bb = ytab[yi], c = ztab[zi];
         ix = unnorm<3>(a, fW) + hW * fmaf(t00 - 1.0f, a, fmaf(t01, bb, fmaf(t02, c, t03)));
@@ -176,12 +247,26 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
         for (int c = 0; c < 3; c++) acc.AB[q][c] = (f2)(0.f);
     acc.M01 = acc.M23 = (f2)(0.f);
     acc.M4 = 0.f;
+    ZAcc acc2;
+    f2 Uxy[3];
+    float Uz[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        acc2.Axy[q] = acc2.Bxy[q] = acc2.ABz[q] = Uxy[q] = (f2)(0.f);
+        Uz[q] = 0.f;
+    }
+    acc2.M01 = acc2.M23 = (f2)(0.f);
+    acc2.M4 = 0.f;
     float U[3][3];   // sum over planes of the running sum(q grad): the zn column
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
         for (int c = 0; c < 3; c++) U[q][c] = 0.f;
     bool ok = true;
+#if TRX_ZS_STAMP
+    unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     for (int sub = 0; sub < nsub; sub++) {
         const int zb = zb0 + sub * sublen, ze = min(zb + sublen, ze0);
@@ -313,18 +398,39 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
             if (TRX_ZS_DBG & 4) return;
             const float zn = lane_bcast(zn_l, s & 63), zid = lane_bcast(zid_l, s & 63);
             const float bxz = fmaf(kxz, zn, cx), byz = fmaf(kyz, zn, cy), bzz = zid + fmaf(kzz, zn, cz);
+            f2 ixp[(R + 1) / 2], iyp[(R + 1) / 2], izp[(R + 1) / 2];
+            if constexpr (kV2) {
+                const f2 bx2 = {bxz, bxz}, by2 = {byz, byz}, bz2 = {bzz, bzz};
+#pragma unroll
+                for (int k = 0; k < R / 2; k++) {
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(ixp[k]) : "v"(bx2), "s"(sx2[k]));
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(iyp[k]) : "v"(by2), "s"(ey2[k]));
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(izp[k]) : "v"(bz2), "s"(sz2[k]));
+                }
+            }
+            unsigned selv = selc;   // (v2: in a vector register - one move per plane instead of a scalar operand in every voxel's add)
+            if constexpr (kV2) asm("v_mov_b32 %0, %1" : "=v"(selv) : "s"(selc));
             struct Fetch { f2 r00, r01, r10, r11; float fx, fy, fz; };
             auto fetch = [&](int j) -> Fetch {
-                const float ix = bxz + sx_r[j], iy = byz + ey_r[j], iz = bzz + sz_r[j];
-                const unsigned sel = (unsigned)floor_to_int(iz) + selc;
+                float ix, iy, iz;
+                if constexpr (kV2) {
+                    ix = (j & 1) ? ixp[j >> 1].y : ixp[j >> 1].x; iy = (j & 1) ? iyp[j >> 1].y : iyp[j >> 1].x; iz = (j & 1) ? izp[j >> 1].y : izp[j >> 1].x;
+                } else {
+                    ix = bxz + sx_r[j]; iy = byz + ey_r[j]; iz = bzz + sz_r[j];
+                }
+                const unsigned sel = (unsigned)floor_to_int(iz) + selv;
                 int a0, a1, aA, aB;
                 asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a0) : "v"(floor_to_int(ix)), "s"(bpb));
                 asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a1) : "v"(floor_to_int(iy)), "s"(ys_s), "v"(a0));
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aA) : "v"(__builtin_amdgcn_perm((unsigned)(tabA >> 32), (unsigned)tabA, sel)), "s"(ps_s), "v"(a1));
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(aB) : "v"(__builtin_amdgcn_perm((unsigned)(tabB >> 32), (unsigned)tabB, sel)), "s"(ps_s), "v"(a1));
                 Fetch f;
+                if (TRX_ZS_DBG & 32) {
+                    f.r00 = f2{__int_as_float(aA), ix}; f.r01 = f2{iy, __int_as_float(aB)}; f.r10 = f2{iz, ix}; f.r11 = f2{iy, iz};
+                } else {
                 f.r00 = *(lds_f2)(unsigned)aA; f.r01 = *(lds_f2)(unsigned)(aA + C::BW * 4);
                 f.r10 = *(lds_f2)(unsigned)aB; f.r11 = *(lds_f2)(unsigned)(aB + C::BW * 4);
+                }
                 f.fx = __builtin_amdgcn_fractf(ix); f.fy = __builtin_amdgcn_fractf(iy); f.fz = __builtin_amdgcn_fractf(iz);
                 return f;
             };
@@ -333,11 +439,21 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
             for (int j = 0; j < R; j++) {
                 Fetch nxt;
                 if (j + 1 < R) nxt = fetch(j + 1);
-                const Samp3 sm = lerp3_pairs<kGrad>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
-                f1_accumulate_pk<MODE>(sm, tv[j], yn_r[j], acc);
+                if (TRX_ZS_DBG & 64) {
+                    const Samp3 sm = lerp3_pairs<kGrad>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
+                    acc2.M4 += sm.v + sm.dx + sm.dy + sm.dz + tv[j];
+                } else if constexpr (kV2) {
+                    zs_lerp_accumulate(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz, tv[j], yn_r[j], yn2[j], acc2);
+                } else {
+                    const Samp3 sm = lerp3_pairs<kGrad>(cur.r00, cur.r01, cur.r10, cur.r11, cur.fx, cur.fy, cur.fz);
+                    f1_accumulate_pk<MODE>(sm, tv[j], yn_r[j], acc);
+                }
                 if (j + 1 < R) cur = nxt;
             }
-            if constexpr (kGrad) {
+            if constexpr (kV2) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) { Uxy[q] += acc2.Axy[q]; Uz[q] += acc2.ABz[q].x; }
+            } else if constexpr (kGrad) {
 #pragma unroll
                 for (int q = 0; q < (NQ > 0 ? NQ : 1); q++)
 #pragma unroll
@@ -352,6 +468,15 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
         const char *dnext = plane_ptr(pbase + TRX_ZS_LEAD);     // ring plane TRX_ZS_LEAD steps ahead ...
         int dslot = pmod(pbase + TRX_ZS_LEAD);                  // ... and its slot
         auto step = [&](int s, float (&use)[R], float (&load)[R]) {
+#if TRX_ZS_STAMP
+            const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+            unsigned long long st1 = st0, st2 = st0;
+#endif
+#if TRX_ZS_PRIO == 1
+            if ((s + second_slot) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#elif TRX_ZS_PRIO == 2
+            if (((__builtin_amdgcn_s_memtime() >> TRX_ZS_PRIO_BIT) + second_slot) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
             if (s > 0) {
                 if ((s & 63) == 0) {   // next chunk of the z tables (compiler-counted loads: the pipeline drains here, once per 64 steps)
                     load_ztab(s);
@@ -359,7 +484,13 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
                 } else if (TRX_ZS_DBG & 16) {
                 } else if (TRX_ZS_LEAD == 2 && s + 1 <= last) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if TRX_ZS_STAMP
+                st1 = __builtin_amdgcn_s_memtime();
+#endif
                 if (!(TRX_ZS_DBG & 8)) __syncthreads();
+#if TRX_ZS_STAMP
+                st2 = __builtin_amdgcn_s_memtime();
+#endif
                 advance_tables();
             }
 #pragma unroll
@@ -370,7 +501,14 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
                 dnext += plane_bytes;
                 dslot = (dslot + 1 == C::NZ) ? 0 : dslot + 1;
             }
+#if TRX_ZS_STAMP
+            const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+#endif
             gather_plane(s, use);
+#if TRX_ZS_STAMP
+            const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+            stamp_sum[0] += st1 - st0; stamp_sum[1] += st2 - st1; stamp_sum[2] += st3 - st2; stamp_sum[3] += st4 - st3; stamp_sum[5] += 1;
+#endif
         };
 
         float tvA[R], tvB[R];
@@ -395,13 +533,19 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
         __syncthreads();   // every wave is done with the ring (it is re-zeroed by the next anchor / becomes the reduction scratch)
     }
 
+#if TRX_ZS_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (!ok) {
         if (tid < NP) partials[((size_t)by * rows_per_pair + bx) * NP + tid] = __builtin_nanf("");
         return;
     }
     float vals[NP];
     int o = 0;
-    if constexpr (MODE == 4) {
+    if constexpr (kV2) {
+        vals[0] = acc2.M01.x; vals[1] = acc2.M01.y; vals[2] = acc2.M23.x; vals[3] = acc2.M23.y; vals[4] = acc2.M4;
+        o = 5;
+    } else if constexpr (MODE == 4) {
         vals[0] = acc.M4;
         o = 1;
     } else {
@@ -418,11 +562,30 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
         for (int q = 0; q < NQ; q++)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float a = acc.AB[q][c].x;
-                vals[o++] = xn * a; vals[o++] = acc.AB[q][c].y; vals[o++] = fmaf(dzn, fmaf(fn, a, -U[q][c]), zn0 * a); vals[o++] = a;
+                float a, bsum, u;
+                if constexpr (kV2) {
+                    a = c == 0 ? acc2.Axy[q].x : (c == 1 ? acc2.Axy[q].y : acc2.ABz[q].x);
+                    bsum = c == 0 ? acc2.Bxy[q].x : (c == 1 ? acc2.Bxy[q].y : acc2.ABz[q].y);
+                    u = c == 0 ? Uxy[q].x : (c == 1 ? Uxy[q].y : Uz[q]);
+                } else {
+                    a = acc.AB[q][c].x; bsum = acc.AB[q][c].y; u = U[q][c];
+                }
+                vals[o++] = xn * a; vals[o++] = bsum; vals[o++] = fmaf(dzn, fmaf(fn, a, -u), zn0 * a); vals[o++] = a;
             }
     }
     block_reduce_store_nw<NP, C::Waves>(vals, partials + ((size_t)by * rows_per_pair + bx) * NP, ring, wave);
+#if TRX_ZS_STAMP
+    if (lane == 0) {
+        unsigned long long *o = trx_zs_stamps + ((size_t)((by * rows_per_pair + bx) & 511) * 8 + wave) * 8;
+        stamp_sum[4] = __builtin_amdgcn_s_memtime() - stamp_t0;
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        for (int k = 0; k < 5; k++) o[k] = stamp_sum[k];
+        o[5] = stamp_sum[5] | ((unsigned long long)(hwid & 0xffff) << 16) | ((unsigned long long)(xcc & 0xf) << 32);
+        o[6] = stamp_r0; o[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 template <int MODE, class C>
@@ -435,6 +598,7 @@ __global__ __launch_bounds__(C::Threads, TRX_ZS_MIN_WAVES) void affine_zstream_k
         if (threadIdx.x < 41) partials[((size_t)blockIdx.y * rows_per_pair + blockIdx.x) * 41 + threadIdx.x] = __builtin_nanf("");
         return;
     }
-    zstream_body<MODE, C>(vol, theta, zg, partials, ring, blockIdx.x, blockIdx.y, rows_per_pair, trx_wave_index());
+    zstream_body<MODE, C>(vol, theta, zg, partials, ring, blockIdx.x, blockIdx.y, rows_per_pair, trx_wave_index(),
+                          (int)((blockIdx.y * gridDim.x + blockIdx.x) * 2 >= gridDim.x * gridDim.y));
 }
 #pragma clang diagnostic pop
