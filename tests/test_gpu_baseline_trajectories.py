@@ -114,7 +114,7 @@ def test_cfg4_share_of_one_gpu_8x256_20_iterations(eng, refs):
     s.run(iters)
     torch.cuda.synchronize()
     rows = s.rows_used().tolist()
-    assert len(set(rows)) == 1 and rows[0] == 64, rows            # the z-streaming body (64 blocks per 256^3 pair) served all eight pairs
+    assert len(set(rows)) == 1 and abs(rows[0]) == 64 and set(s.bodies()) == {"zstream"}, (rows, s.bodies())   # the z-streaming kernel (64 blocks per 256^3 pair) served all eight pairs
     for i in CFG4_PAIRS:   # (round 4: three of the eight pairs instead of one)
         check_affine(s.losses[i].cpu().numpy().astype(np.float64), s.theta[i, :12].cpu().numpy().reshape(3, 4), refs[("cfg4", i, "float32")],
                      refs[("cfg4", i, "float64")], ("pair", i))
@@ -132,7 +132,7 @@ def test_cfg4_rigid_from_the_reference_initial_pose_8x256_20_iterations(eng, ref
     s.run(iters)
     torch.cuda.synchronize()
     rows = s.rows_used().tolist()
-    assert all(r < 0 for r in rows), rows            # every pair of the last step ran the exact-footprint kernel
+    assert all(r < 0 for r in rows) and set(s.bodies()) == {"eft"}, (rows, s.bodies())            # every pair of the last step ran the exact-footprint kernel
     i = CFG4R_PAIR
     check_affine(s.losses[i].cpu().numpy().astype(np.float64), s.theta[i, :12].cpu().numpy().reshape(3, 4), refs[("cfg4r", "adam", "float32")],
                  refs[("cfg4r", "adam", "float64")], ("rigid pair", i))

@@ -197,9 +197,23 @@ def test_flat_grid_mixed_batch_against_oracle(eng):
     s.run(1)
     torch.cuda.synchronize()
     rows = s.rows_used().tolist()
-    assert [r < 0 for r in rows] == [False, True, False, True, False, True, False, True], rows
+    # round 5: the z-streaming kernel runs FIRST and marks its pairs (0 and 2, next to the identity) negative like the exact-footprint kernel marks
+    # the rotated ones; the tile kernel behind both keeps pairs 4 (R_z(0.5): GeomRD) and 6 (zoom 1.6: GeomR) and leaves their counts positive
+    assert [r < 0 for r in rows] == [True, True, True, True, False, True, False, True], rows
+    assert s.bodies() == ["zstream", "eft", "zstream", "eft", "tile-RD", "eft", "tile-R", "eft"], s.bodies()
+    # the same launch with the z-streaming body kept inside the tile kernel (the round 3-4 form, TRX_FLAG_ZS_FUSED): same bodies, same rows
+    import torchregister_amd._lib as lib
+    sf = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=lib.FLAG_ZS_FUSED)
+    sf.run(1)
+    torch.cuda.synchronize()
+    rf = sf.rows_used().tolist()
+    assert [r < 0 for r in rf] == [False, True, False, True, False, True, False, True] and [abs(r) for r in rf] == [abs(r) for r in rows], (rf, rows)
+    assert sf.bodies() == ["zstream-fused", "eft", "zstream-fused", "eft", "tile-RD", "eft", "tile-R", "eft"], sf.bodies()
+    for b in range(B):
+        assert abs(sf.losses[b, 0].item() - s.losses[b, 0].item()) <= 1e-6 * max(1.0, abs(s.losses[b, 0].item())), b
+        assert torch.max(torch.abs(sf.grad[b, :12] - s.grad[b, :12])).item() <= 1e-5 * s.grad[b, :12].abs().max().item(), b
     t64, t32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)
-    for b in (1, 2, 5):
+    for b in (0, 1, 2, 5):
         m, t = mov[b, 0].cpu().numpy(), tgt[b, 0].cpu().numpy()
         total, _, dth, _ = oracle.c_affine_loss_grad(m.astype(np.float64), t.astype(np.float64), th[b].double().numpy(), oracle.wts(**kw), t64)
         _, _, dth32, _ = oracle.c_affine_loss_grad(m, t, th[b].numpy(), oracle.wts(**kw), t32)

@@ -118,6 +118,7 @@ def test_zstream_default_choice_at_headline_share(eng):
         assert abs(s.losses[i, 0].item() - total) <= 2e-5 * max(1.0, abs(total))
         assert np.max(np.abs(s.grad[i, :12].cpu().numpy().reshape(3, 4) - dth)) <= 2e-4 * np.max(np.abs(dth))
     assert torch.equal(s.losses[0], s.losses[2]) and torch.equal(s.grad[1], s.grad[3])   # slot independence, bit for bit
+    assert set(s.bodies()) == {"zstream"}, s.bodies()   # (round 5: the z-streaming kernel, in front of the tile kernel, took every pair)
 
 
 @pytest.mark.parametrize("B", [64, 65])

@@ -196,11 +196,22 @@ class AffineSolver:
                                          _lib.current_stream(self.batch.device))
         _lib.check(rc, "trx_affine_run")
 
-    def rows_used(self):
-        """Partial rows the last 3-D step's streaming launch wrote per pair ([B] int32): identifies the kernel body each pair ran
-        (diagnostics / tests; host sync)."""
+    BODIES = {0: "none", 1: "tile-D", 2: "tile-A", 3: "tile-R", 4: "tile-RD", 5: "zstream-fused", 6: "zstream", 7: "eft"}
+
+    def _rows_notes(self):
         off = int(self.lib.trx_affine_workspace_rows_offset(ctypes.byref(self.vol)))
         return self.workspace[off:off + 4 * self.batch.B].view(torch.int32).cpu()
+
+    def rows_used(self):
+        """Partial rows the last 3-D step's streaming launches wrote per pair ([B] int32; negative: the pair was taken by a kernel launched in
+        front of the tile kernel - the z-streaming or the exact-footprint kernel).  Diagnostics / tests; host sync."""
+        v = self._rows_notes()
+        return torch.sign(v) * (v.abs() & 0xFFFFFF)
+
+    def bodies(self):
+        """Which kernel body ran each pair of the last 3-D step (include/trx.h: the note in bits 24-27 of rows_used): list of names."""
+        v = self._rows_notes()
+        return [self.BODIES.get(int(x), "?") for x in ((v.abs() >> 24) & 15).tolist()]
 
     def accumulate_only(self):
         """Launch only the streaming F1 kernel (partials into the workspace); used for kernel timing."""

@@ -44,6 +44,11 @@ static AffineGeom affine_geom(const trx_volumes &v, int target_blocks_total)
 }
 
 constexpr int np_full(int nd) { return 5 + 3 * nd * (nd + 1); }
+// rows_used[b] (the step kernels' note to the finalise kernel): low 24 bits = partial rows the pair's kernel wrote, bits 24-27 = which body
+// (1 + dual_choice for the tile kernel: 1 GeomD, 2 GeomA, 3 GeomR, 4 GeomRD, 5 z-streaming inside it; 6 = the z-streaming kernel, 7 = the
+// exact-footprint kernel), NEGATIVE when a kernel in front of the tile kernel took the pair.  Read back by AffineSolver.bodies().
+constexpr int kRowsMask = 0xFFFFFF;
+__host__ __device__ constexpr int rows_note(int rows, int body) { return rows > 0 ? (rows | (body << 24)) : 0; }
 constexpr int kNpMse = 13;   // partial-row layout of the MSE / SSD-only step kernel (3-D): sum d^2, then 12 x sum(d J)
 
 // MODE 0: moments + sum(qJ), q in {1,y,w}   (the optimiser step)
@@ -1253,7 +1258,7 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         if (with_ef && lane < B && rows_used[lane] < 0) ch = 6;   // taken by the exact-footprint kernel, which ran in front of this one
         if (lane < B) {
             cnt = blocks_of(ch);
-            if (rows_used && blockIdx.x == 0 && wave_idx == 0 && ch != 6) rows_used[lane] = cnt;   // for the step's finalise kernel
+            if (rows_used && blockIdx.x == 0 && wave_idx == 0 && ch != 6) rows_used[lane] = rows_note(cnt, 1 + ch);   // for the step's finalise kernel
         }
         int pre = cnt;   // inclusive prefix sum over the lanes (pairs)
 #pragma unroll
@@ -1277,7 +1282,7 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         // rows_used[], written here by the pair's first block - it does not repeat the choice (two inlined copies of a float test could
         // disagree by an ulp)
         int *rows_used = a->rows_used;
-        if (rows_used && blockIdx.x == 0 && tid_ == 0 && my_choice != 6) rows_used[blockIdx.y] = mine;
+        if (rows_used && blockIdx.x == 0 && tid_ == 0 && my_choice != 6) rows_used[blockIdx.y] = rows_note(mine, 1 + my_choice);
         if ((int)blockIdx.x >= mine) {
             if (MODE != 3 && a->zero_surplus && tid_ < NP) a->partials[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * NP + tid_] = 0.f;
             return;
@@ -1369,7 +1374,7 @@ __global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_ste
     const unsigned long long take = __builtin_amdgcn_ballot_w64(take_l);
     const int mine = take_l ? zg.blocks_per_pair : 0;
     if (blockIdx.x == 0 && wave == 0) {
-        if (lane < vol.B) rows_used[lane] = -mine;
+        if (lane < vol.B) rows_used[lane] = -rows_note(mine, 6);
         if (lane == 0) {
             rows_used[vol.B] = vol.B - __builtin_popcountll(take);
             rows_used[vol.B + 1] = (int)(unsigned)take; rows_used[vol.B + 2] = (int)(unsigned)(take >> 32);   // which pairs: nobody rewrites this
@@ -1416,13 +1421,13 @@ __device__ __forceinline__ bool eft_wants(int choice, const float *__restrict__ 
 
 template <int MODE>
 __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_volumes vol, const float *__restrict__ theta, TileGeom tg, float *__restrict__ partials,
-                                                                           int *__restrict__ rows_used, int stride, int with_d, int with_rd, int zs_planes, int zs_first = 0)
+                                                                           int *__restrict__ rows_used, int stride, int with_d, int with_rd, int zs_planes_)
 {
+    const bool zs_first = zs_planes_ < 0;   // (flat launches behind affine_zs_step_kernel: the z-streaming test is not repeated here)
+    const int zs_planes = zs_first ? 0 : zs_planes_;
     __shared__ __attribute__((aligned(16))) float lds[ECfg::Alloc];
     __shared__ int s_ef[64];
     const int wave = trx_wave_index(), lane = trx_lane_id();
-    // zs_first (flat launches): affine_zs_step_kernel ran in front - no pair left (rows_used[B] = 0): done; else its pairs are marked rows_used < 0
-    if (zs_first && __builtin_amdgcn_readfirstlane(rows_used[vol.B]) == 0) return;
     const float fD = (float)vol.D, fH = (float)vol.H, fW = (float)vol.W;
     if (stride < 0) {   // (small launches: the body is offered by TRX_FLAG_EFT only)
         if ((int)blockIdx.x >= tg.blocks_per_pair) return;
@@ -1451,12 +1456,17 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
             take = d.ok && g > 0 && g <= ECfg::GCap;
             __syncthreads();   // s_ef is not touched again, but the body's prologue reuses LDS right away: keep the phases apart
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) rows_used[b] = take ? -tg.blocks_per_pair : 0;
+        if (blockIdx.x == 0 && wave == 0 && lane == 0) rows_used[b] = take ? -rows_note(tg.blocks_per_pair, 7) : 0;
         if (!take) return;
-        eft_body<MODE>(vol, theta, tg, partials, lds, blockIdx.x, b, -stride, wave);
-        return;
     }
+    // ONE call site of the body for both grids (as in affine_tile_dual_kernel): with a second inlined copy behind the classic grid's branch the
+    // compiler produced a kernel whose classic-grid launches faulted as soon as round 5 touched the flat branch (tools/repro_eft2.py)
+    const bool flat = stride >= 0;
+    int pre = 0, total = 1;
+    if (flat) {
     // flat: per pair (lane) the decision, one candidate pair per wave and round
+    // zs_first: affine_zs_step_kernel ran in front - no pair left (rows_used[B] = 0): done; else its pairs are those of the mask in rows_used[B + 1, B + 2]
+    if (zs_first && __builtin_amdgcn_readfirstlane(rows_used[vol.B]) == 0) return;
     unsigned long long zs_mask = 0;   // pairs of the kernel in front (its mask is not rewritten by anybody: block 0 of THIS kernel rewrites rows_used[b] of the free pairs)
     if (zs_first) zs_mask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(rows_used[vol.B + 1]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(rows_used[vol.B + 2]) << 32);
     const bool free_l = lane < vol.B && !((zs_mask >> lane) & 1ull);
@@ -1482,25 +1492,32 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
         fit = __builtin_amdgcn_ballot_w64(s_ef[lane] != 0) & cand;
     }
     const int mine = ((fit >> lane) & 1ull) ? tg.blocks_per_pair : 0;
-    if (blockIdx.x == 0 && wave == 0 && free_l) rows_used[lane] = -mine;
+    if (blockIdx.x == 0 && wave == 0 && free_l) rows_used[lane] = -rows_note(mine, 7);
     if (fit == 0) return;
-    int pre = mine;   // inclusive prefix sum over the lanes (pairs)
+    pre = mine;   // inclusive prefix sum over the lanes (pairs)
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int t = __shfl_up(pre, d, 64);
         if (lane >= d) pre += t;
     }
-    const int total = __builtin_amdgcn_readlane(pre, 63);
+    total = __builtin_amdgcn_readlane(pre, 63);
+    }
+    total = __builtin_amdgcn_readfirstlane(total);
+    const int rows_stride = __builtin_amdgcn_readfirstlane(flat ? stride : -stride);
     // A block's items (pair-major index blockIdx + k gridDim) would be the SAME column in pair after pair - and columns differ widely in
     // cost (those that leave the source volume early are cheap): the column index is rotated per pair (by a multiple of 8: blocks b, b + 8,
     // ... still share an XCD's L2 with the neighbouring columns), which evens the blocks' loads without any shared counter.
-    for (int item = blockIdx.x; item < total; item += gridDim.x) {
-        const int pair = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= item)));
-        const int off = pair > 0 ? __builtin_amdgcn_readlane(pre, pair - 1) : 0;
-        int v = item - off + 104 * pair;
-        v = __builtin_amdgcn_readfirstlane(v % tg.blocks_per_pair);
-        if (item != (int)blockIdx.x) __syncthreads();   // the previous item's reduction scratch aliases the buffers
-        eft_body<MODE>(vol, theta, tg, partials, lds, v, pair, stride, wave);
+    const int it0 = flat ? (int)blockIdx.x : 0, it_step = flat ? (int)gridDim.x : 1;
+    for (int item = __builtin_amdgcn_readfirstlane(it0); item < total; item += it_step) {
+        int v = blockIdx.x, pair = blockIdx.y;   // classic grid: the one item of this block
+        if (flat) {
+            pair = __builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= item));
+            const int off = pair > 0 ? __builtin_amdgcn_readlane(pre, pair - 1) : 0;
+            v = (item - off + 104 * pair) % tg.blocks_per_pair;
+        }
+        v = __builtin_amdgcn_readfirstlane(v); pair = __builtin_amdgcn_readfirstlane(pair);
+        if (item != it0) __syncthreads();   // the previous item's reduction scratch aliases the buffers
+        eft_body<MODE>(vol, theta, tg, partials, lds, v, pair, rows_stride, wave);
     }
 }
 
@@ -1691,7 +1708,7 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
         // rows the F1 pass wrote for this pair: the dual kernel lays a pair's rows out with stride nblk and fills the first
         // blocks_per_pair of the geometry it chose for the pair - it left that count in rows_used[b]
         int rows = nblk;
-        if (rows_used) rows = min(abs(rows_used[b]), nblk);   // (negative: the pair was left to the exact-footprint kernel, which wrote |rows_used| rows)
+        if (rows_used) rows = min(abs(rows_used[b]) & kRowsMask, nblk);   // (negative: the pair was left to the exact-footprint kernel, which wrote |rows_used| rows)
         if (ND == 3 && mse_rows) reduce_partials<kNpMse>(partials + (size_t)b * nblk * kNpMse, rows, S);   // rows of the MSE / SSD-only step kernel
         else reduce_partials<NP>(partials + (size_t)b * nblk * NP, rows, S);
     }
@@ -2258,8 +2275,8 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
                     TRX_CHECK_LAUNCH();
                 }
                 if (eft) {   // in front of the tile kernel: takes its pairs and marks them rows_used < 0 (none - the usual case next to the identity - costs ~3 us, ~1.5 behind the z-streaming kernel)
-                    const int wd = td.blocks_per_pair > 0, wrd = trd.blocks_per_pair > 0, zp = (zg.blocks_per_pair > 0 && !zs_first) ? zg.planes_per_seg : 0;
-                    if (flat) hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(slots, 1), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, gxx, wd, wrd, zp, zs_first ? 1 : 0);
+                    const int wd = td.blocks_per_pair > 0, wrd = trd.blocks_per_pair > 0, zp = zs_first ? -1 : (zg.blocks_per_pair > 0 ? zg.planes_per_seg : 0);   // (-1: the z-streaming kernel ran in front)
+                    if (flat) hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(slots, 1), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, gxx, wd, wrd, zp);
                     else hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(tef.blocks_per_pair, vol->B), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, -gxx, wd, wrd, zp);
                     TRX_CHECK_LAUNCH();
                 }
