@@ -28,8 +28,14 @@
 extern "C" {
 #endif
 
-#define TRX_VERSION 230 /* 0.2.3 (the reference package version whose API the host layer mirrors).  Since 200: TRX_FLAG_SAVE_LAST (slab updates store
-                           * flow_last only on request), TRX_FLAG_EFT / TRX_FLAG_NO_EFT, trx_flow_lncc_run, trx_peer_*, sticky peer time-outs */
+/* ABI history (trx_version() returns TRX_VERSION; the first two digits follow the reference package version whose API the host layer mirrors):
+ *   200  round 2: flags in trx_volumes (no environment variables), trx_nmi_from_pdfs, trx_theta_chain, the flow loop's device-side early stop
+ *   220  round 3: TRX_FLAG_ZSTREAM / NO_ZSTREAM, TRX_FLAG_NEAREST, trx_flow_lncc_run, trx_peer_* (first form)
+ *   230  round 4: TRX_FLAG_SAVE_LAST (slab updates store flow_last only on request), TRX_FLAG_EFT / TRX_FLAG_NO_EFT, trx_peer_alloc / export /
+ *        import on raw HIP IPC handles, sticky peer time-outs
+ *   231  round 5: trx_affine_workspace_bytes grows by three ints (the z-streaming kernel's note to the kernels behind it), the rows_used array the
+ *        step kernels leave in the workspace carries the kernel body in bits 24-27, TRX_FLAG_ZS_FUSED.  No entry point changed its signature. */
+#define TRX_VERSION 231
 #define TRX_PSTRIDE 12  /* floats per pair in theta / param / adam / best_theta arrays */
 
 typedef enum {

@@ -102,7 +102,15 @@ struct ZCfg {
 };
 // 64 x 32 voxels per plane, ring of 7 planes of 72 x 40 floats = 80.6 KB: two blocks per CU.  The ring size is not a power of two: the
 // slot of a source plane comes from an 8-entry byte table (v_perm_b32), at the instruction count of a mask.
+#ifndef TRX_ZS_GEOM
+#define TRX_ZS_GEOM 0   // 1: ring of 6 planes of 80 x 42 floats - the same 80.6 KB with 9.7 / 5.4 instead of 1.7 / 3.4 voxels of slack in x / y, one plane less in z:
+                        // measured alternative (profiles/r05a_zs_window_variants.txt: R_z(0.1) joins the window, the identity loses 4 %, a converging run 12 %)
+#endif
+#if TRX_ZS_GEOM == 1
+using ZS64 = ZCfg<64, 32, 6, 80, 42>;
+#else
 using ZS64 = ZCfg<64, 32, 7, 72, 40>;
+#endif
 
 struct ZGeom {
     int ntx, nty, nzseg, planes_per_seg, blocks_per_pair;
