@@ -59,7 +59,11 @@ typedef enum {
                                       callers set it on the LAST iteration of a run - the iteration that meets stop_crit stores it by itself */
 #define TRX_FLAG_NEAREST 128u        /* trx_flow_warp: nearest-neighbour sampling (SpatialTransformer(mode='nearest'), ref:utils.py:339-365) instead of bi/trilinear */
 #define TRX_FLAG_NO_ZSTREAM 32u     /* affine steps: never use the z-streaming body (pairs next to the identity run GeomD / GeomA like the others) */
-#define TRX_FLAG_ZSTREAM 64u        /* affine steps: offer the z-streaming body whatever the batch size (by default only to launches that fill the chip) */
+#define TRX_FLAG_ZSTREAM 64u        /* affine steps: offer the z-streaming body whatever the batch size (by default only to launches that fill the chip).
+                                     * The body re-checks its window per block from the block's own corners and would publish NaN rows for a pair whose
+                                     * pre-image left it; the offer rule (theta and sizes only) is that test's worst case with 0.3 voxels to spare, and
+                                     * tests/test_gpu_zstream.py::test_zstream_offer_boundary_never_trips bisects to the rule's edge in 60 directions of
+                                     * theta space on three shapes without reaching it: a NaN loss from this path would be a bug, not an input property */
 #define TRX_FLAG_NO_EFT 512u        /* affine steps: never use the exact-footprint body (rotated pairs run GeomR as before) */
 #define TRX_FLAG_EFT 1024u          /* affine steps: offer the exact-footprint body whatever the batch size (by default only to launches that fill the chip) */
 #define TRX_FLAG_ZS_FUSED 2048u      /* affine steps on launches that fill the chip: keep the z-streaming body inside the tile kernel (the round 3-4 form) instead of

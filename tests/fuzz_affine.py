@@ -55,7 +55,7 @@ def kink_variants(theta):
 
 def run(n, seed, grad_bar=2e-4, verbose=True, only=None):
     rng = np.random.default_rng(seed)
-    worst = {"loss": 0.0, "grad": 0.0, "warp": 0.0}
+    worst = {"loss": 0.0, "grad": 0.0, "warp": 0.0, "widest_bar": 0.0}
     fails = kinks = 0
     for it in range(n):
         big = rng.random() < 0.3
@@ -130,6 +130,7 @@ def run(n, seed, grad_bar=2e-4, verbose=True, only=None):
             el = max(el, elr)
             worst["loss"] = max(worst["loss"], el); worst["warp"] = max(worst["warp"], ew / bw)
             worst["grad"] = max(worst["grad"], eg, eb, er)
+            worst["widest_bar"] = max(worst["widest_bar"], gbar, mbar, pbar)
             bad = el > 2e-5 or eg > grad_bar or eb > grad_bar or er > grad_bar or ew > bw or not np.isfinite(loss)
             if bad:
                 fails += 1
@@ -141,7 +142,7 @@ def run(n, seed, grad_bar=2e-4, verbose=True, only=None):
                     print(" pose", pu.tolist(), "\n gpu pose grad", sr.grad[b, :6].cpu().numpy(), "\n oracle", dp, "\n oracle fp32", dp32)
                 if verbose: print(f"FAIL case {it} pair {b}: shape {shape} B {B} kind {kind} kw {kw} loss err {el:.2e} grad err {eg:.2e} bwd err {eb:.2e} rigid err {er:.2e} warp err/bar {ew / bw:.2f}\n theta {tu.tolist()}")
     if verbose:
-        print(f"{n} cases, {fails} failures ({kinks} gradient bars widened: a sample within fp32 rounding of an integer coordinate, see kink_variants); worst loss rel {worst['loss']:.2e} (bar 2e-5), grad rel-to-max {worst['grad']:.2e} (bar {grad_bar:.0e}), warp err/bar {worst['warp']:.2f}")
+        print(f"{n} cases, {fails} failures ({kinks} gradient bars widened: a sample within fp32 rounding of an integer coordinate, see kink_variants); worst loss rel {worst['loss']:.2e} (bar 2e-5), grad rel-to-max {worst['grad']:.2e} (bar {grad_bar:.0e}), warp err/bar {worst['warp']:.2f}; widest gradient bar used {worst['widest_bar']:.2e} of the gradient's maximum")
     return fails, worst
 
 

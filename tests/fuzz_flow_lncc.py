@@ -20,10 +20,12 @@ def smooth_nd(shape, f):
     return (torch.sin(f * ax[0])[:, None] + torch.cos(1.3 * f * ax[1] + 0.5)[None, :]).float().view(1, 1, *shape)
 
 
-def run(n, seed, verbose=True):
+def run(n, seed, verbose=True, only=None, details=None):
+    """only: evaluate just that case of the sweep (the random stream is still drawn for the cases before it); details: a list that receives one
+    dict per evaluated case (errors, the fp32-vs-fp64 gap of the torch specification, the bars used)."""
     rng = np.random.default_rng(seed)
     fails = 0
-    worst = {"flow_loss": 0.0, "flow_grad": 0.0, "lncc_loss": 0.0, "lncc_grad": 0.0}
+    worst = {"flow_loss": 0.0, "flow_grad": 0.0, "lncc_loss": 0.0, "lncc_grad": 0.0, "widest_flow_bar": 0.0, "widest_lncc_bar": 0.0}
     for it in range(n):
         nd = 3 if rng.random() < 0.7 else 2
         shape = tuple(int(v) for v in rng.integers(3, 40 if nd == 3 else 90, nd))
@@ -33,6 +35,10 @@ def run(n, seed, verbose=True):
         flow = torch.tensor(amp * rng.standard_normal((1, nd) + shape), dtype=torch.float32)
         flow = flow + 0.37          # keep samples off exact voxel positions
         kw = dict(w_ncc=float(rng.uniform(0, 1)), w_mse=float(rng.uniform(0, 1)))
+        win = int(rng.choice([3, 5, 7, 9]))
+        B = int(rng.integers(1, 3))
+        if only is not None and it != only:
+            continue
         terms, dfl = eng.flow_loss_grad(mov.cuda(), tgt.cuda(), flow.cuda(), eng.LossSpec(**kw))
         args = lambda dt: (mov[0, 0].numpy().astype(dt), tgt[0, 0].numpy().astype(dt), flow[0].numpy().astype(dt), oracle.wts(**kw))
         t64, _, d64, _ = oracle.c_flow_loss_grad(*args(np.float64))
@@ -44,8 +50,6 @@ def run(n, seed, verbose=True):
         worst["flow_loss"] = max(worst["flow_loss"], el); worst["flow_grad"] = max(worst["flow_grad"], eg / gbar)
         bad = el > 2e-5 or eg > gbar
         # local NCC on (target, warped)
-        win = int(rng.choice([3, 5, 7, 9]))
-        B = int(rng.integers(1, 3))
         y = torch.cat([tgt] * B); w = torch.cat([mov + 0.01 * b for b in range(B)])
         loss, grad = eng.local_ncc_loss_grad(y.cuda(), w.cuda(), win, 1.7)
         w64 = w.double().requires_grad_()
@@ -63,16 +67,20 @@ def run(n, seed, verbose=True):
         #  case 231 reached 2.1 x torch's fp32 error)
         glbar = max(2e-4, 2.5 * (g32.double() - g64).abs().max().item() / gm)
         worst["lncc_loss"] = max(worst["lncc_loss"], ell / lbar); worst["lncc_grad"] = max(worst["lncc_grad"], egl / glbar)
+        worst["widest_flow_bar"] = max(worst["widest_flow_bar"], gbar); worst["widest_lncc_bar"] = max(worst["widest_lncc_bar"], glbar)
+        if details is not None:
+            details.append(dict(case=it, shape=shape, win=win, B=B, lncc_grad_err=egl, lncc_grad_fp32_gap=(g32.double() - g64).abs().max().item() / gm, lncc_grad_bar=glbar,
+                                lncc_loss_err=ell, lncc_loss_bar=lbar, flow_grad_err=eg, flow_grad_bar=gbar, flow_loss_err=el))
         bad = bad or ell > lbar or egl > glbar
         if bad:
             fails += 1
             if verbose:
                 print(f"FAIL case {it}: shape {shape} amp {amp} kw {kw} win {win} B {B}: flow loss {el:.2e} grad {eg:.2e}/{gbar:.2e}; lncc loss {ell:.2e}/{lbar:.2e} grad {egl:.2e}/{glbar:.2e}")
     if verbose:
-        print(f"{n} cases, {fails} failures; worst (error / bar): {worst}")
+        print(f"{n} cases, {fails} failures; worst (error / bar; widest_*: the largest bar any case was given, relative to the gradient's maximum): {worst}")
     return fails, worst
 
 
 if __name__ == "__main__":
-    f, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    f, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0, only=int(sys.argv[3]) if len(sys.argv) > 3 else None)
     sys.exit(1 if f else 0)

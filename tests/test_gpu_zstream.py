@@ -146,3 +146,51 @@ def test_largest_flat_grid_batch_and_the_first_classic_one(eng, B):
         assert abs(s1.losses[0, 0].item() - s.losses[b, 0].item()) <= 2e-5 * max(1.0, abs(s.losses[b, 0].item())), b
         gb = s.grad[b, :12]
         assert torch.max(torch.abs(s1.grad[0, :12] - gb)).item() <= 2e-4 * gb.abs().max().item(), b
+
+
+def test_zstream_offer_boundary_never_trips(eng):
+    """VERDICT r4 #7 / ADVICE r3: the body's own per-anchor window test (exact, from the block's corners) reports a violation as NaN rows - it
+    "cannot happen while zs_nsub holds" (the offer rule is the per-anchor test's worst case over the alignment of the window origin, with 0.3
+    voxels to spare).  This sweep walks TO the edge of the offer rule: for random directions in theta space (all twelve entries, or only the
+    shears / only the diagonal / only the translations scaled up) it bisects the largest step from the identity that the rule still accepts
+    (AffineSolver.bodies() says which body ran), and checks there - where the window is as full as the rule ever lets it get, for every
+    block of the pair at once - that the body's result is finite and equal to the tile kernels' to the fp32 floor.  60 directions x 3 shapes."""
+    from torchregister_amd import _lib
+    rng = np.random.default_rng(20261003)
+    shapes = [(40, 32, 64), (72, 64, 128), (130, 96, 64)]     # one z segment without / with re-anchoring (>= 64 and >= 128 planes per segment)
+    tripped, edges = 0, []
+    for shape in shapes:
+        tgt = ph.blobs(shape, 77).cuda()
+        mov = (ph.blobs(shape, 78) + 0.1 * ph.vol(shape, 0.013, "sin")).cuda()
+
+        def run(th, flags):
+            s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0, w_mse=0.3), lr=0.0, init=torch.tensor(th, dtype=torch.float32)[None], capacity=1, flags=flags)
+            s.run(1)
+            torch.cuda.synchronize()
+            return s.losses[0, 0].item(), s.grad[0, :12].cpu().numpy(), s.bodies()[0]
+        for k in range(20):
+            d = rng.standard_normal((3, 4))
+            kind = k % 4
+            if kind == 1: d[:, 3] = 0; d[np.arange(3), np.arange(3)] = 0          # shears / rotations only
+            if kind == 2: d = np.diag(rng.standard_normal(3)) @ np.eye(3, 4)     # zooms only
+            if kind == 3: d[:, :3] *= 0.05                                          # mostly translation
+            d /= np.max(np.abs(d))
+            lo, hi = 0.0, 0.5
+            for _ in range(14):
+                mid = 0.5 * (lo + hi)
+                body = run(np.eye(3, 4) + mid * d, _lib.FLAG_ZSTREAM)[2]
+                if body.startswith("zstream"): lo = mid
+                else: hi = mid
+            th = np.eye(3, 4) + lo * d
+            loss, grad, body = run(th, _lib.FLAG_ZSTREAM)
+            assert body.startswith("zstream"), (shape, k, lo)
+            loss_t, grad_t, body_t = run(th, _lib.FLAG_NO_ZSTREAM)
+            assert not body_t.startswith("zstream")
+            if not (np.isfinite(loss) and np.all(np.isfinite(grad))):
+                tripped += 1
+                continue
+            edges.append(lo)
+            assert abs(loss - loss_t) <= 2e-5 * max(1.0, abs(loss_t)), (shape, k, lo, loss, loss_t)
+            assert np.max(np.abs(grad - grad_t)) <= 4e-4 * np.max(np.abs(grad_t)), (shape, k, lo)
+    assert tripped == 0, f"{tripped} poses at the edge of the offer rule tripped the body's own window test"
+    assert min(edges) > 1e-3 and np.median(edges) < 0.2, (min(edges), np.median(edges), max(edges))   # the bisection found the rule's edge (directions that are mostly translation have none: the window follows)

@@ -1530,7 +1530,8 @@ static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const fl
     if (how == 1) {
         // WHICH = 3: the two-body (GeomA / GeomR) instance for launches that offer nothing else - the five-body kernel's entry costs 2-3 us
         // more (its arguments are fetched in front of the body that needs them), which is what a step of a small volume takes in all
-        if (td.blocks_per_pair == 0 && trd.blocks_per_pair == 0 && zg.blocks_per_pair == 0 && rows_stride == 0)
+        // (and no exact-footprint kernel in front: the two-body instance does not read its marks and would run its pairs a second time - ADVICE r4)
+        if (td.blocks_per_pair == 0 && trd.blocks_per_pair == 0 && zg.blocks_per_pair == 0 && rows_stride == 0 && eft == 0)
             hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 3>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride);
         else
             hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride, eft);
@@ -2235,9 +2236,10 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
                 // big batches as before; smaller ones where the deep tiling still fills every block slot with blocks of at least four tiles
                 // (1 or 2 pairs of 256^3: -3 %; never where it would leave slots empty - 2 x 128^3 measured +29 % with it)
                 const long blocks_d = (long)cand.blocks_per_pair * vol->B;
-                const long rem_d = blocks_d % 512;      // a last round that is less than ~60 % full costs more than the deeper tile saves (6 x 256^3: +6 %)
-                const bool small_ok = TRX_DEEP_SMALL && blocks_d >= 512 && cand.tiles_per_seg >= 4 && (rem_d == 0 || rem_d >= 320);
-                if (TRX_DEEP_TILE && (blocks_d >= 1024 || small_ok || (vol->flags & TRX_FLAG_DEEP_TILE))) td = cand;
+                const long slots_d = persistent_blocks();   // block slots of these 512-thread kernels (MI355X: 512) - the same number the flat grid and the z-streaming / exact-footprint rules use
+                const long rem_d = blocks_d % slots_d;  // a last round that is less than ~60 % full costs more than the deeper tile saves (6 x 256^3: +6 %)
+                const bool small_ok = TRX_DEEP_SMALL && blocks_d >= slots_d && cand.tiles_per_seg >= 4 && (rem_d == 0 || rem_d >= slots_d * 5 / 8);
+                if (TRX_DEEP_TILE && (blocks_d >= 2 * slots_d || small_ok || (vol->flags & TRX_FLAG_DEEP_TILE))) td = cand;
             }
             // GeomRD (GeomR's box under a 16 x 16 x 16 tile) joins under the same condition: rotations whose pre-image still fits that box
             TileGeom trd = TileGeom{};
@@ -2245,7 +2247,7 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
                 const TileGeom cand = tile_geom<GeomRD>(*vol);
                 // tiny volumes (<= 64^3: at most 64 of these tiles) stay with GeomR's smaller tiles: measured +5 ... +14 % otherwise; and a launch
                 // of fewer than 1024 of these tiles (one pair up to 128^3) is a step of ~15 us, of which the five-body kernel's entry is 2-3
-                if ((cand.ntiles >= 128 && (long)cand.ntiles * vol->B >= 1024) || (vol->flags & TRX_FLAG_DEEP_TILE)) trd = cand;
+                if ((cand.ntiles >= 128 && (long)cand.ntiles * vol->B >= 2l * persistent_blocks()) || (vol->flags & TRX_FLAG_DEEP_TILE)) trd = cand;
             }
             // the z-streaming body: pairs next to the identity (zs_fits) in launches that fill the chip
             ZGeom zg = ZGeom{};
