@@ -22,6 +22,9 @@
 #ifndef TRX_EF_STAGES
 #define TRX_EF_STAGES 2   // rows in flight in the gather (3: also the table reads of row j + 2 - measured alternative)
 #endif
+#ifndef TRX_EF_ROWSTEP
+#define TRX_EF_ROWSTEP 1   // row terms of the coordinates and yn by stepping from the first row of a call instead of one v_readlane per row and term (0: measured alternative)
+#endif
 #ifndef TRX_EF_EPS
 #define TRX_EF_EPS 0.05f   // slack of every window bound: fp32 rounding of the coordinates + non-uniformity of ATen's coordinate tables
 #endif
@@ -390,6 +393,11 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             if (TRX_EF_DBG & 2) { tvj = 1.f; return; }
             asm volatile("global_load_dword %0, %1, %2" TRX_TGT_POLICY : "=v"(tvj) : "v"(toffb), "s"(trow) : "memory");
         };
+#if TRX_EF_ROWSTEP
+        // per-row steps of the row terms (wave-uniform): yn advances by dyn per row, the un-normalised y by H / 2 * dyn (= 1 up to rounding)
+        const float dyn_s = uni(H > 1 ? ytab[1] - ytab[0] : 0.f);
+        const float dpx_s = uni(sx * dyn_s), dpy_s = uni((hH + sy) * dyn_s), dpz_s = uni(sz * dyn_s);
+#endif
         // ---- gather of rows [ja, jb) of tile `ty` from buffer `buf`
         auto gather_rows = [&](int ty, const TileOrg &o, int buf, float yn_l, float (&tv)[kRows], int ja, int jb, bool more) {
             if (TRX_EF_DBG & 4) {
@@ -407,8 +415,20 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             asm("s_mov_b32 %0, %1" : "=s"(bufdw_s) : "s"((int)(lds0 >> 2) + buf * C::BufFloats));
             struct S1 { int e00, e01, e10, e11, xi; float fx, fy, fz; };
             struct S2 { f2 r00, r01, r10, r11; float fx, fy, fz; };
+#if TRX_EF_ROWSTEP
+            // Row terms by STEPPING (round 5): the row term of row ja comes from its lane (three v_readlane per call of four rows), rows ja + 1 ..
+            // add the per-row step - yn is an arithmetic progression in the row index up to one fp32 ulp (ATen's linspace table), i.e. up to
+            // ~1e-5 voxels over a tile, below the fp32 resolution of the coordinates themselves; this kernel only runs rotated poses, where no
+            // sample sits on the lattice by construction.  Per voxel: three adds instead of three v_readlane (4.5 cycles each) + three adds.
+            float ixr = bxt + lane_bcast(px_l, ja), iyr = byt + lane_bcast(py_l, ja), izr = bzt + lane_bcast(pz_l, ja);
+            float ynr = lane_bcast(yn_l, ja);
+            auto stage1 = [&](int j) -> S1 {
+                const float ix = ixr, iy = iyr, iz = izr;
+                ixr += dpx_s; iyr += dpy_s; izr += dpz_s;
+#else
             auto stage1 = [&](int j) -> S1 {
                 const float ix = bxt + lane_bcast(px_l, j), iy = byt + lane_bcast(py_l, j), iz = bzt + lane_bcast(pz_l, j);
+#endif
                 int t, ta;
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(floor_to_int(iz)), "s"(tp_s), "v"(floor_to_int(iy)));
                 asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ta) : "v"(t), "s"(tab_s));
@@ -436,7 +456,12 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             // two named register sets taken in turns (a conditional `next = ...` made the compiler copy 11 registers per row)
             auto consume = [&](const S2 &f, int j) {
                 const Samp3 sm = lerp3_pairs<kGrad>(f.r00, f.r01, f.r10, f.r11, f.fx, f.fy, f.fz);
+#if TRX_EF_ROWSTEP
+                if (j < je) f1_accumulate_pk<MODE>(sm, tv[j], ynr, acc);   // (uniform: rows of the last, partial tile)
+                ynr += dyn_s;
+#else
                 if (j < je) f1_accumulate_pk<MODE>(sm, tv[j], lane_bcast(yn_l, j), acc);   // (uniform: rows of the last, partial tile)
+#endif
                 if (more) issue_target(ty + 1, j, tv[j]);
             };
             static_assert(kRows / 2 == 4, "four rows per call");
