@@ -10,7 +10,7 @@ OBJS    := $(SRCS:$(CSRC)/%.hip=build/%.o)
 LIB     := torchregister_amd/lib/libtrx.so
 # -fno-slp-vectorize: on gfx950 v_pk_*_f32 is no faster than two scalar VALU ops, and the SLP
 # vectoriser's register pairing + v_mov shuffles cost ~50 VGPRs in the tile kernel (occupancy 4 -> 2 waves/SIMD)
-HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-slp-vectorize -Wall -Wno-unused-function
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-but-set-variable
 
 all: $(LIB)
 

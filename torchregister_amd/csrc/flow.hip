@@ -451,6 +451,9 @@ __device__ __forceinline__ float lerp_corners3(const Corners3 &c, float *d)
 // target (read) - carry the non-temporal hint: they are 1.3 GB a pass, nothing of them survives in the caches until the next pass, and
 // without the hint they evict the moving volume and the flow planes that the gathers and the regulariser's neighbours DO re-read
 // (256^3, with the row-wide blocks below: Adam 310 -> 247 ... 265 us per iteration depending on the box, Adam + smoothness 338 -> 303; profiles/r04h_flow_variants.txt).
+#ifndef TRX_FLOW_DBG
+#define TRX_FLOW_DBG 0
+#endif
 #ifndef TRX_FLOW_NT
 #define TRX_FLOW_NT 7      // bit 0: stores of flow / m / v, bit 1: loads of m / v, bit 2: loads of the target (0: development baseline)
 #endif
@@ -616,8 +619,16 @@ __global__ __launch_bounds__(TRX_BLOCK, SMOOTH ? 4 : 5) void flow_update3_kernel
                 if (adam) { sd.m[ch] = ld_stream(am + ch * (size_t)nvox + iv); sd.v[ch] = ld_stream(av + ch * (size_t)nvox + iv); }
                 if constexpr (SMOOTH) {
                     const float *fch = fl + ch * (size_t)nvox;
+#if TRX_FLOW_DBG & 1   // development ablation: no y-neighbour loads (wrong results: what would removing them buy?)
+                    sd.yl[ch] = sd.yh[ch] = 0.5f;
+#else
                     sd.yl[ch] = fch[iv - dyl]; sd.yh[ch] = fch[iv + dyh];
+#endif
+#if TRX_FLOW_DBG & 2   // ... no x-neighbour loads
+                    sd.xl[ch] = sd.xh[ch] = 0.25f;
+#else
                     sd.xl[ch] = fch[iv - dxl]; sd.xh[ch] = fch[iv + dxh];
+#endif
                 }
             }
             return sd;

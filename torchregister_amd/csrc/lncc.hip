@@ -30,6 +30,12 @@ namespace trx {
 #ifndef TRX_LNCC_RCP
 #define TRX_LNCC_RCP 0
 #endif
+#ifndef TRX_LNCC_DIRECT
+#define TRX_LNCC_DIRECT 1   // round 5: ONE barrier per plane (1: in the builds where it wins - windows 7 and 9 at two blocks per CU; 2: everywhere; 0: nowhere).  The x window is summed in registers straight from the global loads (a thread of the
+                            // x pass loads the 12 consecutive cells of its row as three aligned float4 per input, forms the product fields, slides
+                            // the sums) and only the x sums go to LDS, double-buffered by plane parity - the raw tile, its commit and two of the
+                            // three barriers of a plane are gone.  0: the round 1-4 form (tile -> LDS -> x pass -> LDS -> y pass, three barriers)
+#endif
 #ifndef TRX_LNCC_PREFETCH
 #define TRX_LNCC_PREFETCH 1   // planes of the tile in flight ahead of the window passes (2: measured alternative - +20 registers, 8 x 256^3 w = 5 1818 -> 1932 us, w = 9 2274 -> 2251)
 #endif
@@ -40,10 +46,21 @@ namespace trx {
 // CU; under __launch_bounds__(256, 3) the same code fits 160 without spilling = three blocks.  Measured on one box (256^3, w = 9, loss +
 // gradient): one pair 371 us with two blocks per CU, 336 us with three (six z segments fill 768 slots); eight pairs 2.62 ms with two,
 // 2.83 ms with three - so the three-wave build runs w = 7, 9 when the batch is small enough to be z-split, the default build otherwise.
+// The direct form keeps 12 x NL prefetched cells per thread where the tile form keeps 3.75 x NL: with the z ring of a wide window at two blocks
+// per CU (194-196 VGPRs, no scratch) it is 12 % faster (8 x 256^3, w = 9: 2269 -> 1983 us), in the three- and four-blocks-per-CU builds it
+// spills and loses 40 % (profiles/r05a_lncc_direct.txt) - so it is chosen per build: windows 7 / 9 at two blocks per CU, and windows 3 / 5 (whose
+// strip is 8 cells, two of them halo float2s: 102-128 VGPRs at four blocks per CU, 8 x 256^3 w = 5 1817 -> 1750 us).
+template <int R, int MW>
+constexpr bool lncc_direct() { return TRX_LNCC_DIRECT == 2 || (TRX_LNCC_DIRECT == 1 && ((MW == 1 && R >= 3) || R <= 2)); }
 constexpr int kLO = TRX_LNCC_TWO_ROWS ? 2 : 1;      // outputs per thread: rows kLO * (tid >> 5) + o of the tile
 constexpr int kLX = 32, kLY = 8 * kLO;      // output tile of a block in x, y
 constexpr int kLRows = kLY + 8, kLCols = kLX + 8;   // tile + halo 4 (the largest radius)
 
+#ifndef TRX_LNCC_XS_PITCH
+#define TRX_LNCC_XS_PITCH (kLRows + 1)   // row pitch of the transposed x sums.  25: the y pass of a wave (32 columns x 2 thread rows, two apart) collides two-way on 14 of
+                                         // its 32 column pairs (25 (ox' - ox) = 2 mod 64 at ox' - ox = 18); 27 has no such pair below 32 (d = 38) - measured alternative
+#endif
+constexpr int kXsPitch = TRX_LNCC_XS_PITCH;
 constexpr int kLCells = (kLRows * kLCols + TRX_BLOCK - 1) / TRX_BLOCK;   // tile cells per thread (4: a 40 x 24 tile on 256 threads)
 
 // The raw inputs of one plane of the block's tile (+halo), held in registers between the global loads and the LDS
@@ -75,7 +92,7 @@ __device__ __forceinline__ void plane_fetch(int zin, int D, int H, int W, int X0
 // All threads of the block must call this together.
 template <int R, int NF, int NL, typename Expand>
 __device__ __forceinline__ void plane_window_sums(const PlaneRegs<NL> &r, Expand expand, float (*raw)[kLRows][kLCols],
-                                                  float (*xs)[kLX][kLRows + 1], float (&P)[kLO][NF])
+                                                  float (*xs)[kLX][kXsPitch], float (&P)[kLO][NF])
 {
     const int tid = threadIdx.x;
     __syncthreads();   // the previous plane's LDS reads are done
@@ -138,13 +155,110 @@ __device__ __forceinline__ void plane_window_sums(const PlaneRegs<NL> &r, Expand
     }
 }
 
+// ---- the direct form (TRX_LNCC_DIRECT) ----
+// The inputs of one plane for one thread of the x pass: 12 consecutive cells (output quad + halo 4 on both sides) of one tile row, NL inputs.
+template <int NL>
+struct StripRegs {
+    float v[NL][12];
+};
+// Loads of plane `zin` for x-pass thread (row, q): cells gx0 .. gx0 + 11 of row gy from the NL arrays src[f] (zeros outside the volume).
+// W % 4 == 0 (uniform): three float4 per input - the strip starts on a multiple of four, so a float4 is inside or outside as a whole.
+template <int NL, int R>
+__device__ __forceinline__ void strip_fetch(int zin, int D, int H, int W, int X0, int Y0, const float *const (&src)[NL], StripRegs<NL> &r)
+{
+    const int tid = threadIdx.x;
+    const int row = tid >> 3, q = tid & 7;
+    const int gy = Y0 - 4 + row, gx0 = X0 + 4 * q - 4;
+    const bool row_ok = (zin >= 0) && (zin < D) && (tid < kLRows * (kLX / 4)) && ((unsigned)gy < (unsigned)H);
+#pragma unroll
+    for (int f = 0; f < NL; f++)
+#pragma unroll
+        for (int k = 0; k < 12; k++) r.v[f][k] = 0.f;
+    if (!row_ok) return;
+    const size_t base = ((size_t)zin * H + gy) * W;
+    if ((W & 3) == 0) {
+#pragma unroll
+        for (int f = 0; f < NL; f++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int gx = gx0 + 4 * c;
+                if (gx >= 0 && gx + 4 <= W) {
+                    if (R <= 2 && c != 1) {   // windows 3 and 5 touch cells 2 .. 9 only: two of the halo quad's cells (a float2), half the registers
+                        const int k0 = (c == 0) ? 2 : 8;
+                        const float2 t = *reinterpret_cast<const float2 *>(src[f] + base + gx0 + k0);
+                        r.v[f][k0] = t.x; r.v[f][k0 + 1] = t.y;
+                    } else {
+                        const float4 t = *reinterpret_cast<const float4 *>(src[f] + base + gx);
+                        r.v[f][4 * c] = t.x; r.v[f][4 * c + 1] = t.y; r.v[f][4 * c + 2] = t.z; r.v[f][4 * c + 3] = t.w;
+                    }
+                }
+            }
+    } else {
+#pragma unroll
+        for (int f = 0; f < NL; f++)
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const int gx = gx0 + k;
+                if ((unsigned)gx < (unsigned)W) r.v[f][k] = src[f][base + gx];
+            }
+    }
+}
+// x window in registers -> xs (this plane's buffer) -> ONE barrier -> y window.  field(f, in[NL]) = field f of a cell from its NL inputs.
+// All threads of the block must call this together; xsb = the xs buffer of this plane's parity (the other one may still be read by threads
+// that have not finished the previous plane's y pass - nobody writes it before the NEXT barrier).
+template <int R, int NF, int NL, typename Field>
+__device__ __forceinline__ void plane_window_sums_direct(const StripRegs<NL> &r, Field field, float (*xsb)[kLX][kXsPitch], float (&P)[kLO][NF])
+{
+    const int tid = threadIdx.x;
+    if (tid < kLRows * (kLX / 4)) {
+        const int row = tid >> 3, q = tid & 7;
+        if (row >= 4 - R && row < kLY + 4 + R) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                float v[12];
+#pragma unroll
+                for (int k = 3 - R + 1; k <= 4 + R + 3; k++) {   // the cells this window radius touches: 4 - R .. 7 + R
+                    float in[NL];
+#pragma unroll
+                    for (int l = 0; l < NL; l++) in[l] = r.v[l][k];
+                    v[k] = field(f, in);
+                }
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 4 - R; k <= 4 + R; k++) sum += v[k];
+                xsb[f][4 * q][row] = sum;
+#pragma unroll
+                for (int i = 1; i < 4; i++) {
+                    sum += v[4 + R + i] - v[3 - R + i];
+                    xsb[f][4 * q + i][row] = sum;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int ox = tid & (kLX - 1), oy = kLO * (tid >> 5);
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        float v[2 * R + kLO];
+#pragma unroll
+        for (int k = 0; k < 2 * R + kLO; k++) v[k] = xsb[f][ox][oy + 4 - R + k];
+#pragma unroll
+        for (int o = 0; o < kLO; o++) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * R; k++) sum += v[o + k];
+            P[o][f] = sum;
+        }
+    }
+}
+
 // Walks the column along z, keeping the z window as a running sum over a register ring; emit(z, Z) is called for
 // every output plane with the full window sums Z[NF] of this thread's voxel.
 // pre(z, o) is called one plane's worth of window passes BEFORE emit(z, Z, o, pre(z, o)): what emit needs from global memory about its
 // own voxel (the gradient kernel: I_p, J_p) is requested there, so that its latency hides under the passes instead of stalling every plane.
 template <int R, int NF, int NL, typename Fetch, typename Expand, typename Pre, typename Emit>
 __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0, int Y0, int z0, int z1, Fetch fetch, Expand expand, Pre pre, Emit emit,
-                                            float (*raw)[kLRows][kLCols], float (*xs)[kLX][kLRows + 1])
+                                            float (*raw)[kLRows][kLCols], float (*xs)[kLX][kXsPitch])
 {   // output planes [z0, z1) of the column (a z segment: small batches split columns so that the chip is filled)
     PlaneRegs<NL> regs;
     if (nd == 2) {   // images: the window has no z extent
@@ -228,6 +342,81 @@ __device__ __forceinline__ void column_walk(int nd, int D, int H, int W, int X0,
     }
 }
 
+// The same walk over the direct form of the plane passes: src[NL] = the input arrays of this pair, field(f, in) = field f of a cell.
+template <int R, int NF, int NL, typename Field, typename Pre, typename Emit>
+__device__ __forceinline__ void column_walk_direct(int nd, int D, int H, int W, int X0, int Y0, int z0, int z1, const float *const (&src)[NL], Field field, Pre pre, Emit emit,
+                                                   float (*xs)[NF][kLX][kXsPitch])
+{
+    StripRegs<NL> regs;
+    int par = 0;
+    if (nd == 2) {
+        float P[kLO][NF];
+        strip_fetch<NL, R>(0, 1, H, W, X0, Y0, src, regs);
+        decltype(pre(0, 0)) pv[kLO];
+#pragma unroll
+        for (int o = 0; o < kLO; o++) pv[o] = pre(0, o);
+        plane_window_sums_direct<R, NF, NL>(regs, field, xs[0], P);
+#pragma unroll
+        for (int o = 0; o < kLO; o++) emit(0, P[o], o, pv[o]);
+        return;
+    }
+    constexpr int WN = 2 * R + 1;
+    float ring[kLO][WN][NF], Z[kLO][NF];
+#pragma unroll
+    for (int o = 0; o < kLO; o++) {
+#pragma unroll
+        for (int k = 0; k < WN; k++)
+#pragma unroll
+            for (int f = 0; f < NF; f++) ring[o][k][f] = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; f++) Z[o][f] = 0.f;
+    }
+    strip_fetch<NL, R>(z0 - R, D, H, W, X0, Y0, src, regs);
+    for (int base = z0 - R; base < z1 + R; base += WN) {
+#pragma unroll
+        for (int k = 0; k < WN; k++) {
+            const int zin = base + k;
+            if (zin < z1 + R) {
+                float P[kLO][NF];
+                decltype(pre(0, 0)) pv[kLO];
+                if (zin - R >= z0) {
+#pragma unroll
+                    for (int o = 0; o < kLO; o++) pv[o] = pre(zin - R, o);
+                }
+                if (zin >= 0 && zin < D) {   // uniform
+                    const StripRegs<NL> cur = regs;
+                    strip_fetch<NL, R>(zin + 1, D, H, W, X0, Y0, src, regs);   // next plane in flight during this plane's passes
+                    plane_window_sums_direct<R, NF, NL>(cur, field, xs[par], P);
+                    par ^= 1;
+                } else {                     // planes outside the volume are zero padding
+                    strip_fetch<NL, R>(zin + 1, D, H, W, X0, Y0, src, regs);
+#pragma unroll
+                    for (int o = 0; o < kLO; o++)
+#pragma unroll
+                        for (int f = 0; f < NF; f++) P[o][f] = 0.f;
+                }
+#pragma unroll
+                for (int o = 0; o < kLO; o++) {
+#pragma unroll
+                    for (int f = 0; f < NF; f++) {
+                        if (k == 0) {   // once per ring turn: exact re-summation instead of the running update
+                            ring[o][0][f] = P[o][f];
+                            float sum = 0.f;
+#pragma unroll
+                            for (int j = 0; j < WN; j++) sum += ring[o][j][f];
+                            Z[o][f] = sum;
+                        } else {
+                            Z[o][f] += P[o][f] - ring[o][k][f];
+                            ring[o][k][f] = P[o][f];
+                        }
+                    }
+                    if (zin - R >= z0) emit(zin - R, Z[o], o, pv[o]);
+                }
+            }
+        }
+    }
+}
+
 #ifndef TRX_LNCC_NT
 #define TRX_LNCC_NT 7   // non-temporal hints - bit 0 stores of the fields, bit 1 store of the gradient, bit 2 loads of I, J at the emit of the gradient kernel
                         // (8 x 256^3: w = 5 1890 -> 1826 us, w = 9 2323 -> 2278; one pair within the noise; profiles/r04h_lncc_variants.txt)
@@ -238,8 +427,13 @@ template <int R, int MW>
 __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_fields_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
                                                                int W, int zsplit, float eps, float *__restrict__ fields, float *__restrict__ partials)
 {
-    __shared__ __attribute__((aligned(16))) float raw[5][kLRows][kLCols];   // I, J, I^2, J^2, I J of the tile (+halo)
-    __shared__ float xs[5][kLX][kLRows + 1];
+    // direct form: x sums of I, J, I^2, J^2, I J - the plane in work / the previous one (by plane parity); else: the five fields of the tile (+halo), then their x sums
+    constexpr bool kDirect = lncc_direct<R, MW>();
+    constexpr int kTile = 5 * kLRows * kLCols, kXs = 5 * kLX * kXsPitch;
+    __shared__ __attribute__((aligned(16))) float lds[kDirect ? 2 * kXs : kTile + kXs];
+    float (*raw)[kLRows][kLCols] = reinterpret_cast<float (*)[kLRows][kLCols]>(lds);
+    float (*xs)[kLX][kXsPitch] = reinterpret_cast<float (*)[kLX][kXsPitch]>(lds + (kDirect ? 0 : kTile));
+    float (*xs2)[5][kLX][kXsPitch] = reinterpret_cast<float (*)[5][kLX][kXsPitch]>(lds);
     const int b = blockIdx.z / zsplit, seg = blockIdx.z - b * zsplit, X0 = blockIdx.x * kLX, Y0 = blockIdx.y * kLY;
     const int zlen = (D + zsplit - 1) / zsplit, z0 = seg * zlen, z1 = min(D, z0 + zlen);
     const size_t n = (size_t)D * H * W;
@@ -276,7 +470,13 @@ __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_fields_kernel(const float 
         const size_t off = ((size_t)z * H + y + o) * W + x;
         st_nt<0>(F + off, Pq); st_nt<0>(F + n + off, Qq); st_nt<0>(F + 2 * n + off, (Qq * Js - Pq * Is) * inv_n);
     };
-    column_walk<R, 5, 2>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, pre, emit, raw, xs);
+    if constexpr (kDirect) {
+        const float *const src[2] = {I, J};
+        auto field = [](int f, const float (&in)[2]) { return f == 0 ? in[0] : (f == 1 ? in[1] : (f == 2 ? in[0] * in[0] : (f == 3 ? in[1] * in[1] : in[0] * in[1]))); };
+        column_walk_direct<R, 5, 2>(nd, D, H, W, X0, Y0, z0, z1, src, field, pre, emit, xs2);
+    } else {
+        column_walk<R, 5, 2>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, pre, emit, raw, xs);
+    }
     // block sum of the cc partials in a fixed order: butterfly inside each wave, then the 4 wave sums through LDS
     // (a generic block_reduce_store would add 16 KB of static LDS and halve the blocks per CU)
 #pragma unroll
@@ -292,8 +492,12 @@ template <int R, int MW>
 __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_grad_kernel(const float *__restrict__ tgt, const float *__restrict__ wrp, int nd, int D, int H,
                                                              int W, int zsplit, float scale, const float *__restrict__ fields, float *__restrict__ grad)
 {
-    __shared__ __attribute__((aligned(16))) float raw[3][kLRows][kLCols];
-    __shared__ float xs[3][kLX][kLRows + 1];
+    constexpr bool kDirect = lncc_direct<R, MW>();
+    constexpr int kTile = 3 * kLRows * kLCols, kXs = 3 * kLX * kXsPitch;
+    __shared__ __attribute__((aligned(16))) float lds[kDirect ? 2 * kXs : kTile + kXs];
+    float (*raw)[kLRows][kLCols] = reinterpret_cast<float (*)[kLRows][kLCols]>(lds);
+    float (*xs)[kLX][kXsPitch] = reinterpret_cast<float (*)[kLX][kXsPitch]>(lds + (kDirect ? 0 : kTile));
+    float (*xs2)[3][kLX][kXsPitch] = reinterpret_cast<float (*)[3][kLX][kXsPitch]>(lds);
     const int b = blockIdx.z / zsplit, seg = blockIdx.z - b * zsplit, X0 = blockIdx.x * kLX, Y0 = blockIdx.y * kLY;
     const int zlen = (D + zsplit - 1) / zsplit, z0 = seg * zlen, z1 = min(D, z0 + zlen);
     const size_t n = (size_t)D * H * W;
@@ -325,7 +529,13 @@ __global__ __launch_bounds__(TRX_BLOCK, MW) void lncc_grad_kernel(const float *_
         const size_t off = ((size_t)z * H + y + o) * W + x;
         st_nt<1>(G + off, scale * (v.i * Z[0] - v.j * Z[1] + Z[2]));
     };
-    column_walk<R, 3, 3>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, pre, emit, raw, xs);
+    if constexpr (kDirect) {
+        const float *const src[3] = {F, F + n, F + 2 * n};
+        auto field = [](int f, const float (&in)[3]) { return f == 0 ? in[0] : (f == 1 ? in[1] : in[2]); };
+        column_walk_direct<R, 3, 3>(nd, D, H, W, X0, Y0, z0, z1, src, field, pre, emit, xs2);
+    } else {
+        column_walk<R, 3, 3>(nd, D, H, W, X0, Y0, z0, z1, fetch, expand, pre, emit, raw, xs);
+    }
 }
 
 // loss[b] = alpha * (1 - sum(partials) / N), partials reduced in fp64 in a fixed order
