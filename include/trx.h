@@ -68,6 +68,7 @@ typedef enum {
 #define TRX_FLAG_EFT 1024u          /* affine steps: offer the exact-footprint body whatever the batch size (by default only to launches that fill the chip) */
 #define TRX_FLAG_ZS_FUSED 2048u      /* affine steps on launches that fill the chip: keep the z-streaming body inside the tile kernel (the round 3-4 form) instead of
                                       * running it as a kernel of its own in front (measured alternative; tests compare the two) */
+#define TRX_FLAG_NO_ZS_FLAT 4096u     /* affine steps: the z-streaming kernel never uses its flat 64 x 16 tile (pairs beyond the 64 x 32 tile's window run the tile kernels) */
 #define TRX_FLAG_NO_ROT_DEEP_TILE 16u /* affine steps: never use GeomRD (the 16 x 16 x 16 tile in GeomR's box) - rotated pairs all run GeomR */
 
 /* A batch of B independent (moving, target) pairs. */

@@ -194,3 +194,48 @@ def test_zstream_offer_boundary_never_trips(eng):
             assert np.max(np.abs(grad - grad_t)) <= 4e-4 * np.max(np.abs(grad_t)), (shape, k, lo)
     assert tripped == 0, f"{tripped} poses at the edge of the offer rule tripped the body's own window test"
     assert min(edges) > 1e-3 and np.median(edges) < 0.2, (min(edges), np.median(edges), max(edges))   # the bisection found the rule's edge (directions that are mostly translation have none: the window follows)
+
+
+def _rot(ax, ay, az):
+    cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+    return np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+
+
+def test_zstream_flat_tile_in_the_convergence_basin(eng):
+    """Round 5: the z-streaming kernel's FLAT tile (64 x 16 voxels per plane under a ring of 8 planes of 80 x 30: csrc/affine_zstream.h ZSF) takes the
+    pairs of a chip-filling launch that the 64 x 32 tile's window does not hold - rotations up to ~0.15 rad about z, zooms to ~1.1, a few
+    planes of tilt: where an affine run converges to.  One launch of 16 pairs of 64 x 128 x 128 at sixteen such poses (and two that neither tile
+    takes): every pair against the same launch with TRX_FLAG_NO_ZS_FLAT (the tile kernels) to the fp32 floor, four of them against the C oracle."""
+    from torchregister_amd import _lib
+    shape, B = (64, 128, 128), 16
+    rng = np.random.default_rng(7)
+    mats = []
+    for i in range(B):
+        A = _rot(rng.uniform(-0.02, 0.02), rng.uniform(-0.02, 0.02), rng.choice([-1.0, 1.0]) * rng.uniform(0.07, 0.14)) @ np.diag(1.0 + rng.uniform(-0.04, 0.08, 3))
+        if i == 5: A = _rot(0.0, 0.0, 0.5)              # beyond both tiles: GeomRD / exact-footprint
+        if i == 11: A = np.eye(3) + 0.002               # inside the 64 x 32 tile's window
+        mats.append(np.concatenate([A, rng.uniform(-0.05, 0.05, (3, 1))], axis=1))
+    th = torch.tensor(np.stack(mats), dtype=torch.float32)
+    tgt = torch.cat([ph.blobs(shape, 1200 + b) for b in range(B)]).cuda()
+    mov = torch.cat([ph.blobs(shape, 1300 + b) + 0.1 * ph.vol(shape, 0.017, "sin") for b in range(B)]).cuda()
+    kw = dict(w_ncc=1.0, w_mse=0.3)
+    s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
+    s.run(1)
+    sn = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=_lib.FLAG_NO_ZS_FLAT)
+    sn.run(1)
+    torch.cuda.synchronize()
+    bodies, bodies_n = s.bodies(), sn.bodies()
+    assert bodies.count("zstream-flat") >= 8 and bodies[11] == "zstream" and not bodies[5].startswith("zstream"), bodies
+    assert "zstream-flat" not in bodies_n, bodies_n
+    for b in range(B):
+        assert abs(s.losses[b, 0].item() - sn.losses[b, 0].item()) <= 2e-5 * max(1.0, abs(sn.losses[b, 0].item())), (b, bodies[b])
+        gb = sn.grad[b, :12]
+        assert torch.max(torch.abs(s.grad[b, :12] - gb)).item() <= 3e-4 * gb.abs().max().item(), (b, bodies[b])
+    t64, t32 = oracle.base_tables(shape, np.float64), oracle.base_tables(shape, np.float32)
+    flat = [b for b in range(B) if bodies[b] == "zstream-flat"]
+    for b in flat[:4]:
+        m, t = mov[b, 0].cpu().numpy(), tgt[b, 0].cpu().numpy()
+        total, _, dth, _ = oracle.c_affine_loss_grad(m.astype(np.float64), t.astype(np.float64), th[b].double().numpy(), oracle.wts(**kw), t64)
+        _, _, dth32, _ = oracle.c_affine_loss_grad(m, t, th[b].numpy(), oracle.wts(**kw), t32)
+        assert abs(s.losses[b, 0].item() - total) <= 2e-5 * max(1.0, abs(total)), b
+        assert np.max(np.abs(s.grad[b, :12].cpu().numpy().reshape(3, 4) - dth)) <= max(2e-4 * np.max(np.abs(dth)), 2.0 * np.max(np.abs(dth32 - dth))), b

@@ -196,7 +196,7 @@ class AffineSolver:
                                          _lib.current_stream(self.batch.device))
         _lib.check(rc, "trx_affine_run")
 
-    BODIES = {0: "none", 1: "tile-D", 2: "tile-A", 3: "tile-R", 4: "tile-RD", 5: "zstream-fused", 6: "zstream", 7: "eft"}
+    BODIES = {0: "none", 1: "tile-D", 2: "tile-A", 3: "tile-R", 4: "tile-RD", 5: "zstream-fused", 6: "zstream", 7: "eft", 8: "zstream-flat"}
 
     def _rows_notes(self):
         off = int(self.lib.trx_affine_workspace_rows_offset(ctypes.byref(self.vol)))

@@ -46,7 +46,7 @@ static AffineGeom affine_geom(const trx_volumes &v, int target_blocks_total)
 constexpr int np_full(int nd) { return 5 + 3 * nd * (nd + 1); }
 // rows_used[b] (the step kernels' note to the finalise kernel): low 24 bits = partial rows the pair's kernel wrote, bits 24-27 = which body
 // (1 + dual_choice for the tile kernel: 1 GeomD, 2 GeomA, 3 GeomR, 4 GeomRD, 5 z-streaming inside it; 6 = the z-streaming kernel, 7 = the
-// exact-footprint kernel), NEGATIVE when a kernel in front of the tile kernel took the pair.  Read back by AffineSolver.bodies().
+// exact-footprint kernel, 8 = the z-streaming kernel's flat tile), NEGATIVE when a kernel in front of the tile kernel took the pair.  Read back by AffineSolver.bodies().
 constexpr int kRowsMask = 0xFFFFFF;
 __host__ __device__ constexpr int rows_note(int rows, int body) { return rows > 0 ? (rows | (body << 24)) : 0; }
 constexpr int kNpMse = 13;   // partial-row layout of the MSE / SSD-only step kernel (3-D): sum d^2, then 12 x sum(d J)
@@ -1363,18 +1363,29 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
 // rows_used[b] = -(its rows) for them and 0 for the rest, the number of pairs it did NOT take in rows_used[B] and the bit mask of those it
 // took in rows_used[B + 1, B + 2]: the two kernels behind it return at once when the count is zero (a launch boundary each, ~1.5 us), and
 // otherwise skip the pairs of the mask.
+#ifndef TRX_ZS_FLAT
+#define TRX_ZS_FLAT 1   // the z-streaming kernel also carries the FLAT tile (ZSF: 64 x 16 voxels per plane, ring of 8 planes of 80 x 30) for pairs the 64 x 32 tile
+                        // does not take: poses of the convergence basin (rotations up to ~0.15 rad about z, zooms to 1.15, 3.7 planes of tilt) run 10-11 %
+                        // faster on it than on the deep tile kernel (profiles/r05a_zs_flat_tile.txt); 0: never
+#endif
 template <int MODE>
-__global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_step_kernel(trx_volumes vol, const float *__restrict__ theta, ZGeom zg, float *__restrict__ partials,
+__global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_step_kernel(trx_volumes vol, const float *__restrict__ theta, ZGeom zg, ZGeom zgf, float *__restrict__ partials,
                                                                                          int *__restrict__ rows_used, int stride)
 {
-    __shared__ __attribute__((aligned(16))) float ring[ZS64::Alloc];
+    constexpr int kAlloc = (TRX_ZS_FLAT && ZSF::Alloc > ZS64::Alloc) ? ZSF::Alloc : ZS64::Alloc;
+    __shared__ __attribute__((aligned(16))) float ring[kAlloc];
     const int wave = trx_wave_index(), lane = trx_lane_id();
     const float fD = (float)vol.D, fH = (float)vol.H, fW = (float)vol.W;
-    const bool take_l = lane < vol.B && zs_nsub<ZS64>(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, zg.planes_per_seg) > 0;
-    const unsigned long long take = __builtin_amdgcn_ballot_w64(take_l);
-    const int mine = take_l ? zg.blocks_per_pair : 0;
+    // per pair (lane): 1 = the 64 x 32 tile takes it, 2 = the flat tile does, 0 = left to the kernels behind
+    int which = 0;
+    if (lane < vol.B) {
+        if (zs_nsub<ZS64>(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, zg.planes_per_seg) > 0) which = 1;
+        else if (TRX_ZS_FLAT && zgf.blocks_per_pair > 0 && zs_nsub<ZSF>(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, zgf.planes_per_seg) > 0) which = 2;
+    }
+    const unsigned long long take = __builtin_amdgcn_ballot_w64(which != 0), take1 = __builtin_amdgcn_ballot_w64(which == 1);
+    const int mine = which == 1 ? zg.blocks_per_pair : (which == 2 ? zgf.blocks_per_pair : 0);
     if (blockIdx.x == 0 && wave == 0) {
-        if (lane < vol.B) rows_used[lane] = -rows_note(mine, 6);
+        if (lane < vol.B) rows_used[lane] = -rows_note(mine, which == 2 ? 8 : 6);
         if (lane == 0) {
             rows_used[vol.B] = vol.B - __builtin_popcountll(take);
             rows_used[vol.B + 1] = (int)(unsigned)take; rows_used[vol.B + 2] = (int)(unsigned)(take >> 32);   // which pairs: nobody rewrites this
@@ -1394,7 +1405,8 @@ __global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_ste
         const int off = pair > 0 ? __builtin_amdgcn_readlane(pre, pair - 1) : 0;
         const int v = __builtin_amdgcn_readfirstlane(item - off);
         if (item != (int)blockIdx.x) __syncthreads();   // the previous item's reduction scratch aliases the ring
-        zstream_body<MODE, ZS64>(vol, theta, zg, partials, ring, v, pair, stride, wave, second);
+        if (!TRX_ZS_FLAT || ((take1 >> pair) & 1ull)) zstream_body<MODE, ZS64>(vol, theta, zg, partials, ring, v, pair, stride, wave, second);
+        else zstream_body<MODE, ZSF>(vol, theta, zgf, partials, ring, v, pair, stride, wave, second);
     }
 }
 
@@ -2141,7 +2153,8 @@ static size_t tile_rows_per_pair(const trx_volumes &v)
     size_t n = (size_t)tile_geom<GeomP>(v).blocks_per_pair;
     const size_t a = (size_t)tile_geom<GeomA>(v).blocks_per_pair, r = (size_t)tile_geom<GeomR>(v).blocks_per_pair;
     const size_t d = (size_t)tile_geom<GeomD>(v).blocks_per_pair, rd = (size_t)tile_geom<GeomRD>(v).blocks_per_pair;
-    const size_t z = zs_shape_ok<ZS64>(v) ? (size_t)zs_geom<ZS64>(v).blocks_per_pair : 0;
+    size_t z = zs_shape_ok<ZS64>(v) ? (size_t)zs_geom<ZS64>(v).blocks_per_pair : 0;
+    if (TRX_ZS_FLAT && zs_shape_ok<ZSF>(v) && (size_t)zs_geom<ZSF>(v).blocks_per_pair > z) z = (size_t)zs_geom<ZSF>(v).blocks_per_pair;
     if (a > n) n = a;
     if (r > n) n = r;
     if (d > n) n = d;
@@ -2256,6 +2269,7 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             if (td.blocks_per_pair > gxx) gxx = td.blocks_per_pair;
             if (trd.blocks_per_pair > gxx) gxx = trd.blocks_per_pair;
             if (zg.blocks_per_pair > gxx) gxx = zg.blocks_per_pair;
+            if (TRX_ZS_FLAT && zg.blocks_per_pair > 0 && zs_shape_ok<ZSF>(*vol) && zs_geom<ZSF>(*vol).blocks_per_pair > gxx) gxx = zs_geom<ZSF>(*vol).blocks_per_pair;
             int *ru = aware ? (int *)((char *)partials + ws.off_rows_used) : nullptr;
             // big batches of the step kernels: a flat grid of persistent blocks over a pair-major work list (no surplus blocks; see the kernel)
             const int slots = persistent_blocks();
@@ -2273,7 +2287,8 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             const bool zs_first = flat && zg.blocks_per_pair > 0 && ru != nullptr && !(vol->flags & TRX_FLAG_ZS_FUSED);
             if constexpr (MODE == 0 || MODE == 4) {
                 if (zs_first) {
-                    hipLaunchKernelGGL((affine_zs_step_kernel<MODE>), dim3(slots, 1), dim3(ZS64::Threads), 0, s, v, theta, zg, partials, ru, gxx);
+                    const ZGeom zgf = (TRX_ZS_FLAT && zs_shape_ok<ZSF>(*vol) && !(vol->flags & TRX_FLAG_NO_ZS_FLAT)) ? zs_geom<ZSF>(*vol) : ZGeom{};
+                    hipLaunchKernelGGL((affine_zs_step_kernel<MODE>), dim3(slots, 1), dim3(ZS64::Threads), 0, s, v, theta, zg, zgf, partials, ru, gxx);
                     TRX_CHECK_LAUNCH();
                 }
                 if (eft) {   // in front of the tile kernel: takes its pairs and marks them rows_used < 0 (none - the usual case next to the identity - costs ~3 us, ~1.5 behind the z-streaming kernel)

@@ -98,7 +98,7 @@ struct ZCfg {
     static constexpr int Span = NZ - TRX_ZS_LEAD;                                // source planes a step may touch: [p - Span + 1, p], p = pbase + step
     static constexpr int ReduceScratch = Waves * 16 * 65 + Waves * 16;
     static constexpr int Alloc = (RingFloats + 4 > ReduceScratch) ? RingFloats + 4 : ReduceScratch;   // + one float4 the dummy DMAs write
-    static_assert(TX % 64 == 0 && Waves % XW == 0 && TY % RG == 0 && BW % 4 == 0 && LPP <= 64 && NZ >= 4 && NZ <= 8 && Span <= 6, "geometry");
+    static_assert(TX % 64 == 0 && Waves % XW == 0 && TY % RG == 0 && BW % 4 == 0 && LPP <= 64 && NZ >= 4 && NZ <= 8 && Span <= 7, "geometry");   // (the slot tables hold eight planes: floor(z) - zlo <= Span - 1 and its upper neighbour <= 7)
 };
 // 64 x 32 voxels per plane, ring of 7 planes of 72 x 40 floats = 80.6 KB: two blocks per CU.  The ring size is not a power of two: the
 // slot of a source plane comes from an 8-entry byte table (v_perm_b32), at the instruction count of a mask.
@@ -106,6 +106,9 @@ struct ZCfg {
 #define TRX_ZS_GEOM 0   // 1: ring of 6 planes of 80 x 42 floats - the same 80.6 KB with 9.7 / 5.4 instead of 1.7 / 3.4 voxels of slack in x / y, one plane less in z:
                         // measured alternative (profiles/r05a_zs_window_variants.txt: R_z(0.1) joins the window, the identity loses 4 %, a converging run 12 %)
 #endif
+// development (tools/zbench.hip): a FLAT tile - 64 x 16 voxels per plane under a ring of 8 planes of 80 x 30 floats (76.8 KB): 9.7 / 10.7 voxels of slack in
+// x / y and 3.7 planes of tilt, for poses of the convergence basin that the 64 x 32 tile leaves to the deep tile kernel
+using ZSF = ZCfg<64, 16, 8, 80, 30>;
 #if TRX_ZS_GEOM == 1
 using ZS64 = ZCfg<64, 32, 6, 80, 42>;
 #else
