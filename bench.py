@@ -376,8 +376,8 @@ def main():
             REP = 3   # launches per pose between the two events (the bracket itself costs 1-2 us)
             for e0, e1 in ev:
                 e0.record()
-                for _ in range(REP):
-                    rep.accumulate_only()
+                for r_ in range(REP):
+                    rep.accumulate_only(walk_down=bool(r_ & 1))   # (alternating directions, as the iterations of a run do: TRX_FLAG_WALK_DOWN)
                 e1.record()
                 rep.run(1)
             torch.cuda.synchronize()

@@ -239,3 +239,59 @@ def test_zstream_flat_tile_in_the_convergence_basin(eng):
         _, _, dth32, _ = oracle.c_affine_loss_grad(m, t, th[b].numpy(), oracle.wts(**kw), t32)
         assert abs(s.losses[b, 0].item() - total) <= 2e-5 * max(1.0, abs(total)), b
         assert np.max(np.abs(s.grad[b, :12].cpu().numpy().reshape(3, 4) - dth)) <= max(2e-4 * np.max(np.abs(dth)), 2.0 * np.max(np.abs(dth32 - dth))), b
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 64), (40, 64, 64), (70, 64, 128), (150, 32, 64)])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_zstream_walk_down_equals_walk_up(eng, shape, case):
+    """Round 5: TRX_FLAG_WALK_DOWN - the z-streaming columns walked from the last plane to the first (what every second iteration of
+    trx_affine_run does, so that a pass starts on the planes the previous one left in the Infinity Cache).  Same voxels, same per-voxel
+    arithmetic, another order of the sums along z: loss and gradient equal the upward walk's to the fp32 floor and meet the oracle's bars.
+    (150 planes: a column that re-anchors its window; the whole-voxel shifts of the 'shift' case put samples on lattice planes.)"""
+    from torchregister_amd import _lib
+    _, eps, shift = case
+    tgt = ph.blobs(shape, 41)
+    mov = ph.blobs(shape, 42) + 0.1 * ph.vol(shape, 0.013, "sin")
+    th = torch.tensor(near_identity(sum(shape), eps, shift), dtype=torch.float32)[None]
+    kw = dict(w_ncc=1.0, w_mse=0.5)
+    out = {}
+    for name, flags in (("up", _lib.FLAG_ZSTREAM), ("down", _lib.FLAG_ZSTREAM | _lib.FLAG_WALK_DOWN)):
+        s = eng.AffineSolver(mov.cuda(), tgt.cuda(), mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=flags)
+        s.run(1)
+        torch.cuda.synchronize()
+        out[name] = (s.losses[0, 0].item(), s.grad[0, :12].cpu().numpy().reshape(3, 4), s.bodies()[0])
+    assert out["up"][2] == out["down"][2]
+    from fuzz_affine import kink_variants
+    m64, t64, tu, tabs = mov[0, 0].double().numpy(), tgt[0, 0].double().numpy(), th[0].double().numpy(), oracle.base_tables(shape, np.float64)
+    total, _, dth, _ = oracle.c_affine_loss_grad(m64, t64, tu, oracle.wts(**kw), tabs)
+    gmax = np.max(np.abs(dth))
+    # (next to the identity bands of voxels sample within fp32 rounding of a lattice plane: the oracle's own sensitivity to a one-ulp nudge of
+    #  the translations widens the bar as in tests/fuzz_zstream.py - it is the same for both directions, which share every coordinate)
+    ksens = max(np.max(np.abs(oracle.c_affine_loss_grad(m64, t64, t, oracle.wts(**kw), tabs)[2] - dth)) for t in kink_variants(tu)) / gmax
+    gbar = max(2e-4, 2.0 * ksens)
+    for name in ("up", "down"):
+        loss, grad, _ = out[name]
+        assert abs(loss - total) <= 2e-5 * max(1.0, abs(total)), (name, loss, total)
+        assert np.max(np.abs(grad - dth)) <= gbar * gmax, (name, np.max(np.abs(grad - dth)) / gmax, gbar)
+    if out["up"][2].startswith("zstream"):   # the same voxels with the same coordinates in another order of summation
+        assert abs(out["up"][0] - out["down"][0]) <= 2e-6 * max(1.0, abs(total))
+        assert np.max(np.abs(out["up"][1] - out["down"][1])) <= 2e-5 * gmax, np.max(np.abs(out["up"][1] - out["down"][1])) / gmax
+
+
+def test_run_alternates_the_walk_and_follows_the_one_way_trajectory(eng):
+    """trx_affine_run toggles TRX_FLAG_WALK_DOWN on odd iterations (TRX_FLAG_NO_PINGPONG: never).  A 12-iteration Adam run of a chip-filling
+    launch (16 x 64 x 128 x 128: z-streaming kernel, both tiles) with and without the alternation: same loss curve and theta to the fp32 floor."""
+    from torchregister_amd import _lib
+    shape, B = (64, 128, 128), 16
+    tgt = torch.cat([ph.blobs(shape, 500 + i) for i in range(2)]).repeat(B // 2, 1, 1, 1, 1).cuda()
+    mov = torch.cat([ph.blobs(shape, 600 + i) for i in range(2)]).repeat(B // 2, 1, 1, 1, 1).cuda()
+    th = torch.stack([torch.tensor(near_identity(7 + i, 5e-3 if i % 3 else 0.09), dtype=torch.float32) for i in range(B)])
+    res = []
+    for flags in (0, _lib.FLAG_NO_PINGPONG):
+        s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), optimizer="adam", lr=1e-3, init=th, capacity=12, flags=flags)
+        s.run(12)
+        torch.cuda.synchronize()
+        res.append((s.losses.clone(), s.theta.clone(), s.bodies()))
+    assert any(b.startswith("zstream") for b in res[0][2]), res[0][2]
+    assert torch.allclose(res[0][0], res[1][0], rtol=3e-5, atol=3e-5)
+    assert torch.allclose(res[0][1], res[1][1], rtol=0, atol=3e-5)

@@ -213,11 +213,18 @@ class AffineSolver:
         v = self._rows_notes()
         return [self.BODIES.get(int(x), "?") for x in ((v.abs() >> 24) & 15).tolist()]
 
-    def accumulate_only(self):
-        """Launch only the streaming F1 kernel (partials into the workspace); used for kernel timing."""
-        with torch.cuda.device(self.batch.device):
-            rc = self.lib.trx_affine_accumulate(ctypes.byref(self.vol), _lib.ptr(self.theta), _lib.ptr(self.workspace), self.ws_bytes,
-                                                _lib.current_stream(self.batch.device))
+    def accumulate_only(self, walk_down=False):
+        """Launch only the streaming F1 kernel (partials into the workspace); used for kernel timing.  walk_down: this launch walks the
+        z-streaming columns downward (TRX_FLAG_WALK_DOWN) - what every second iteration of run() does."""
+        flags = self.vol.flags
+        if walk_down:
+            self.vol.flags = flags ^ _lib.FLAG_WALK_DOWN
+        try:
+            with torch.cuda.device(self.batch.device):
+                rc = self.lib.trx_affine_accumulate(ctypes.byref(self.vol), _lib.ptr(self.theta), _lib.ptr(self.workspace), self.ws_bytes,
+                                                    _lib.current_stream(self.batch.device))
+        finally:
+            self.vol.flags = flags
         _lib.check(rc, "trx_affine_accumulate")
 
     def eval_loss(self, theta=None):

@@ -19,6 +19,7 @@ PARAM_AFFINE, PARAM_RIGID = 0, 1
 # trx_volumes.flags (include/trx.h)
 FLAG_GATHER_PATH, FLAG_SINGLE_GEOM, FLAG_TWO_PASS_FLOW, FLAG_DEEP_TILE, FLAG_NO_ROT_DEEP_TILE, FLAG_NO_ZSTREAM, FLAG_ZSTREAM, FLAG_NEAREST, FLAG_SAVE_LAST = 1, 2, 4, 8, 16, 32, 64, 128, 256
 FLAG_NO_EFT, FLAG_EFT = 512, 1024
+FLAG_WALK_DOWN, FLAG_NO_PINGPONG = 8192, 16384   # z-streaming columns walked downward / trx_affine_run does not alternate the direction
 FLAG_NO_ZS_FLAT = 4096   # the z-streaming kernel without its flat tile (measured alternative)
 FLAG_ZS_FUSED = 2048   # keep the z-streaming body inside the tile kernel (measured alternative of round 5)
 

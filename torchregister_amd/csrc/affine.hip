@@ -2369,8 +2369,13 @@ extern "C" int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, 
 {
     if (iters < 0 || !st) return TRX_ERR_ARG;
     if (st->losses && iters > st->losses_capacity) return TRX_ERR_CAPACITY;
+    if (!vol) return TRX_ERR_ARG;
+    trx_volumes v = *vol;
     for (int i = 0; i < iters; i++) {
-        int rc = trx_affine_step(vol, loss, opt, st, workspace, workspace_bytes, stream);
+        // odd iterations walk the z-streaming columns downward: the tail of one pass is the head of the next (TRX_FLAG_WALK_DOWN)
+        v.flags = vol->flags;
+        if ((i & 1) && !(vol->flags & TRX_FLAG_NO_PINGPONG)) v.flags ^= TRX_FLAG_WALK_DOWN;
+        int rc = trx_affine_step(&v, loss, opt, st, workspace, workspace_bytes, stream);
         if (rc) return rc;
     }
     return TRX_OK;

@@ -173,6 +173,13 @@ template <int MODE, class C>
 __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float *__restrict__ theta, const ZGeom &zg, float *__restrict__ partials,
                                              float *ring, const int bx, const int by, int rows_per_pair, const int wave_in, const int second_slot = 0)
 {
+    const int walk_down = __builtin_amdgcn_readfirstlane((int)(vol.flags & TRX_FLAG_WALK_DOWN));
+    // walk_down (TRX_FLAG_WALK_DOWN; wave-uniform): the column is walked from its last plane to its first.  Nothing else changes - the sums are
+    // order-independent up to rounding - but a registration that alternates the direction from iteration to iteration finds the planes it
+    // read LAST in the 256 MiB Infinity Cache when it starts the next pass with them (profiles/r05a_power_cap.txt: a quarter of a 1 GiB pass,
+    // at 40 % of the energy of an HBM read).
+    const int dir = walk_down ? -1 : 1;
+    const bool down = walk_down != 0;
     static_assert(MODE == 0 || MODE == 1 || MODE == 4, "step kernels and the moments pass");
     constexpr int NQ = (MODE == 0) ? 3 : (MODE == 4 ? 1 : 0);
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 4 ? kNpMse : 5);
@@ -279,16 +286,18 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    for (int sub = 0; sub < nsub; sub++) {
+    for (int si = 0; si < nsub; si++) {
+        const int sub = down ? nsub - 1 - si : si;
         const int zb = zb0 + sub * sublen, ze = min(zb + sublen, ze0);
-        if (zb >= ze) break;
+        if (zb >= ze) continue;
         const int nsteps = ze - zb, last = nsteps - 1;
+        const int zf = down ? ze - 1 : zb, zl = down ? zb : ze - 1;   // the planes of the first and of the last step
         // ---- window of this anchor: x / y origin fixed, source plane p(s) = pbase + s is the highest one step s may touch
         float mnx = 1e30f, mxx = -1e30f, mny = 1e30f, mxy = -1e30f, mnz0 = 1e30f, mxz0 = -1e30f, mnz1 = 1e30f, mxz1 = -1e30f;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             float ix, iy, iz;
-            coord(X0 + ((k & 1) ? C::TX - 1 : 0), Y0 + ((k & 2) ? C::TY - 1 : 0), (k & 4) ? ze - 1 : zb, ix, iy, iz);
+            coord(X0 + ((k & 1) ? C::TX - 1 : 0), Y0 + ((k & 2) ? C::TY - 1 : 0), (k & 4) ? zl : zf, ix, iy, iz);
             mnx = fminf(mnx, ix); mxx = fmaxf(mxx, ix); mny = fminf(mny, iy); mxy = fmaxf(mxy, iy);
             if (k & 4) { mnz1 = fminf(mnz1, iz); mxz1 = fmaxf(mxz1, iz); } else { mnz0 = fminf(mnz0, iz); mxz0 = fmaxf(mxz0, iz); }
         }
@@ -303,8 +312,15 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
             need_rows = hy - oy; need_c4 = (hx - ox) >> 2;
             const int hi0 = (int)floorf(mxz0 + slack) + 1, hi1 = (int)floorf(mxz1 + slack) + 1;
             const int lo0 = (int)floorf(mnz0 - slack), lo1 = (int)floorf(mnz1 - slack);
-            pbase = max(hi0, hi1 - last);
-            fits = (hx <= ox + C::BW - 1) && (hy <= oy + C::BH - 1) && (lo0 >= pbase - (C::Span - 1)) && (lo1 >= pbase + last - (C::Span - 1));
+            // pbase = the LEADING plane of the window at step 0: walking up the highest plane a step may touch (window [pbase + s - (Span - 1),
+            // pbase + s]), walking down the lowest one (window [pbase - s, pbase - s + (Span - 1)])
+            if (!down) {
+                pbase = max(hi0, hi1 - last);
+                fits = (hx <= ox + C::BW - 1) && (hy <= oy + C::BH - 1) && (lo0 >= pbase - (C::Span - 1)) && (lo1 >= pbase + last - (C::Span - 1));
+            } else {
+                pbase = min(lo0, lo1 + last);
+                fits = (hx <= ox + C::BW - 1) && (hy <= oy + C::BH - 1) && (hi0 <= pbase + (C::Span - 1)) && (hi1 <= pbase - last + (C::Span - 1));
+            }
         }
         ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy); pbase = __builtin_amdgcn_readfirstlane(pbase);
         need_rows = __builtin_amdgcn_readfirstlane(need_rows); need_c4 = __builtin_amdgcn_readfirstlane(need_c4);
@@ -379,7 +395,7 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
         // being a vector-memory operation the compiler counts, drain the DMA pipeline with its s_waitcnt vmcnt(0))
         float zn_l = 0.f, zid_l = 0.f;
         auto load_ztab = [&](int s0) {
-            zn_l = ztab[min(zb + s0 + lane, D - 1)];
+            zn_l = ztab[max(0, min(zf + dir * (s0 + lane), D - 1))];
             zid_l = unnorm<3>(zn_l, fD);
         };
         // Ring slots of the source planes step s may touch, zlo = pbase + s - (Span - 1) being the lowest: byte r of `tabA` = slot of
@@ -472,12 +488,20 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
             }
         };
 
+        auto retreat_tables = [&]() {   // zlo -> zlo - 1 (walking down)
+            mlo = (mlo == 0) ? C::NZ - 1 : mlo - 1;
+            tabB = tabA;
+            tabA = (tabA << 8) | (unsigned long long)mlo;
+            selc += 1u;
+        };
+
         // ---- one step.  Program order of a wave:  T(s+1) | D(s+2) || wait: all but D(s+2) | barrier | T(s+2) | D(s+3) | gather(s+1) ...
         //   T(s+1): this thread's targets of the next plane into the other register set
         //   D(s+2): ring plane pbase + s + 2 into the slot of plane pbase + s + 2 - NZ, which no step >= s reads
-        const float *tnext = tgt + (size_t)(zb + 1) * H * W;   // target plane of the next step
-        const char *dnext = plane_ptr(pbase + TRX_ZS_LEAD);     // ring plane TRX_ZS_LEAD steps ahead ...
-        int dslot = pmod(pbase + TRX_ZS_LEAD);                  // ... and its slot
+        const ptrdiff_t tstep = (ptrdiff_t)dir * H * W, dstep = (ptrdiff_t)dir * (ptrdiff_t)plane_bytes;
+        const float *tnext = tgt + (ptrdiff_t)(zf + dir) * H * W;    // target plane of the next step
+        const char *dnext = plane_ptr(pbase + dir * TRX_ZS_LEAD);     // ring plane TRX_ZS_LEAD steps ahead ...
+        int dslot = pmod(pbase + dir * TRX_ZS_LEAD);                  // ... and its slot
         auto step = [&](int s, float (&use)[R], float (&load)[R]) {
 #if TRX_ZS_STAMP
             const unsigned long long st0 = __builtin_amdgcn_s_memtime();
@@ -502,15 +526,16 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
 #if TRX_ZS_STAMP
                 st2 = __builtin_amdgcn_s_memtime();
 #endif
-                advance_tables();
+                if (down) retreat_tables(); else advance_tables();
             }
 #pragma unroll
             for (int j = 0; j < R; j++) asm volatile("" : "+v"(use[j]));
-            if (s + 1 <= last) { issue_targets(tnext, load); tnext += (size_t)H * W; }
+            if (s + 1 <= last) { issue_targets(tnext, load); tnext += tstep; }
             if (s + TRX_ZS_LEAD <= last) {
-                issue_plane(pbase + s + TRX_ZS_LEAD, dslot, dnext);
-                dnext += plane_bytes;
-                dslot = (dslot + 1 == C::NZ) ? 0 : dslot + 1;
+                issue_plane(pbase + dir * (s + TRX_ZS_LEAD), dslot, dnext);
+                dnext += dstep;
+                dslot += dir;
+                dslot = (dslot == C::NZ) ? 0 : (dslot < 0 ? C::NZ - 1 : dslot);
             }
 #if TRX_ZS_STAMP
             const unsigned long long st3 = __builtin_amdgcn_s_memtime();
@@ -526,11 +551,15 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
 #pragma unroll
         for (int j = 0; j < R; j++) tvA[j] = tvB[j] = 0.f;
         load_ztab(0);
-        set_tables(pbase - (C::Span - 1));
+        set_tables(down ? pbase : pbase - (C::Span - 1));
         __syncthreads();   // the ring is zeroed
         // fill the pipeline: the planes steps 0 and 1 touch, the targets of step 0
-        for (int p = pbase - (C::Span - 1); p <= pbase + min(last, TRX_ZS_LEAD - 1); p++) issue_plane(p, pmod(p), plane_ptr(p));
-        issue_targets(tgt + (size_t)zb * H * W, tvA);
+        {
+            const int ahead = min(last, TRX_ZS_LEAD - 1);
+            const int pa = down ? pbase - ahead : pbase - (C::Span - 1), pb = down ? pbase + (C::Span - 1) : pbase + ahead;
+            for (int p = pa; p <= pb; p++) issue_plane(p, pmod(p), plane_ptr(p));
+        }
+        issue_targets(tgt + (size_t)zf * H * W, tvA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int s = 0;
@@ -565,9 +594,10 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
     }
     if constexpr (kGrad) {
         // sum_z zn_z P_z = zn_0 S + d (n S - U): zn_z = zn_0 + d (z - zb0), S = the final running sum, U = sum over planes of the running sums
+        // (in step order: walking down, the first step's plane is the segment's last one and zn falls by the same amount per step)
         const int nall = ze0 - zb0;
-        const float zn0 = ztab[zb0];
-        const float dzn = nall > 1 ? (ztab[ze0 - 1] - zn0) / (float)(nall - 1) : 0.f;
+        const float zn0 = ztab[down ? ze0 - 1 : zb0];
+        const float dzn = nall > 1 ? (ztab[down ? zb0 : ze0 - 1] - zn0) / (float)(nall - 1) : 0.f;
         const float fn = (float)nall;
 #pragma unroll
         for (int q = 0; q < NQ; q++)
