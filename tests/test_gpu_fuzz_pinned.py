@@ -8,6 +8,7 @@ each case is now a fixed regression test that holds the widened bar - and record
    slide sums along x (add the entering column, subtract the leaving one), and the two orders lose different last bits of that
    difference, which the 1 / (var_w var_y) factor of the gradient then amplifies.  The kernel's error is 2.1 x torch's own fp32 error at
    the worst voxel, not a different formula: the fp64 specification is met to 3.1e-4 of the gradient's maximum.  Bar since: 2.5 x.
+   (Round 5: with the x window summed in registers - TRX_LNCC_DIRECT - the same case is at 0.99 x torch's fp32 error.)
 2. tests/fuzz_zstream.py, seed 13, case 111: next to the identity whole bands of voxels sample within fp32 rounding of a lattice plane,
    where trilinear interpolation has a kink (the derivative jumps by up to a voxel value).  The oracle measures that sensitivity on
    itself: its fp64 gradient re-evaluated with the translations nudged by +-1 fp32 ulp of a coordinate (kink_variants).  The kernels'
@@ -32,8 +33,10 @@ def test_lncc_window3_seed51_case231():
     d = det[0]
     assert fails == 0, d
     ratio = d["lncc_grad_err"] / d["lncc_grad_fp32_gap"]
-    # the case needs more than the old factor 2 and must stay inside the new one; absolute: the fp64 specification to 4e-4 of the gradient's maximum
-    assert 1.5 < ratio <= 2.5, (ratio, d)
+    # round 4's kernels (x window by sliding sums over the LDS tile) sat at 2.11 x torch's own fp32 error here - over the factor 2 of that time -;
+    # round 5's direct form (x window summed in registers, windows 3 and 5) sits at 0.99 x.  The case holds the CURRENT bar (2.5 x) and, absolutely,
+    # the fp64 specification to 4e-4 of the gradient's maximum
+    assert ratio <= 2.5, (ratio, d)
     assert d["lncc_grad_err"] <= 4e-4, d
     assert d["lncc_loss_err"] <= d["lncc_loss_bar"], d
 
