@@ -399,13 +399,14 @@ def main():
                 else:
                     traffic_note = (f"profiles/traffic.json (tag {tj.get('tag')}) was measured on another build of libtrx.so "
                                     f"(sha256 {str(tj.get('lib_sha256'))[:12]} != {sha[:12]}): not quoted")
-            out["roofline"] = {"bound": "hbm", "kernel": "affine_tile_dual_kernel<0,0> (fused warp+NCC fwd/bwd; kernel body per pair from theta: "
-                                                         "z-streaming next to the identity, tile geometries further out)",
+            out["roofline"] = {"bound": "hbm", "kernel": "affine_zs_step_kernel<0> (fused warp+NCC fwd/bwd, z-streaming: every pair of this workload; the "
+                                                         "exact-footprint and tile kernels behind it take pairs further from the identity and return at once here)",
                                "achieved": alg / k_s / 1e9,
                                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / k_s / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
                                "kernel_ms": k_s * 1e3, "kernel_ms_first": per_it[0] * 1e3, "kernel_ms_last": per_it[-1] * 1e3,
-                               "kernel_ms_note": f"mean over the {args.steps} timed iterations' poses of the F1 launch at that pose (replica run; events around "
-                                                 f"{REP} back-to-back launches per pose); first / last = the first and last pose",
+                               "kernel_ms_note": f"mean over the {args.steps} timed iterations' poses of the F1 launches of a step at that pose - the z-streaming kernel and "
+                                                 f"the two kernels behind it that find nothing to do - (replica run; events around {REP} back-to-back steps' launches per "
+                                                 "pose, alternating the walk direction as the iterations of a run do); first / last = the first and last pose",
                                "partial_rows_per_pair_last": rows[0],
                                "algorithmic_bytes_per_launch": alg,
                                "l2_requests_per_launch": l2req, "l2_request_bytes": 128}

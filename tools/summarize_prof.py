@@ -34,9 +34,10 @@ for name in ("fetch", "write", "sq", "sqw", "l2"):
                 out.append(f"{k.replace(',', ';')},{c},{sum(x) / len(x):.1f},{len(x)}")
                 res[(k, c)] = sum(x) / len(x)
 open(os.path.join(root, "profiles", f"{tag}_bench_rocprof_summary.csv"), "w").write("\n".join(out) + "\n")
-dom = [k for k in {k for k, _ in res} if "affine_tile" in k or "affine_accum" in k]
+dom = [k for k in {k for k, _ in res} if "affine_tile" in k or "affine_accum" in k or "affine_zs_step" in k]
 if dom:
-    k = max(dom, key=lambda n: ("dual_kernel<0" in n or n.endswith("tile_kernel<0>"), "dual" in n, n))   # the F1 step kernel (MODE 0), not the warp that builds the synthetic inputs
+    # the F1 step kernel (MODE 0), not the warp that builds the synthetic inputs; since round 5 the z-streaming kernel in front of the tile kernel
+    k = max(dom, key=lambda n: ("affine_zs_step_kernel<0" in n, "dual_kernel<0" in n or n.endswith("tile_kernel<0>"), "dual" in n, n))
     fetch, write = res.get((k, "FETCH_SIZE")), res.get((k, "WRITE_SIZE"))
     if fetch is not None and write is not None:
         traffic = 2 * fetch * 1024 + write * 1024

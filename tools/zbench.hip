@@ -51,6 +51,8 @@ int main(int argc, char **argv)
         double M[12];
         if (!strcmp(pose, "inv")) { const double m[12] = {1.0413, 0.1074, -0.0204, -0.0484, -0.1074, 1.0199, 0.0021, 0.0359, 0.0032, -0.0300, 0.9803, -0.0209}; memcpy(M, m, sizeof M); }
         else if (!strcmp(pose, "rz0.1")) { const double m[12] = {cos(0.1), -sin(0.1), 0, 0.01, sin(0.1), cos(0.1), 0, -0.02, 0, 0, 1, 0.015}; memcpy(M, m, sizeof M); }
+        else if (!strcmp(pose, "rz0.2")) { const double m[12] = {cos(0.2), -sin(0.2), 0, 0.01, sin(0.2), cos(0.2), 0, -0.02, 0, 0, 1, 0.015}; memcpy(M, m, sizeof M); }
+        else if (!strcmp(pose, "rz0.3")) { const double m[12] = {cos(0.3), -sin(0.3), 0, 0.01, sin(0.3), cos(0.3), 0, -0.02, 0, 0, 1, 0.015}; memcpy(M, m, sizeof M); }
         else if (!strcmp(pose, "rz0.15")) { const double m[12] = {cos(0.15), -sin(0.15), 0, 0.01, sin(0.15), cos(0.15), 0, -0.02, 0, 0, 1, 0.015}; memcpy(M, m, sizeof M); }
         else { const double m[12] = {0.9975, -0.0474, 0.0524, 0.01, 0.0499, 0.9963, -0.0474, -0.02, -0.05, 0.0499, 0.9975, 0.015}; memcpy(M, m, sizeof M); }   // R(0.05, 0.05, 0.05)
         for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = (float)M[i] + 1e-4f * (2.f * rand() / RAND_MAX - 1.f);

@@ -22,6 +22,12 @@
 #ifndef TRX_EF_STAGES
 #define TRX_EF_STAGES 2   // rows in flight in the gather (3: also the table reads of row j + 2 - measured alternative)
 #endif
+#ifndef TRX_EF_PRIO
+#define TRX_EF_PRIO 0       // 1: the two blocks of a CU alternate at s_setprio 1 in time slices of 2^TRX_EF_PRIO_BIT cycles (development)
+#endif
+#ifndef TRX_EF_PRIO_BIT
+#define TRX_EF_PRIO_BIT 14
+#endif
 #ifndef TRX_EF_ROWSTEP
 #define TRX_EF_ROWSTEP 1   // row terms of the coordinates and yn by stepping from the first row of a call instead of one v_readlane per row and term (0: measured alternative)
 #endif
@@ -213,6 +219,9 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     int *wtot = ilds;                         // (prologue scratch in buffer 0) 16 chunk totals
     int cnt_r[2], wlo_r[2], pre_r[2];
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
+#if TRX_EF_PRIO
+    const int ef_second = (int)((blockIdx.y * gridDim.x + blockIdx.x) * 2 >= gridDim.x * gridDim.y);
+#endif
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int r = tid + h * C::Threads, iy = r & (C::NY - 1), iz = r >> 5;
@@ -530,6 +539,10 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         }
         __syncthreads();
         auto tile_step = [&](int ty, int par, float (&use)[kRows], float &yn_use, float (&load)[kRows], float &yn_load) {
+#if TRX_EF_PRIO
+            // fair sharing of a CU between its two blocks (see TRX_ZS_PRIO in affine_zstream.h): they take turns at the higher priority in time slices
+            if (((__builtin_amdgcn_s_memtime() >> TRX_EF_PRIO_BIT) + ef_second) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
             const bool more = ty + 1 < t1;
             TileOrg nxt = cur;
             if (more) {
@@ -566,6 +579,9 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             }
         }
         target_only(t1, ty_end);
+#if TRX_EF_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     } else {
         // the plan does not fit (dual_choice tests the same numbers, so this is a safety net): every voxel gathers from global memory
         for (int ty = ty_begin; ty < ty_end; ty++) {
