@@ -48,3 +48,12 @@ def test_random_sweep_zstream_body():
     import fuzz_zstream
     fails, worst = fuzz_zstream.run(40, 5, grad_bar=3e-4, verbose=True)
     assert fails == 0, worst
+
+
+def test_random_sweep_chip_filling_launches():
+    """Round 5: launches that fill the chip - the z-streaming kernel in front (both tiles, walking up or down), the exact-footprint kernel and the
+    tile kernel behind it in ONE launch, poses per pair from the identity to general rotations - against the same launch on the tile kernels
+    alone (tests/fuzz_zs_flat.py)."""
+    import fuzz_zs_flat
+    fails, worst = fuzz_zs_flat.run(6, 3, verbose=True)
+    assert fails == 0, worst
