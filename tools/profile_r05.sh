@@ -10,7 +10,7 @@ cd $R
 bash tools/profile_bench.sh > $O/profile_bench.log 2>&1
 python3 tools/summarize_prof.py gpurun_out/prof $1 "$2" > $O/summary.log 2>&1
 bash tools/pmc_pose.sh 0 > $O/pmc_pose.log 2>&1
-{ echo "== affine_eft_step_kernel"; python3 tools/pmc_zsummary.py affine_eft_step gpurun_out 2>/dev/null | grep zpmc_pose; echo "== affine_tile_dual_kernel (skips every pair)"; python3 tools/pmc_zsummary.py affine_tile_dual gpurun_out 2>/dev/null | grep zpmc_pose; } > $O/pose_pmc.txt
+{ echo "== affine_zs_step_kernel (takes no pair at this pose)"; python3 tools/pmc_zsummary.py affine_zs_step gpurun_out 2>/dev/null | grep zpmc_pose; echo "== affine_eft_step_kernel"; python3 tools/pmc_zsummary.py affine_eft_step gpurun_out 2>/dev/null | grep zpmc_pose; echo "== affine_tile_dual_kernel (skips every pair)"; python3 tools/pmc_zsummary.py affine_tile_dual gpurun_out 2>/dev/null | grep zpmc_pose; } > $O/pose_pmc.txt
 bash tools/pmc_flow.sh final adam 1.0 30 > /dev/null 2>&1
 python3 tools/pmc_zsummary.py flow_ gpurun_out 2>/dev/null | grep zpmc_flow_final > $O/flow_pmc.txt
 python3 tools/summarize_traffic.py $1 > $O/traffic_summary.log 2>&1

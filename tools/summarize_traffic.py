@@ -26,9 +26,9 @@ def counters(pattern_dir, kernels):
                     launches[k] = len(v)
     return out, launches
 
-rot, n = counters("zpmc_pose_rot_*", ("affine_eft_step_kernel", "affine_tile_dual_kernel"))
+rot, n = counters("zpmc_pose_rot_*", ("affine_zs_step_kernel", "affine_eft_step_kernel", "affine_tile_dual_kernel"))
 if "FETCH_SIZE" in rot and "WRITE_SIZE" in rot:
-    j = {"what": "one F1 step of 8 x 256^3 at theta = R(0.5,0.4,0.3) diag(1.05,0.95,1.02): affine_eft_step_kernel<0> + affine_tile_dual_kernel<0,0> (which skips every pair)",
+    j = {"what": "one F1 step of 8 x 256^3 at theta = R(0.5,0.4,0.3) diag(1.05,0.95,1.02): affine_zs_step_kernel<0> (takes no pair) + affine_eft_step_kernel<0> + affine_tile_dual_kernel<0,4> (which skips every pair)",
          "FETCH_SIZE_KiB": rot["FETCH_SIZE"], "WRITE_SIZE_KiB": rot["WRITE_SIZE"], "hbm_bytes_per_launch": 2 * rot["FETCH_SIZE"] * 1024 + rot["WRITE_SIZE"] * 1024,
          "algorithmic_bytes_per_launch": 8 * 256 ** 3 * 8, "l2_requests_per_launch": rot.get("TCC_REQ_sum"), "l2_misses_per_launch": rot.get("TCC_MISS_sum"),
          "launches_sampled": n, "tag": tag, "lib_sha256": sha}
