@@ -26,7 +26,8 @@ def counters(pattern_dir, kernels):
                     launches[k] = len(v)
     return out, launches
 
-rot, n = counters("zpmc_pose_rot_*", ("affine_zs_step_kernel", "affine_eft_step_kernel", "affine_tile_dual_kernel"))
+# (the step kernels only - "<0": the one MODE 3 launch of affine_tile_dual_kernel that builds the synthetic moving volumes is not part of a step)
+rot, n = counters("zpmc_pose_rot_*", ("affine_zs_step_kernel<0", "affine_eft_step_kernel<0", "affine_tile_dual_kernel<0"))
 if "FETCH_SIZE" in rot and "WRITE_SIZE" in rot:
     j = {"what": "one F1 step of 8 x 256^3 at theta = R(0.5,0.4,0.3) diag(1.05,0.95,1.02): affine_zs_step_kernel<0> (takes no pair) + affine_eft_step_kernel<0> + affine_tile_dual_kernel<0,4> (which skips every pair)",
          "FETCH_SIZE_KiB": rot["FETCH_SIZE"], "WRITE_SIZE_KiB": rot["WRITE_SIZE"], "hbm_bytes_per_launch": 2 * rot["FETCH_SIZE"] * 1024 + rot["WRITE_SIZE"] * 1024,
