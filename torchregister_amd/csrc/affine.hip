@@ -1164,6 +1164,27 @@ __device__ __forceinline__ int dual_choice(const float *__restrict__ th, float f
 // WHICH = 0: every body in one kernel (3: only GeomA and GeomR, whatever the mode).  WHICH = 1 / 2: only the GeomA / GeomR body - the pair of launches (1 then 2) does the
 // same job with each body compiled on its own (measured alternative: bench.py 0.328 ms per step against 0.323 ms for the two-body
 // kernel and 0.311-0.320 ms for the single-geometry kernel): blocks of a pair that the other geometry owns leave at once.
+#ifndef TRX_EF_RULE
+#define TRX_EF_RULE 1   // 0: round 4's first rule (GeomRD keeps every pair whose rotation is mostly about z)
+#endif
+__device__ __forceinline__ bool eft_wants(int choice, const float *__restrict__ th, float fD, float fH, float fW)
+{
+    if (choice == 2) return true;
+    if (choice != 3) return false;
+    const float tilt = fabsf(th[8] * fD / fW) + fabsf(th[9] * fD / fH);                 // how far the tile's pre-image leans out of its z planes
+    const float zspan = (tilt + fabsf(th[10])) * (float)(ECfg::TZ - 1);
+#ifdef TRX_EF_ZSPAN
+    return zspan > TRX_EF_ZSPAN;   // development
+#endif
+#if TRX_EF_RULE == 0
+    return zspan > 17.0f;
+#else
+    if (zspan > 17.0f || tilt > 0.07f) return true;
+    const float s = fmaxf(fabsf(th[1] * fW / fH), fabsf(th[4] * fH / fW));              // in-plane rotation (its sine, in voxels)
+    return s > 0.15f && s < 0.37f;   // GeomRD's rows are at their longest just past GeomD's window (NaN compares false: GeomRD)
+#endif
+}
+
 // The kernel arguments of affine_tile_dual_kernel as one struct: the kernel reads its arguments THROUGH THE KERNARG SEGMENT at the point
 // of use (a few scalar loads in front of the body that needs them) instead of through its parameters, which the compiler loads at entry
 // and keeps in SGPRs across the dispatch to five inlined bodies: that cost ~60 SGPRs, pushed the bodies' own scalars into VGPR lanes
@@ -1194,11 +1215,16 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     static_assert(GeomRD::BoxAlloc <= GeomR::BoxAlloc, "GeomRD lives in GeomR's box");
     // the step kernels (MODE 0 / 4) of the one-launch form also carry the deep tile for transforms next to the identity
     // WHICH = 4: the same without the z-streaming body - behind affine_zs_step_kernel, which has taken the pairs next to the identity
-    constexpr bool kDeep = (WHICH == 0 || WHICH == 4) && (MODE == 0 || MODE == 4) && (TRX_TILE_CFG == 0) && (TRX_DEEP_TILE != 0);
+    // WHICH = 5: WHICH = 4 plus the exact-footprint body - ONE kernel behind the z-streaming kernel instead of two (a launch boundary and an
+    // empty 512-block dispatch less per step: 4-5 us; inside the five-body kernel of round 4 the same merge cost the z-streaming loop 7-12 %,
+    // which no longer lives here)
+    constexpr bool kDeep = (WHICH == 0 || WHICH == 4 || WHICH == 5) && (MODE == 0 || MODE == 4) && (TRX_TILE_CFG == 0) && (TRX_DEEP_TILE != 0);
     constexpr bool kZs = kDeep && WHICH == 0;
+    constexpr bool kEft = kDeep && WHICH == 5;
     constexpr int kAllocAR = GeomA::BoxAlloc > GeomR::BoxAlloc ? GeomA::BoxAlloc : GeomR::BoxAlloc;
     constexpr int kAllocD = WHICH == 1 ? GeomA::BoxAlloc : (WHICH == 2 ? GeomR::BoxAlloc : ((kDeep && GeomD::BoxAlloc > kAllocAR) ? GeomD::BoxAlloc : kAllocAR));
-    constexpr int kAlloc = (kZs && ZS64::Alloc > kAllocD) ? ZS64::Alloc : kAllocD;
+    constexpr int kAllocZ = (kZs && ZS64::Alloc > kAllocD) ? ZS64::Alloc : kAllocD;
+    constexpr int kAlloc = (kEft && ECfg::Alloc > kAllocZ) ? ECfg::Alloc : kAllocZ;
     __shared__ __attribute__((aligned(16))) float box[kAlloc];
     constexpr bool kPerChannel = (MODE == 2) || (MODE == 3);
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 2 ? 12 : (MODE == 4 ? kNpMse : 5));
@@ -1224,15 +1250,16 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         zs_planes = kZs && nZ > 0 ? a->zg.planes_per_seg : 0;   // (WHICH = 4: the z-streaming test is the kernel's in front - never repeated here, where it could round differently)
         rows_stride = a->rows_stride;
         theta = a->theta;
-        with_ef = kDeep && a->rows_used != nullptr && (((TRX_EFT_BODY != 0) && a->eft != 0) || WHICH == 4);   // pairs with rows_used < 0 belong to a kernel that ran in front
-        if constexpr (WHICH == 4) {   // the kernels in front left the number of pairs they did NOT take: none - the usual case next to the identity - and this launch is over
+        with_ef = kDeep && a->rows_used != nullptr && (((TRX_EFT_BODY != 0) && a->eft != 0) || WHICH == 4 || WHICH == 5);   // pairs with rows_used < 0 belong to a kernel that ran in front
+        if constexpr (WHICH == 4 || WHICH == 5) {   // the kernels in front left the number of pairs they did NOT take: none - the usual case next to the identity - and this launch is over
             const int *plan = a->rows_used + a->vol.B;
             if (__builtin_amdgcn_readfirstlane(*plan) == 0) return;
         }
     }
     // 6 = taken by the exact-footprint kernel (affine_eft_step_kernel, launched IN FRONT of this one: it left rows_used[b] = -(its row
     // count) for the pairs it took - rotated pairs that GeomR would run and whose plan fits its buffers): no block here
-    auto blocks_of = [&](int choice) { return choice == 6 ? 0 : (choice == 4 ? nZ : (choice == 0 ? nD : (choice == 3 ? nRD : (choice == 1 ? nA : nR)))); };
+    // 7 = (WHICH = 5) the exact-footprint body inside this kernel: its 16^3 tiling is GeomRD's
+    auto blocks_of = [&](int choice) { return choice == 6 ? 0 : (choice == 7 ? nRD : (choice == 4 ? nZ : (choice == 0 ? nD : (choice == 3 ? nRD : (choice == 1 ? nA : nR))))); };
     // Work items of this block: (pair / slab `by`, block index v of that pair's geometry).  Classic grid: exactly one, from blockIdx.
     // FLAT grid (rows_stride > 0; the launcher's choice for big batches of the step kernels): gridDim.x persistent blocks share one list
     // of work items - pair 0's blocks, then pair 1's, ... each pair with the block count of the body ITS theta selects - and block p runs
@@ -1256,9 +1283,33 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         int cnt = 0, ch = 2;
         if (lane < B) ch = dual_choice(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, with_d, with_rd, zs_planes);
         if (with_ef && lane < B && rows_used[lane] < 0) ch = 6;   // taken by the exact-footprint kernel, which ran in front of this one
+        if constexpr (kEft) {
+            // the exact-footprint body's pairs (affine_eft_step_kernel's decision, here): those GeomR or (eft_wants) GeomRD would run and whose plan
+            // fits its buffers - counted exactly, one candidate pair per wave and round
+            const float *thl = theta + (size_t)(lane < B ? lane : 0) * TRX_PSTRIDE;
+            const bool cand_l = lane < B && (ch == 2 || ch == 3) && eft_wants(ch, thl, fD, fH, fW) && ef_candidate(thl, fD, fH, fW);
+            const unsigned long long cand = __builtin_amdgcn_ballot_w64(cand_l);
+            if (cand) {   // (block-uniform)
+                if (wave_idx == 0) s_pre[lane] = 0;
+                __syncthreads();
+                unsigned long long rest = cand;
+                for (int k = 0; rest; k++) {
+                    const int pb = __builtin_ctzll(rest);
+                    rest &= rest - 1;
+                    if ((k & 7) != wave_idx) continue;
+                    const EfMap m = ef_map(theta + (size_t)pb * TRX_PSTRIDE, fD, fH, fW);
+                    const EfDims d = ef_dims(m);
+                    const int g = ef_plan_granules_wave(m, d, lane);
+                    if (lane == 0) s_pre[pb] = (d.ok && g > 0 && g <= ECfg::GCap) ? 1 : 0;
+                }
+                __syncthreads();
+                if (cand_l && s_pre[lane] != 0) ch = 7;
+                __syncthreads();   // (s_pre is rewritten below)
+            }
+        }
         if (lane < B) {
             cnt = blocks_of(ch);
-            if (rows_used && blockIdx.x == 0 && wave_idx == 0 && ch != 6) rows_used[lane] = rows_note(cnt, 1 + ch);   // for the step's finalise kernel
+            if (rows_used && blockIdx.x == 0 && wave_idx == 0 && ch != 6) rows_used[lane] = ch == 7 ? -rows_note(cnt, 7) : rows_note(cnt, 1 + ch);   // for the step's finalise kernel
         }
         int pre = cnt;   // inclusive prefix sum over the lanes (pairs)
 #pragma unroll
@@ -1314,6 +1365,14 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
                 const ZGeom zg = {a->zg.ntx, a->zg.nty, a->zg.nzseg, a->zg.planes_per_seg, a->zg.blocks_per_pair};
                 zstream_body<MODE, ZS64>(vol, theta, zg, partials, box, v, by, stride, wave_idx,
                                          (int)((blockIdx.y * gridDim.x + blockIdx.x) * 2 >= gridDim.x * gridDim.y));   // (second half of the grid = the later block of its CU)
+                continue;
+            }
+        }
+        if constexpr (kEft) {
+            if (choice == 7) {   // (columns differ widely in cost: the column index is rotated per pair, by a multiple of 8 - see affine_eft_step_kernel)
+                const TileGeom t = tile_of(&a->tgRD);
+                const int ve = __builtin_amdgcn_readfirstlane((v + 104 * by) % t.blocks_per_pair);
+                eft_body<MODE>(vol, theta, t, partials, box, ve, by, stride, wave_idx);
                 continue;
             }
         }
@@ -1408,27 +1467,6 @@ __global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_ste
         if (!TRX_ZS_FLAT || ((take1 >> pair) & 1ull)) zstream_body<MODE, ZS64>(vol, theta, zg, partials, ring, v, pair, stride, wave, second);
         else zstream_body<MODE, ZSF>(vol, theta, zgf, partials, ring, v, pair, stride, wave, second);
     }
-}
-
-#ifndef TRX_EF_RULE
-#define TRX_EF_RULE 1   // 0: round 4's first rule (GeomRD keeps every pair whose rotation is mostly about z)
-#endif
-__device__ __forceinline__ bool eft_wants(int choice, const float *__restrict__ th, float fD, float fH, float fW)
-{
-    if (choice == 2) return true;
-    if (choice != 3) return false;
-    const float tilt = fabsf(th[8] * fD / fW) + fabsf(th[9] * fD / fH);                 // how far the tile's pre-image leans out of its z planes
-    const float zspan = (tilt + fabsf(th[10])) * (float)(ECfg::TZ - 1);
-#ifdef TRX_EF_ZSPAN
-    return zspan > TRX_EF_ZSPAN;   // development
-#endif
-#if TRX_EF_RULE == 0
-    return zspan > 17.0f;
-#else
-    if (zspan > 17.0f || tilt > 0.07f) return true;
-    const float s = fmaxf(fabsf(th[1] * fW / fH), fabsf(th[4] * fH / fW));              // in-plane rotation (its sine, in voxels)
-    return s > 0.15f && s < 0.37f;   // GeomRD's rows are at their longest just past GeomD's window (NaN compares false: GeomRD)
-#endif
 }
 
 template <int MODE>
@@ -2285,20 +2323,23 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             // flat launches that offer the z-streaming body run it as a kernel of its own, FIRST (affine_zs_step_kernel): it alone evaluates the
             // test, the kernels behind it skip its pairs and return at once when it has taken them all
             const bool zs_first = flat && zg.blocks_per_pair > 0 && ru != nullptr && !(vol->flags & TRX_FLAG_ZS_FUSED);
+            // ... and the exact-footprint body then rides in the tile kernel (WHICH = 5) when its tiling is the one GeomRD is offered with
+            const bool eft_merged = TRX_EFT_MERGED && zs_first && eft != 0 && trd.blocks_per_pair == tef.blocks_per_pair && (MODE == 0 || MODE == 4);
             if constexpr (MODE == 0 || MODE == 4) {
                 if (zs_first) {
                     const ZGeom zgf = (TRX_ZS_FLAT && zs_shape_ok<ZSF>(*vol) && !(vol->flags & TRX_FLAG_NO_ZS_FLAT)) ? zs_geom<ZSF>(*vol) : ZGeom{};
                     hipLaunchKernelGGL((affine_zs_step_kernel<MODE>), dim3(slots, 1), dim3(ZS64::Threads), 0, s, v, theta, zg, zgf, partials, ru, gxx);
                     TRX_CHECK_LAUNCH();
                 }
-                if (eft) {   // in front of the tile kernel: takes its pairs and marks them rows_used < 0 (none - the usual case next to the identity - costs ~3 us, ~1.5 behind the z-streaming kernel)
+                if (eft && !eft_merged) {   // in front of the tile kernel: takes its pairs and marks them rows_used < 0 (none - the usual case next to the identity - costs ~3 us, ~1.5 behind the z-streaming kernel)
                     const int wd = td.blocks_per_pair > 0, wrd = trd.blocks_per_pair > 0, zp = zs_first ? -1 : (zg.blocks_per_pair > 0 ? zg.planes_per_seg : 0);   // (-1: the z-streaming kernel ran in front)
                     if (flat) hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(slots, 1), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, gxx, wd, wrd, zp);
                     else hipLaunchKernelGGL((affine_eft_step_kernel<MODE>), dim3(tef.blocks_per_pair, vol->B), dim3(ECfg::Threads), 0, s, v, theta, tef, partials, ru, -gxx, wd, wrd, zp);
                     TRX_CHECK_LAUNCH();
                 }
             }
-            if (zs_first) hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 4>), dim3(slots, 1), dim3(512), 0, s, v, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gxx, eft);
+            if (eft_merged) hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 5>), dim3(slots, 1), dim3(512), 0, s, v, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gxx, eft);
+            else if (zs_first) hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 4>), dim3(slots, 1), dim3(512), 0, s, v, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gxx, eft);
             else if (flat) launch_dual<MODE>(dim3(slots, 1), s, v, theta, ta, tr, 1, partials, 1, 0, td, trd, zg, ru, gxx, eft);
             else launch_dual<MODE>(dim3(gxx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd, zg, ru, 0, eft);
             TRX_CHECK_LAUNCH();

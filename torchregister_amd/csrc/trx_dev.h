@@ -61,6 +61,11 @@
 #ifndef TRX_EFT_BODY
 #define TRX_EFT_BODY 1   // the step kernels carry the exact-footprint body for rotated pairs (0: GeomR as before - measured alternative)
 #endif
+#ifndef TRX_EFT_MERGED
+#define TRX_EFT_MERGED 0   // 1: behind the z-streaming kernel the exact-footprint body rides in the tile kernel as a fifth body (one kernel and one launch boundary less per
+                           // step) - measured alternative: the headline does not move (30.0-30.4 k against 30.1-30.3 k: the empty launch hides behind the dispatch of the next),
+                           // the rotated poses lose 5.5 % (17.2 against 18.1 k: 43 spilled registers in the merged kernel); profiles/r05a_eft_merged.txt
+#endif
 #ifndef TRX_PERSISTENT_BLOCKS
 #define TRX_PERSISTENT_BLOCKS 512   // block slots for the 512-thread step kernels if the device cannot be queried (MI355X: 2 x 256 CUs); persistent_blocks() asks the device
 #endif
