@@ -102,6 +102,31 @@ int main(int argc, char **argv)
                nan ? "  NaN" : "", got[1], ref[1], got[4], ref[4], got[5], ref[5]);
     }
     rep("exact-footprint 16^3 tiles", time_it([&] { hipLaunchKernelGGL((trx::affine_eft_kernel<0>), dim3(trd.blocks_per_pair, B), dim3(512), 0, 0, vol, theta, trd, partials); }, reps));
+#if TRX_EF_STAMP
+    {   // the flat step kernel once more, then its stamps: phases of a tile step per wave (cycles), blocks' start / end (100 MHz), blocks per CU
+        auto ef_flat = [&] { hipLaunchKernelGGL((trx::affine_eft_step_kernel<0>), dim3(512, 1), dim3(512), 0, 0, vol, theta, trd, partials, ru, gx, 1, 1, 0); };
+        rep("EF step kernel, flat grid (stamped)", time_it(ef_flat, reps));
+        std::vector<unsigned long long> st(1024 * 8 * 8);
+        CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(trx::trx_ef_stamps), st.size() * 8));
+        double sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int nb = 0;
+        for (int b = 0; b < 1024; b++) {
+            if (st[(size_t)b * 64 + 4] == 0) continue;
+            nb++;
+            for (int w = 0; w < 8; w++) {
+                const unsigned long long *o = &st[((size_t)b * 8 + w) * 8];
+                for (int k = 0; k < 4; k++) sum[k] += (double)o[k];
+                sum[4] += (double)(o[4] & 0xffffffffull); sum[8] += (double)(o[4] >> 32);
+                sum[5] += (double)(o[5] & 0xffff);
+                sum[6] += (double)o[6]; sum[7] += (double)o[7];
+            }
+        }
+        const double nw = nb * 8.0;
+        printf("   stamps of %d items (s_memtime ticks, mean over their waves): %.1f tiles in the walk; per tile: issue %.0f  gather %.0f  wait+barrier %.0f = %.0f\n", nb, sum[5] / nw,
+               sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], (sum[0] + sum[1] + sum[2]) / sum[5]);
+        printf("   an item: plan done at %.0f, first tile landed at %.0f, walk done at %.0f, tail (tiles outside the volume) done at %.0f, sums stored at %.0f\n", sum[3] / nw, sum[6] / nw, sum[7] / nw, sum[4] / nw, sum[8] / nw);
+    }
+#endif
     if (only) return 0;
     rep("tile kernels, classic grid", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, trx::ZGeom{}, ru, 0); }, reps));
     rep("tile kernels, flat grid 512", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0>), dim3(512, 1), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials, 0, td, trd, trx::ZGeom{}, ru, gx); }, reps));

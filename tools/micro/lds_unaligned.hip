@@ -44,6 +44,13 @@ static void run(const char *name, int stride_dw, int blocks)
     const int iters = 2000;
     hipLaunchKernelGGL((k<KIND>), dim3(blocks), dim3(512), 0, 0, out, tk, iters, stride_dw);
     hipDeviceSynchronize();
+    hipEvent_t e0, e1;   // wall clock (round 5: a stamp of thread 0 times the oldest wave only, which the arbiter favours)
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; r++) hipLaunchKernelGGL((k<KIND>), dim3(blocks), dim3(512), 0, 0, out, tk, iters, stride_dw);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double wall_cyc = ms / 5 * 1e-3 * 2.4e9;
     std::vector<float> h(1024); std::vector<unsigned long long> t(blocks);
     hipMemcpy(h.data(), out, 1024 * 4, hipMemcpyDeviceToHost);
     hipMemcpy(t.data(), tk, blocks * 8, hipMemcpyDeviceToHost);
@@ -58,7 +65,7 @@ static void run(const char *name, int stride_dw, int blocks)
     s /= blocks;
     // per CU: blocks/256 blocks x 8 waves x iters x 8 reads
     const double reads_per_cu = (double)(blocks / 256) * 8 * iters * 8;
-    printf("%-34s lane stride %d dw, %d blocks/CU: %s, %.2f LDS cycles per wave-instruction per CU\n", name, stride_dw, blocks / 256, bad ? "WRONG DATA" : "data ok", s / reads_per_cu);
+    printf("%-34s lane stride %d dw, %d blocks/CU: %s, %.2f (stamps of thread 0) / %.2f (wall clock at 2.4 GHz) LDS cycles per wave-instruction per CU\n", name, stride_dw, blocks / 256, bad ? "WRONG DATA" : "data ok", s / reads_per_cu, wall_cyc / reads_per_cu);
     hipFree(out); hipFree(tk);
 }
 

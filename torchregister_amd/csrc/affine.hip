@@ -1372,7 +1372,8 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
             if (choice == 7) {   // (columns differ widely in cost: the column index is rotated per pair, by a multiple of 8 - see affine_eft_step_kernel)
                 const TileGeom t = tile_of(&a->tgRD);
                 const int ve = __builtin_amdgcn_readfirstlane((v + 104 * by) % t.blocks_per_pair);
-                eft_body<MODE>(vol, theta, t, partials, box, ve, by, stride, wave_idx);
+                EfPlanRegs pr;
+                eft_body<MODE>(vol, theta, t, partials, box, ve, by, stride, wave_idx, pr, true);
                 continue;
             }
         }
@@ -1557,17 +1558,31 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
     // A block's items (pair-major index blockIdx + k gridDim) would be the SAME column in pair after pair - and columns differ widely in
     // cost (those that leave the source volume early are cheap): the column index is rotated per pair (by a multiple of 8: blocks b, b + 8,
     // ... still share an XCD's L2 with the neighbouring columns), which evens the blocks' loads without any shared counter.
-    const int it0 = flat ? (int)blockIdx.x : 0, it_step = flat ? (int)gridDim.x : 1;
-    for (int item = __builtin_amdgcn_readfirstlane(it0); item < total; item += it_step) {
+    // TRX_EF_CHUNK (round 5, measured alternative, off - see affine_eft.h): a block takes `ipb` CONSECUTIVE items of the pair-major list instead of every
+    // gridDim-th one, i.e. (when the pairs' item counts are multiples of ipb) items of ONE pair, whose plan it then makes once (eft_body's `replan`).
+    // Block jb of a pair (XCD jb & 7) takes the columns (jb & 7) + 8 (s nblk / 8 + jb / 8), s = 0 .. ipb - 1, of its XCD's slab.
+    const int ipb = __builtin_amdgcn_readfirstlane(flat ? (TRX_EF_CHUNK ? (total + (int)gridDim.x - 1) / (int)gridDim.x : 1) : 1);
+    const int it0 = flat ? (TRX_EF_CHUNK ? (int)blockIdx.x * ipb : (int)blockIdx.x) : 0, it_step = flat ? (TRX_EF_CHUNK ? 1 : (int)gridDim.x) : 1;
+    const int it_end = flat ? (TRX_EF_CHUNK ? min(total, it0 + ipb) : total) : 1;
+    EfPlanRegs pr;
+    int planned = -1;   // the pair the registers and the row table in LDS belong to
+    for (int item = __builtin_amdgcn_readfirstlane(it0); item < it_end; item += it_step) {
         int v = blockIdx.x, pair = blockIdx.y;   // classic grid: the one item of this block
         if (flat) {
             pair = __builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= item));
             const int off = pair > 0 ? __builtin_amdgcn_readlane(pre, pair - 1) : 0;
-            v = (item - off + 104 * pair) % tg.blocks_per_pair;
+            if (TRX_EF_CHUNK) {
+                const int idx = item - off, nblk = tg.blocks_per_pair / ipb;
+                if (nblk * ipb == tg.blocks_per_pair && (nblk & 7) == 0 && (off % ipb) == 0) {
+                    const int jb = idx / ipb, sidx = idx - jb * ipb;
+                    v = (jb & 7) + 8 * (sidx * (nblk >> 3) + (jb >> 3));
+                } else v = idx;
+            } else v = (item - off + 104 * pair) % tg.blocks_per_pair;
         }
         v = __builtin_amdgcn_readfirstlane(v); pair = __builtin_amdgcn_readfirstlane(pair);
         if (item != it0) __syncthreads();   // the previous item's reduction scratch aliases the buffers
-        eft_body<MODE>(vol, theta, tg, partials, lds, v, pair, rows_stride, wave);
+        eft_body<MODE>(vol, theta, tg, partials, lds, v, pair, rows_stride, wave, pr, pair != planned);
+        planned = pair;
     }
 }
 

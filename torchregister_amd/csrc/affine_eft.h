@@ -22,14 +22,35 @@
 #ifndef TRX_EF_STAGES
 #define TRX_EF_STAGES 2   // rows in flight in the gather (3: also the table reads of row j + 2 - measured alternative)
 #endif
+#ifndef TRX_EF_STAMP
+#define TRX_EF_STAMP 0   // development (tools/ebench.hip): per-wave s_memtime sums of a tile step's phases and the block's start / end -> trx_ef_stamps
+#endif
+#if TRX_EF_STAMP
+__device__ unsigned long long trx_ef_stamps[1024 * 8 * 8];   // [item][wave][issue, gather, wait (sums over the tiles), plan done, tail done | all done << 32, tiles | hwid << 16 | xcc << 32, first tile landed, walk done] in s_memtime ticks since the item began
+#endif
 #ifndef TRX_EF_PRIO
 #define TRX_EF_PRIO 0       // 1: the two blocks of a CU alternate at s_setprio 1 in time slices of 2^TRX_EF_PRIO_BIT cycles (development)
 #endif
 #ifndef TRX_EF_PRIO_BIT
 #define TRX_EF_PRIO_BIT 14
 #endif
+#ifndef TRX_EF_CHUNK
+#define TRX_EF_CHUNK 0   // 1: flat grid of the step kernel: a block's items are consecutive (one pair, ONE plan for all of them) instead of every gridDim-th one - measured
+                         // alternative (profiles/r05c_eft_item_timeline.txt): the plan is made once instead of four times (an item's plan is done after 11.5 k ticks
+                         // instead of 19.7 k) and the launch is 12 % SLOWER: an XCD then holds 8 columns of each of 8 pairs instead of whole 32-column slabs of 2
+                         // pairs, and a tile step takes 10.4 k ticks instead of 8.8 k
+#endif
+#ifndef TRX_EF_ISSUE_PRIO
+#define TRX_EF_ISSUE_PRIO 0   // s_setprio of a wave while it requests the next tile (the stamps of tools/ebench.hip: 3 500 of a tile step's 8 900 cycles pass there) - development
+#endif
 #ifndef TRX_EF_ROWSTEP
 #define TRX_EF_ROWSTEP 1   // row terms of the coordinates and yn by stepping from the first row of a call instead of one v_readlane per row and term (0: measured alternative)
+#endif
+#ifndef TRX_EF_V2
+#define TRX_EF_V2 1   // round 5, by the price list of profiles/r05a_mfma_coissue_and_op_costs.txt (with TRX_EF_ROWSTEP): the row table in BYTES, so that the four data
+                      // addresses of a voxel are plain v_add_u32 (2.6 cycles) instead of v_add_lshl_u32 (5.0), and (x, y) stepped per row by one v_pk_add with a
+                      // scalar pair instead of two adds with scalar operands.  (The z-streaming body's lerp + accumulate, also tried here: 22 packed
+                      // instructions per voxel against this body's 17.5 - it has no v_mov to save - measured in profiles/r05c_eft_v2.txt.)
 #endif
 #ifndef TRX_EF_EPS
 #define TRX_EF_EPS 0.05f   // slack of every window bound: fp32 rounding of the coordinates + non-uniformity of ATen's coordinate tables
@@ -153,9 +174,16 @@ typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+// What a thread keeps of a plan between the items of one block (round 5): the plan depends on theta alone, so a block whose consecutive items
+// belong to the same pair makes it once (`replan` = false: the row table in LDS and these registers are still those of the pair).
+struct EfPlanRegs {
+    int G, ok;
+    int geo[ECfg::K];
+    unsigned goff[ECfg::K];
+};
 template <int MODE>
 __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__restrict__ theta, const TileGeom &tg, float *__restrict__ partials,
-                                         float *lds, const int bx, const int by, const int rows_stride, const int wave_in)
+                                         float *lds, const int bx, const int by, const int rows_stride, const int wave_in, EfPlanRegs &pr, const bool replan)
 {
     static_assert(MODE == 0 || MODE == 1 || MODE == 4, "step kernels and the moments pass");
     using C = ECfg;
@@ -163,6 +191,8 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     constexpr int NP = (MODE == 0) ? np_full(3) : (MODE == 4 ? kNpMse : 5);
     constexpr bool kGrad = MODE != 1;
     constexpr int kRows = C::Rows, K = C::K;
+    constexpr bool kV2 = (TRX_EF_V2 != 0) && (TRX_EF_ROWSTEP != 0);
+    constexpr int kTabShift = kV2 ? 2 : 0;   // the row table holds byte offsets (V2) or dword indices
     const int b = by;
     const int D = vol.D, H = vol.H, W = vol.W;
     const float *__restrict__ th = uni_ptr(theta + (size_t)b * TRX_PSTRIDE);
@@ -217,11 +247,19 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     int *tab = ilds + 2 * C::BufFloats;
     int *desc = ilds + C::BufFloats;          // (prologue scratch in buffer 1) granule slot -> packed (iz, iy, x - xmin)
     int *wtot = ilds;                         // (prologue scratch in buffer 0) 16 chunk totals
-    int cnt_r[2], wlo_r[2], pre_r[2];
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
+#if TRX_EF_STAMP
+    unsigned long long ef_stamp[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long ef_t0 = __builtin_amdgcn_s_memtime();
+#endif
 #if TRX_EF_PRIO
     const int ef_second = (int)((blockIdx.y * gridDim.x + blockIdx.x) * 2 >= gridDim.x * gridDim.y);
 #endif
+    int w4_s, hw4_s;   // row / plane pitch of the volume in bytes, pinned in SGPRs (v_mad_u32_u24 operands)
+    asm("s_mov_b32 %0, %1" : "=s"(w4_s) : "s"(W * 4));
+    asm("s_mov_b32 %0, %1" : "=s"(hw4_s) : "s"(H * W * 4));
+    if (replan) {   // (block-uniform)
+    int cnt_r[2], wlo_r[2], pre_r[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int r = tid + h * C::Threads, iy = r & (C::NY - 1), iz = r >> 5;
@@ -258,23 +296,19 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         for (int h = 0; h < 2; h++) {
             const int r = tid + h * C::Threads, iy = r & (C::NY - 1), iz = r >> 5;
             // E = dword index of (x = 0) of this row inside a buffer; rows nobody touches point at granule 0 (never read)
-            tab[iz * C::TP + iy] = pre_r[h] * 4 - wlo_r[h];
+            tab[iz * C::TP + iy] = (pre_r[h] * 4 - wlo_r[h]) * (1 << kTabShift);
             for (int k = 0; k < cnt_r[h]; k++) desc[pre_r[h] + k] = (iz << 20) | (iy << 12) | ((wlo_r[h] + 4 * k - dm.xmin) << 2);
         }
     }
     __syncthreads();
     // this thread's granules: slot g = tid + 512 k; geo = (iz << 20) | (iy << 12) | ((x - xmin) << 2): row of the plan and x offset (bytes) from
     // its corner (one register per granule; the byte offset inside the volume is re-formed per tile: iz (H W 4) + iy (W 4) + x 4)
-    int geo[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int g = tid + k * C::Threads;
-        geo[k] = (plan_ok && g < G) ? desc[g] : 0;
+        pr.geo[k] = (plan_ok && g < G) ? desc[g] : 0;
     }
     // (the DMA staging needs no vector registers for the data, so the byte offsets are kept per granule instead of being re-formed per tile)
-    int w4_s, hw4_s;   // row / plane pitch of the volume in bytes, pinned in SGPRs (v_mad_u32_u24 operands)
-    asm("s_mov_b32 %0, %1" : "=s"(w4_s) : "s"(W * 4));
-    asm("s_mov_b32 %0, %1" : "=s"(hw4_s) : "s"(H * W * 4));
     auto goff_of = [&](int pk) -> unsigned {
         unsigned t0, t1, t2;
         asm("v_and_b32 %0, 0xffc, %1" : "=v"(t0) : "v"(pk));
@@ -284,10 +318,18 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t0) : "v"(t1), "s"(hw4_s), "v"(t2));
         return t0;
     };
-    unsigned goff[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) goff[k] = goff_of(geo[k]);
+    for (int k = 0; k < K; k++) pr.goff[k] = goff_of(pr.geo[k]);
+    pr.G = G; pr.ok = plan_ok ? 1 : 0;
     __syncthreads();   // desc (buffer 1) is consumed
+    }
+    const int G = __builtin_amdgcn_readfirstlane(pr.G);
+    const bool plan_ok = __builtin_amdgcn_readfirstlane(pr.ok) != 0;
+    const int (&geo)[K] = pr.geo;
+    const unsigned (&goff)[K] = pr.goff;
+#if TRX_EF_STAMP
+    ef_stamp[3] = __builtin_amdgcn_s_memtime() - ef_t0;
+#endif
 
     F1Acc acc;
 #pragma unroll
@@ -406,6 +448,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         // per-row steps of the row terms (wave-uniform): yn advances by dyn per row, the un-normalised y by H / 2 * dyn (= 1 up to rounding)
         const float dyn_s = uni(H > 1 ? ytab[1] - ytab[0] : 0.f);
         const float dpx_s = uni(sx * dyn_s), dpy_s = uni((hH + sy) * dyn_s), dpz_s = uni(sz * dyn_s);
+        const unsigned long long dxy2 = sgpr_pair(dpx_s, dpy_s);   // (V2) per-row step of (x, y)
 #endif
         // ---- gather of rows [ja, jb) of tile `ty` from buffer `buf`
         auto gather_rows = [&](int ty, const TileOrg &o, int buf, float yn_l, float (&tv)[kRows], int ja, int jb, bool more) {
@@ -421,7 +464,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             const int tab_s = (int)lds0 + 2 * C::BufFloats * 4;
             int tp_s, bufdw_s;   // table pitch and the buffer's dword index inside the LDS array, pinned in SGPRs
             asm("s_mov_b32 %0, %1" : "=s"(tp_s) : "i"(C::TP));
-            asm("s_mov_b32 %0, %1" : "=s"(bufdw_s) : "s"((int)(lds0 >> 2) + buf * C::BufFloats));
+            asm("s_mov_b32 %0, %1" : "=s"(bufdw_s) : "s"(kV2 ? (int)lds0 + buf * C::BufFloats * 4 : (int)(lds0 >> 2) + buf * C::BufFloats));   // (V2: in bytes)
             struct S1 { int e00, e01, e10, e11, xi; float fx, fy, fz; };
             struct S2 { f2 r00, r01, r10, r11; float fx, fy, fz; };
 #if TRX_EF_ROWSTEP
@@ -431,9 +474,17 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             // sample sits on the lattice by construction.  Per voxel: three adds instead of three v_readlane (4.5 cycles each) + three adds.
             float ixr = bxt + lane_bcast(px_l, ja), iyr = byt + lane_bcast(py_l, ja), izr = bzt + lane_bcast(pz_l, ja);
             float ynr = lane_bcast(yn_l, ja);
+            f2 xyr = {ixr, iyr};   // (V2)
             auto stage1 = [&](int j) -> S1 {
-                const float ix = ixr, iy = iyr, iz = izr;
-                ixr += dpx_s; iyr += dpy_s; izr += dpz_s;
+                float ix, iy, iz = izr;
+                if constexpr (kV2) {
+                    ix = xyr.x; iy = xyr.y;
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(xyr) : "v"(xyr), "s"(dxy2));
+                } else {
+                    ix = ixr; iy = iyr;
+                    ixr += dpx_s; iyr += dpy_s;
+                }
+                izr += dpz_s;
 #else
             auto stage1 = [&](int j) -> S1 {
                 const float ix = bxt + lane_bcast(px_l, j), iy = byt + lane_bcast(py_l, j), iz = bzt + lane_bcast(pz_l, j);
@@ -444,16 +495,24 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
                 S1 s;
                 const i2u ea = *(lds_i2)(unsigned)ta, eb = *(lds_i2)(unsigned)(ta + C::TP * 4);
                 s.e00 = ea.x; s.e01 = ea.y; s.e10 = eb.x; s.e11 = eb.y;
-                asm("v_add_u32 %0, %1, %2" : "=v"(s.xi) : "s"(bufdw_s), "v"(floor_to_int(ix)));   // dword index of x inside this buffer, before the row's E
+                if constexpr (kV2) asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(s.xi) : "v"(floor_to_int(ix)), "s"(bufdw_s));   // byte address of x inside this buffer, before the row's E
+                else asm("v_add_u32 %0, %1, %2" : "=v"(s.xi) : "s"(bufdw_s), "v"(floor_to_int(ix)));   // dword index of x inside this buffer, before the row's E
                 s.fx = __builtin_amdgcn_fractf(ix); s.fy = __builtin_amdgcn_fractf(iy); s.fz = __builtin_amdgcn_fractf(iz);
                 return s;
             };
             auto stage2 = [&](const S1 &s) -> S2 {
                 int a00, a01, a10, a11;
-                asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a00) : "v"(s.xi), "v"(s.e00));
-                asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a01) : "v"(s.xi), "v"(s.e01));
-                asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a10) : "v"(s.xi), "v"(s.e10));
-                asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a11) : "v"(s.xi), "v"(s.e11));
+                if constexpr (kV2) {
+                    asm("v_add_u32 %0, %1, %2" : "=v"(a00) : "v"(s.xi), "v"(s.e00));
+                    asm("v_add_u32 %0, %1, %2" : "=v"(a01) : "v"(s.xi), "v"(s.e01));
+                    asm("v_add_u32 %0, %1, %2" : "=v"(a10) : "v"(s.xi), "v"(s.e10));
+                    asm("v_add_u32 %0, %1, %2" : "=v"(a11) : "v"(s.xi), "v"(s.e11));
+                } else {
+                    asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a00) : "v"(s.xi), "v"(s.e00));
+                    asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a01) : "v"(s.xi), "v"(s.e01));
+                    asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a10) : "v"(s.xi), "v"(s.e10));
+                    asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a11) : "v"(s.xi), "v"(s.e11));
+                }
                 S2 f;
                 f.r00 = *(lds_f2)(unsigned)a00; f.r01 = *(lds_f2)(unsigned)a01;
                 f.r10 = *(lds_f2)(unsigned)a10; f.r11 = *(lds_f2)(unsigned)a11;
@@ -538,10 +597,16 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             asm volatile("" : "+v"(ynA));
         }
         __syncthreads();
+#if TRX_EF_STAMP
+        const unsigned long long ef_first = __builtin_amdgcn_s_memtime() - ef_t0;
+#endif
         auto tile_step = [&](int ty, int par, float (&use)[kRows], float &yn_use, float (&load)[kRows], float &yn_load) {
 #if TRX_EF_PRIO
             // fair sharing of a CU between its two blocks (see TRX_ZS_PRIO in affine_zstream.h): they take turns at the higher priority in time slices
             if (((__builtin_amdgcn_s_memtime() >> TRX_EF_PRIO_BIT) + ef_second) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+#if TRX_EF_STAMP
+            const unsigned long long es0 = __builtin_amdgcn_s_memtime();
 #endif
             const bool more = ty + 1 < t1;
             TileOrg nxt = cur;
@@ -552,13 +617,25 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
                     __syncthreads();
                 }
                 nxt = tile_org(ty + 1);
+#if TRX_EF_ISSUE_PRIO
+                __builtin_amdgcn_s_setprio(TRX_EF_ISSUE_PRIO);
+#endif
                 issue_yn(ty + 1, yn_load);
 #pragma unroll
                 for (int j = 0; j < kRows; j++) issue_target(ty + 1, j, load[j]);
                 issue_tile(nxt, par ^ 1);
+#if TRX_EF_ISSUE_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
+#if TRX_EF_STAMP
+            const unsigned long long es1 = __builtin_amdgcn_s_memtime();
+#endif
             gather_rows(ty, cur, par, yn_use, use, 0, kRows / 2, false);
             gather_rows(ty, cur, par, yn_use, use, kRows / 2, kRows, false);
+#if TRX_EF_STAMP
+            const unsigned long long es2 = __builtin_amdgcn_s_memtime();
+#endif
             if (more) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -567,6 +644,10 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             }
             cur = nxt;
             __syncthreads();
+#if TRX_EF_STAMP
+            const unsigned long long es3 = __builtin_amdgcn_s_memtime();
+            ef_stamp[0] += es1 - es0; ef_stamp[1] += es2 - es1; ef_stamp[2] += es3 - es2; ef_stamp[5] += 1;
+#endif
         };
         {
             int ty = t0;
@@ -578,7 +659,17 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
                 ty++;
             }
         }
+#if TRX_EF_STAMP
+        const unsigned long long ef_walk = __builtin_amdgcn_s_memtime() - ef_t0;
+#endif
         target_only(t1, ty_end);
+#if TRX_EF_STAMP
+        ef_stamp[4] = __builtin_amdgcn_s_memtime() - ef_t0;   // (tail done)
+        if (trx_lane_id() == 0) {
+            unsigned long long *o = trx_ef_stamps + ((size_t)((by * rows_stride + bx) & 1023) * 8 + wave) * 8;
+            o[6] = ef_first; o[7] = ef_walk;
+        }
+#endif
 #if TRX_EF_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -628,6 +719,17 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             }
     }
     block_reduce_store_nw<NP, C::Waves>(vals, partials + ((size_t)by * rows_stride + bx) * NP, lds, wave);
+#if TRX_EF_STAMP
+    if (trx_lane_id() == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *o = trx_ef_stamps + ((size_t)((by * rows_stride + bx) & 1023) * 8 + wave) * 8;
+        for (int k = 0; k < 4; k++) o[k] = ef_stamp[k];
+        o[4] = (ef_stamp[4] & 0xffffffffull) | ((__builtin_amdgcn_s_memtime() - ef_t0) << 32);   // tail done | all done
+        o[5] = ef_stamp[5] | ((unsigned long long)(hwid & 0xffff) << 16) | ((unsigned long long)(xcc & 0xf) << 32);
+    }
+#endif
 }
 
 // stand-alone kernel (tools/ebench.hip; the library runs the body inside affine_tile_dual_kernel)
@@ -636,6 +738,7 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_kernel(trx_volume
 {
     __shared__ __attribute__((aligned(16))) float lds[ECfg::Alloc];
     if ((int)blockIdx.x >= tg.blocks_per_pair) return;
-    eft_body<MODE>(vol, theta, tg, partials, lds, blockIdx.x, blockIdx.y, gridDim.x, trx_wave_index());
+    EfPlanRegs pr;
+    eft_body<MODE>(vol, theta, tg, partials, lds, blockIdx.x, blockIdx.y, gridDim.x, trx_wave_index(), pr, true);
 }
 #pragma clang diagnostic pop
