@@ -1,6 +1,8 @@
+#!/usr/bin/env python3
+"""Extension of eft_lds_banks.py: LDS cycles of the exact-footprint gather for wave shapes with a y extent (x * y * z lanes; VERDICT r4 item 4 ii).  CPU model."""
 import itertools, os, sys
 import numpy as np
-sys.path.insert(0, '/root/repo/tools')
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from eft_plan_check import plan, rot
 from eft_lds_banks import cycles32, packed, box
 
