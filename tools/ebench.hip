@@ -124,6 +124,14 @@ int main(int argc, char **argv)
         const double nw = nb * 8.0;
         printf("   stamps of %d items (s_memtime ticks, mean over their waves): %.1f tiles in the walk; per tile: issue %.0f  gather %.0f  wait+barrier %.0f = %.0f\n", nb, sum[5] / nw,
                sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], (sum[0] + sum[1] + sum[2]) / sum[5]);
+        {
+            std::vector<unsigned long long> s2(1024 * 8 * 8);
+            CK(hipMemcpyFromSymbol(s2.data(), HIP_SYMBOL(trx::trx_ef_stamps2), s2.size() * 8));
+            double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < 1024; b++) { if (st[(size_t)b * 64 + 4] == 0) continue; for (int w = 0; w < 8; w++) for (int k = 0; k < 8; k++) m[k] += (double)s2[((size_t)b * 8 + w) * 8 + k]; }
+            printf("   the prologue: windows + wave scans %.0f, barrier %.0f, totals + barrier %.0f, table + descriptors + barrier %.0f, granule registers + barrier %.0f | origins + barrier %.0f, head tiles %.0f, first tile requested %.0f\n",
+                   m[0] / nw, m[1] / nw, m[2] / nw, m[3] / nw, m[4] / nw, m[5] / nw, m[6] / nw, m[7] / nw);
+        }
         printf("   an item: plan done at %.0f, first tile landed at %.0f, walk done at %.0f, tail (tiles outside the volume) done at %.0f, sums stored at %.0f\n", sum[3] / nw, sum[6] / nw, sum[7] / nw, sum[4] / nw, sum[8] / nw);
     }
 #endif

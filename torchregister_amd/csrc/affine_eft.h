@@ -26,7 +26,12 @@
 #define TRX_EF_STAMP 0   // development (tools/ebench.hip): per-wave s_memtime sums of a tile step's phases and the block's start / end -> trx_ef_stamps
 #endif
 #if TRX_EF_STAMP
+__device__ unsigned long long trx_ef_stamps2[1024 * 8 * 8];   // the prologue in detail: windows + wave scans, barrier, totals + barrier, table + descriptors + barrier, granule registers + barrier, origins + barrier, head tiles, first tile requested
+#define TRX_EF_ST2(k) do { if (trx_lane_id() == 0) trx_ef_stamps2[((size_t)((by * rows_stride + bx) & 1023) * 8 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime() - ef_t0; } while (0)
 __device__ unsigned long long trx_ef_stamps[1024 * 8 * 8];   // [item][wave][issue, gather, wait (sums over the tiles), plan done, tail done | all done << 32, tiles | hwid << 16 | xcc << 32, first tile landed, walk done] in s_memtime ticks since the item began
+#endif
+#if !TRX_EF_STAMP
+#define TRX_EF_ST2(k) do { } while (0)
 #endif
 #ifndef TRX_EF_PRIO
 #define TRX_EF_PRIO 0       // 1: the two blocks of a CU alternate at s_setprio 1 in time slices of 2^TRX_EF_PRIO_BIT cycles (development)
@@ -274,7 +279,9 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         pre_r[h] = p;
         if (lane == 63) wtot[h * C::Waves + wave] = p;
     }
+    TRX_EF_ST2(0);
     __syncthreads();
+    TRX_EF_ST2(1);
     int G = 0;
     {
         int before[2] = {0, 0};
@@ -291,6 +298,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     G = __builtin_amdgcn_readfirstlane(G);
     const bool plan_ok = dm.ok && G <= C::GCap && G > 0;
     __syncthreads();   // wtot is read; buffer 0 may be written from here on
+    TRX_EF_ST2(2);
     if (plan_ok) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -301,6 +309,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         }
     }
     __syncthreads();
+    TRX_EF_ST2(3);
     // this thread's granules: slot g = tid + 512 k; geo = (iz << 20) | (iy << 12) | ((x - xmin) << 2): row of the plan and x offset (bytes) from
     // its corner (one register per granule; the byte offset inside the volume is re-formed per tile: iz (H W 4) + iy (W 4) + x 4)
 #pragma unroll
@@ -322,6 +331,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     for (int k = 0; k < K; k++) pr.goff[k] = goff_of(pr.geo[k]);
     pr.G = G; pr.ok = plan_ok ? 1 : 0;
     __syncthreads();   // desc (buffer 1) is consumed
+    TRX_EF_ST2(4);
     }
     const int G = __builtin_amdgcn_readfirstlane(pr.G);
     const bool plan_ok = __builtin_amdgcn_readfirstlane(pr.ok) != 0;
@@ -564,6 +574,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         // taken out of the pipelined walk: [ty_begin, t0) and [t1, ty_end) run the plain loop below, [t0, t1) the walk.
         lane_origins(ty_begin);
         __syncthreads();
+        TRX_EF_ST2(5);
         int t0 = ty_begin, t1 = ty_end;
         while (t0 < ty_end && tile_org(t0).outside) t0++;
         while (t1 > t0 && tile_org(t1 - 1).outside) t1--;
@@ -578,6 +589,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             }
         };
         target_only(ty_begin, t0);
+        TRX_EF_ST2(6);
         // Vector-memory operations of a wave per tile, in program order:  YN' T'0 .. T'7 D0 .. D4  (' = of the next tile; T = the targets, into
         // the OTHER of two register sets, D = the DMA pieces): everything a tile needs is requested at the START of the tile before it, so the
         // one wait per tile finds it landed.  (Refilling the targets in place, row by row, left the last target load a few hundred cycles
@@ -591,6 +603,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
 #pragma unroll
             for (int j = 0; j < kRows; j++) issue_target(t0, j, tvA[j]);
             issue_tile(cur, 0);
+            TRX_EF_ST2(7);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tvA[j]));
