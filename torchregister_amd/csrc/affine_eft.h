@@ -179,6 +179,19 @@ typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+// Inclusive prefix sum over the 64 lanes of a wave by DPP (row shifts, then the two row broadcasts): ~10 vector instructions instead of the six LDS
+// round trips of a __shfl_up ladder - the plan's two scans waited 3-4 k ticks on an LDS that the co-resident block's gather keeps busy.
+__device__ __forceinline__ int wave_scan_incl(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // What a thread keeps of a plan between the items of one block (round 5): the plan depends on theta alone, so a block whose consecutive items
 // belong to the same pair makes it once (`replan` = false: the row table in LDS and these registers are still those of the pair).
 struct EfPlanRegs {
@@ -263,6 +276,27 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     int w4_s, hw4_s;   // row / plane pitch of the volume in bytes, pinned in SGPRs (v_mad_u32_u24 operands)
     asm("s_mov_b32 %0, %1" : "=s"(w4_s) : "s"(W * 4));
     asm("s_mov_b32 %0, %1" : "=s"(hw4_s) : "s"(H * W * 4));
+    int *org = ilds + 2 * C::BufFloats + C::TabInts;
+    auto lane_origins = [&](int ty_first) {   // (wave 0 writes; the caller's barrier publishes)
+        if (wave != 0) return;
+        const int ty = min(ty_first + lane, tg.nty - 1);
+        const float yn0 = ytab[ty * C::TY], yid0 = unnorm<3>(yn0, fH);
+        const float cx = fmaf(sx, yn0, corner_x), cy = yid0 + fmaf(sy, yn0, corner_y), cz = fmaf(sz, yn0, corner_z);
+        const bool sane = (fabsf(cx) < 1.0e6f) && (fabsf(cy) < 1.0e6f) && (fabsf(cz) < 1.0e6f);
+        const int rx = sane ? (int)floorf(cx) : -100000, ry = sane ? (int)floorf(cy) : -100000, rz = sane ? (int)floorf(cz) : -100000;
+        const int x0 = rx + dm.xmin, y0 = ry + dm.dy0, z0 = rz + dm.dz0;
+        const bool interior = (x0 >= 0) && (rx + dm.xmax + 3 < W) && (y0 >= 0) && (y0 + dm.ny <= H) && (z0 >= 0) && (z0 + dm.nz <= D);
+        // the plan's bounding box misses the volume: every sample of the tile is zero padding (nothing is staged or gathered)
+        const bool outside = (rx + dm.xmax < 0) || (x0 >= W) || (y0 + dm.ny <= 0) || (y0 >= H) || (z0 + dm.nz <= 0) || (z0 >= D);
+        int4 v;
+        v.x = rx; v.y = ry; v.z = rz;
+        v.w = outside ? 0 : (int)((((long long)z0 * H + y0) * W + x0) * 4);   // byte offset of the plan's corner (only dereferenced where inside the volume)
+        *reinterpret_cast<int4 *>(org + lane * 8) = v;
+        org[lane * 8 + 4] = (interior ? 1 : 0) | (outside ? 2 : 0);
+    };
+    // Round 5: the origins of the column's tiles are requested FIRST (wave 0 reads the y table: a global load whose latency the other seven waves used
+    // to sit out at a barrier behind the plan) and published by the barriers of the plan, or by the one in front of the walk.
+    if (dm.ok) lane_origins(ty_begin);
     if (replan) {   // (block-uniform)
     int cnt_r[2], wlo_r[2], pre_r[2];
 #pragma unroll
@@ -270,12 +304,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         const int r = tid + h * C::Threads, iy = r & (C::NY - 1), iz = r >> 5;
         cnt_r[h] = 0; wlo_r[h] = 0;
         if (dm.ok && iy < dm.ny && iz < dm.nz) cnt_r[h] = ef_row_window(mp, dm.dy0 + iy, dm.dz0 + iz, wlo_r[h]);
-        int p = cnt_r[h];   // inclusive scan inside the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(p, o, 64);
-            if (lane >= o) p += t;
-        }
+        const int p = wave_scan_incl(cnt_r[h]);   // inclusive scan inside the wave
         pre_r[h] = p;
         if (lane == 63) wtot[h * C::Waves + wave] = p;
     }
@@ -359,24 +388,6 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         // plan's corner.  Computed for 64 tiles at a time, ONE TILE PER LANE, and fetched with v_readlane (a per-tile scalar load of the row
         // table in front of everything it feeds was ~1 us of exposed latency per tile).
         struct TileOrg { int rx, ry, rz; bool interior, outside; const char *base; int dP; };
-        int *org = ilds + 2 * C::BufFloats + C::TabInts;
-        auto lane_origins = [&](int ty_first) {   // (wave 0 writes; the caller's barrier publishes)
-            if (wave != 0) return;
-            const int ty = min(ty_first + lane, tg.nty - 1);
-            const float yn0 = ytab[ty * C::TY], yid0 = unnorm<3>(yn0, fH);
-            const float cx = fmaf(sx, yn0, corner_x), cy = yid0 + fmaf(sy, yn0, corner_y), cz = fmaf(sz, yn0, corner_z);
-            const bool sane = (fabsf(cx) < 1.0e6f) && (fabsf(cy) < 1.0e6f) && (fabsf(cz) < 1.0e6f);
-            const int rx = sane ? (int)floorf(cx) : -100000, ry = sane ? (int)floorf(cy) : -100000, rz = sane ? (int)floorf(cz) : -100000;
-            const int x0 = rx + dm.xmin, y0 = ry + dm.dy0, z0 = rz + dm.dz0;
-            const bool interior = (x0 >= 0) && (rx + dm.xmax + 3 < W) && (y0 >= 0) && (y0 + dm.ny <= H) && (z0 >= 0) && (z0 + dm.nz <= D);
-            // the plan's bounding box misses the volume: every sample of the tile is zero padding (nothing is staged or gathered)
-            const bool outside = (rx + dm.xmax < 0) || (x0 >= W) || (y0 + dm.ny <= 0) || (y0 >= H) || (z0 + dm.nz <= 0) || (z0 >= D);
-            int4 v;
-            v.x = rx; v.y = ry; v.z = rz;
-            v.w = outside ? 0 : (int)((((long long)z0 * H + y0) * W + x0) * 4);   // byte offset of the plan's corner (only dereferenced where inside the volume)
-            *reinterpret_cast<int4 *>(org + lane * 8) = v;
-            org[lane * 8 + 4] = (interior ? 1 : 0) | (outside ? 2 : 0);
-        };
         auto tile_org = [&](int ty) -> TileOrg {
             const int g = (ty - ty_begin) & 63;
             const int4 v = *reinterpret_cast<const int4 *>(org + g * 8);
@@ -572,24 +583,35 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         // Tiles whose plan misses the volume altogether (warped = 0, gradient 0: only the target's moments count) form a prefix and a suffix
         // of the column - the plan's box moves along a straight line, and it meets the volume's box in one interval of tiles - and are
         // taken out of the pipelined walk: [ty_begin, t0) and [t1, ty_end) run the plain loop below, [t0, t1) the walk.
-        lane_origins(ty_begin);
         __syncthreads();
         TRX_EF_ST2(5);
         int t0 = ty_begin, t1 = ty_end;
-        while (t0 < ty_end && tile_org(t0).outside) t0++;
-        while (t1 > t0 && tile_org(t1 - 1).outside) t1--;
-        auto target_only = [&](int ta, int tb) {
+        if (ty_end - ty_begin <= 64) {   // (every lane reads its tile's flags: one LDS read and a ballot instead of a tile_org per candidate)
+            const int fl = org[min(lane, ty_end - ty_begin - 1) * 8 + 4];
+            const unsigned long long valid = (ty_end - ty_begin) == 64 ? ~0ull : ((1ull << (ty_end - ty_begin)) - 1ull);
+            const unsigned long long in = ~__builtin_amdgcn_ballot_w64((fl >> 1) & 1) & valid;
+            if (in == 0) t0 = t1 = ty_end;
+            else { t0 = ty_begin + __builtin_ctzll(in); t1 = ty_begin + 64 - __builtin_clzll(in); }
+        } else {
+            while (t0 < ty_end && tile_org(t0).outside) t0++;
+            while (t1 > t0 && tile_org(t1 - 1).outside) t1--;
+        }
+        t0 = __builtin_amdgcn_readfirstlane(t0); t1 = __builtin_amdgcn_readfirstlane(t1);
+        auto target_only = [&](int ta, int tb) {   // (the rows of a tile are requested together: eight loads in flight, not one)
             for (int ty = ta; ty < tb; ty++) {
-                const int Y0 = ty * C::TY, ny = min(C::TY, H - Y0);
-                for (int j = j0; j < min(j0 + kRows, ny); j++) {
-                    const float yv = tgt[(size_t)(z * H + Y0 + j) * W + x];
-                    if constexpr (MODE == 4) acc.M4 = fmaf(yv, yv, acc.M4);
-                    else { acc.M01.x += yv; acc.M23.x = fmaf(yv, yv, acc.M23.x); }
+                const int Y0 = ty * C::TY, nrow = min(C::TY, H - Y0) - j0;
+                float yv[kRows];
+#pragma unroll
+                for (int j = 0; j < kRows; j++) yv[j] = tgt[(size_t)(z * H + min(Y0 + j0 + j, H - 1)) * W + x];   // (rows past the volume repeat the last one: not accumulated)
+#pragma unroll
+                for (int j = 0; j < kRows; j++) {
+                    if (j < nrow) {
+                        if constexpr (MODE == 4) acc.M4 = fmaf(yv[j], yv[j], acc.M4);
+                        else { acc.M01.x += yv[j]; acc.M23.x = fmaf(yv[j], yv[j], acc.M23.x); }
+                    }
                 }
             }
         };
-        target_only(ty_begin, t0);
-        TRX_EF_ST2(6);
         // Vector-memory operations of a wave per tile, in program order:  YN' T'0 .. T'7 D0 .. D4  (' = of the next tile; T = the targets, into
         // the OTHER of two register sets, D = the DMA pieces): everything a tile needs is requested at the START of the tile before it, so the
         // one wait per tile finds it landed.  (Refilling the targets in place, row by row, left the last target load a few hundred cycles
@@ -604,6 +626,10 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
             for (int j = 0; j < kRows; j++) issue_target(t0, j, tvA[j]);
             issue_tile(cur, 0);
             TRX_EF_ST2(7);
+        }
+        target_only(ty_begin, t0);   // (the tiles in front of the volume, while the first tile of the walk is on its way)
+        TRX_EF_ST2(6);
+        if (t0 < t1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tvA[j]));
