@@ -554,7 +554,17 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
                 if (more) issue_target(ty + 1, j, tv[j]);
             };
             static_assert(kRows / 2 == 4, "four rows per call");
-#if TRX_EF_STAGES == 3
+#if TRX_EF_STAGES == 4   // (measured alternative) the table reads of all four rows of a call first
+            S1 ta = stage1(ja), tb = stage1(ja + 1), tc = stage1(ja + 2), td = stage1(ja + 3);
+            S2 fa = stage2(ta);
+            S2 fb = stage2(tb);
+            consume(fa, ja);
+            fa = stage2(tc);
+            consume(fb, ja + 1);
+            fb = stage2(td);
+            consume(fa, ja + 2);
+            consume(fb, ja + 3);
+#elif TRX_EF_STAGES == 3
             S1 ta = stage1(ja);
             S1 tb = stage1(ja + 1);
             S2 fa = stage2(ta);
