@@ -34,8 +34,10 @@ extern "C" {
  *   230  round 4: TRX_FLAG_SAVE_LAST (slab updates store flow_last only on request), TRX_FLAG_EFT / TRX_FLAG_NO_EFT, trx_peer_alloc / export /
  *        import on raw HIP IPC handles, sticky peer time-outs
  *   231  round 5: trx_affine_workspace_bytes grows by three ints (the z-streaming kernel's note to the kernels behind it), the rows_used array the
- *        step kernels leave in the workspace carries the kernel body in bits 24-27, TRX_FLAG_ZS_FUSED.  No entry point changed its signature. */
-#define TRX_VERSION 231
+ *        step kernels leave in the workspace carries the kernel body in bits 24-27, TRX_FLAG_ZS_FUSED.  No entry point changed its signature.
+ *   232  round 5: trx_affine_workspace_bytes reserves eight more ints (work tickets of the exact-footprint kernel, zeroed by the z-streaming kernel in
+ *        front of it on every launch: the workspace still needs no initialisation by the caller).  No entry point changed its signature. */
+#define TRX_VERSION 232
 #define TRX_PSTRIDE 12  /* floats per pair in theta / param / adam / best_theta arrays */
 
 typedef enum {

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/trx.h but not exported by libtrx.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.trx_version() == 231
+    assert lib.trx_version() == 232
     assert b"workspace" in lib.trx_status_string(-3)
 
 

@@ -1450,6 +1450,7 @@ __global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_ste
             rows_used[vol.B] = vol.B - __builtin_popcountll(take);
             rows_used[vol.B + 1] = (int)(unsigned)take; rows_used[vol.B + 2] = (int)(unsigned)(take >> 32);   // which pairs: nobody rewrites this
         }
+        if (lane < 8) rows_used[vol.B + 3 + lane] = 0;   // work tickets of the exact-footprint kernel behind this one (one queue per XCD)
     }
     if (take == 0) return;
     int pre = mine;   // inclusive prefix sum over the lanes (pairs)
@@ -1513,6 +1514,9 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
     // ONE call site of the body for both grids (as in affine_tile_dual_kernel): with a second inlined copy behind the classic grid's branch the
     // compiler produced a kernel whose classic-grid launches faulted as soon as round 5 touched the flat branch (tools/repro_eft2.py)
     const bool flat = stride >= 0;
+#if TRX_EF_STAMP
+    if (flat && wave == 0 && lane == 0) { for (int k = 1; k < 8; k++) trx_ef_blocks[blockIdx.x * 8 + k] = 0; trx_ef_blocks[blockIdx.x * 8] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     int pre = 0, total = 1;
     if (flat) {
     // flat: per pair (lane) the decision, one candidate pair per wave and round
@@ -1561,14 +1565,32 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
     // TRX_EF_CHUNK (round 5, measured alternative, off - see affine_eft.h): a block takes `ipb` CONSECUTIVE items of the pair-major list instead of every
     // gridDim-th one, i.e. (when the pairs' item counts are multiples of ipb) items of ONE pair, whose plan it then makes once (eft_body's `replan`).
     // Block jb of a pair (XCD jb & 7) takes the columns (jb & 7) + 8 (s nblk / 8 + jb / 8), s = 0 .. ipb - 1, of its XCD's slab.
+    // TRX_EF_TICKETS (round 5): behind affine_zs_step_kernel (which zeroes them) the flat grid's blocks DRAW their items - items cost 43 k ... 345 k ticks, and
+    // with every gridDim-th item a launch waited 460 us for blocks whose median finished at 349 (profiles/r05c_eft_item_timeline.txt).  One queue per XCD
+    // (block b draws from queue b & 7: the columns v = b & 7 (mod 8) of every pair, pair-major - the slab of its XCD's L2, as before); a block's first item is the
+    // one it had (no draw), the ticket of the next item is drawn when the current one is done (TRX_EF_TICKETS 2: at its START - no round trip to wait for, but every block then
+    // holds an item that nobody else can take: measured worse).
+    const bool tickets = TRX_EF_TICKETS && !TRX_EF_CHUNK && flat && zs_first && (tg.blocks_per_pair & 7) == 0 && (gridDim.x & 7) == 0 && (total % tg.blocks_per_pair) == 0;
     const int ipb = __builtin_amdgcn_readfirstlane(flat ? (TRX_EF_CHUNK ? (total + (int)gridDim.x - 1) / (int)gridDim.x : 1) : 1);
     const int it0 = flat ? (TRX_EF_CHUNK ? (int)blockIdx.x * ipb : (int)blockIdx.x) : 0, it_step = flat ? (TRX_EF_CHUNK ? 1 : (int)gridDim.x) : 1;
     const int it_end = flat ? (TRX_EF_CHUNK ? min(total, it0 + ipb) : total) : 1;
     EfPlanRegs pr;
     int planned = -1;   // the pair the registers and the row table in LDS belong to
-    for (int item = __builtin_amdgcn_readfirstlane(it0); item < it_end; item += it_step) {
+    int q = blockIdx.x & 7;                                                                   // (tickets) the queue the current item came from: this block's XCD's, at the end any
+    const int qlen = total >> 3, per_pair_q = tg.blocks_per_pair >> 3;                        // (tickets) a queue's length, a pair's items in it
+    int qk = (int)blockIdx.x >> 3;                                                            // (tickets) position in the queue of the current item
+    int drawn = 0;                                                                            // (tickets 2; lane 0 of wave 0) the ticket drawn for the next item
+    for (int item = __builtin_amdgcn_readfirstlane(it0); tickets ? (qk < qlen) : (item < it_end); item += it_step) {
         int v = blockIdx.x, pair = blockIdx.y;   // classic grid: the one item of this block
         if (flat) {
+            if (tickets) {
+                // (order of a queue: pair-major.  The pairs' inner columns first and their columns on a face of the volume - the cheap items - last was measured
+                // worse, 429 against 408 us: profiles/r05c_eft_item_timeline.txt)
+                const int ord = qk / per_pair_q, j = qk - ord * per_pair_q;   // the ord-th pair of those that fit, position in the XCD's slab
+                pair = __builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= ord * tg.blocks_per_pair));
+                v = q + 8 * j;
+                if (TRX_EF_TICKETS == 2 && wave == 0 && lane == 0) drawn = __hip_atomic_fetch_add(rows_used + vol.B + 3 + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
             pair = __builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= item));
             const int off = pair > 0 ? __builtin_amdgcn_readlane(pre, pair - 1) : 0;
             if (TRX_EF_CHUNK) {
@@ -1578,11 +1600,33 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
                     v = (jb & 7) + 8 * (sidx * (nblk >> 3) + (jb >> 3));
                 } else v = idx;
             } else v = (item - off + 104 * pair) % tg.blocks_per_pair;
+            }
         }
         v = __builtin_amdgcn_readfirstlane(v); pair = __builtin_amdgcn_readfirstlane(pair);
         if (item != it0) __syncthreads();   // the previous item's reduction scratch aliases the buffers
         eft_body<MODE>(vol, theta, tg, partials, lds, v, pair, rows_stride, wave, pr, pair != planned);
         planned = pair;
+#if TRX_EF_STAMP
+        if (flat && wave == 0 && lane == 0) { trx_ef_blocks[blockIdx.x * 8 + 1 + min((item - it0) / it_step, 5)] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        if (tickets) {   // the next item: the ticket drawn above, counted behind the (gridDim / 8) items the queue's blocks started with
+            if (wave == 0 && lane == 0) {
+                const int first = (int)gridDim.x >> 3;
+                int nq = blockIdx.x & 7, k = drawn + first;
+                if (TRX_EF_TICKETS != 2) {   // own queue first; when it is empty the others in turn (the XCDs' slabs differ in cost: edge slabs leave the source volume early)
+                    k = qlen;
+                    for (int t = 0; t < 8 && k >= qlen; t++) {
+                        nq = ((int)blockIdx.x + t) & 7;
+                        k = __hip_atomic_fetch_add(rows_used + vol.B + 3 + nq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + first;
+                    }
+                }
+                s_ef[63] = k < qlen ? ((nq << 24) | k) : -1;
+            }
+            __syncthreads();
+            const int nx = __builtin_amdgcn_readfirstlane(s_ef[63]);
+            if (nx < 0) break;
+            q = nx >> 24; qk = nx & 0xffffff;
+        }
     }
 }
 
@@ -2216,7 +2260,7 @@ static size_t tile_rows_per_pair(const trx_volumes &v)
     return n;
 }
 
-// Workspace of the affine entry points: [B][rows][41] partial sums | coordinate tables (callers that pass none) | rows_used[B + 3]
+// Workspace of the affine entry points: [B][rows][41] partial sums | coordinate tables (callers that pass none) | rows_used[B + 11]
 struct AffineWs {
     size_t rows, off_tab, off_rows_used, bytes;
 };
@@ -2231,7 +2275,7 @@ static AffineWs affine_ws(const trx_volumes &v)
     }
     w.off_tab = ((size_t)v.B * w.rows * np_full(3) * sizeof(float) + 255) & ~(size_t)255;
     w.off_rows_used = w.off_tab + (((size_t)(v.W + v.H + v.D) * sizeof(float) + 255) & ~(size_t)255);
-    w.bytes = w.off_rows_used + (((size_t)(v.B + 3) * sizeof(int) + 255) & ~(size_t)255);   // rows_used[B] | pairs left by the z-streaming kernel | its pair mask (2)
+    w.bytes = w.off_rows_used + (((size_t)(v.B + 11) * sizeof(int) + 255) & ~(size_t)255);   // rows_used[B] | pairs left by the z-streaming kernel | its pair mask (2) | the exact-footprint kernel's work tickets, one per XCD (8)
     return w;
 }
 

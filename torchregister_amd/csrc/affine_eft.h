@@ -28,6 +28,7 @@
 #if TRX_EF_STAMP
 __device__ unsigned long long trx_ef_stamps2[1024 * 8 * 8];   // the prologue in detail: windows + wave scans, barrier, totals + barrier, table + descriptors + barrier, granule registers + barrier, origins + barrier, head tiles, first tile requested
 #define TRX_EF_ST2(k) do { if (trx_lane_id() == 0) trx_ef_stamps2[((size_t)((by * rows_stride + bx) & 1023) * 8 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime() - ef_t0; } while (0)
+__device__ unsigned long long trx_ef_blocks[1024 * 8];   // flat step kernel: per block the 100 MHz clock at its start and after each of its items
 __device__ unsigned long long trx_ef_stamps[1024 * 8 * 8];   // [item][wave][issue, gather, wait (sums over the tiles), plan done, tail done | all done << 32, tiles | hwid << 16 | xcc << 32, first tile landed, walk done] in s_memtime ticks since the item began
 #endif
 #if !TRX_EF_STAMP
@@ -38,6 +39,14 @@ __device__ unsigned long long trx_ef_stamps[1024 * 8 * 8];   // [item][wave][iss
 #endif
 #ifndef TRX_EF_PRIO_BIT
 #define TRX_EF_PRIO_BIT 14
+#endif
+#ifndef TRX_EF_PARTFIX
+#define TRX_EF_PARTFIX 0   // 1: granules that straddle a face in x travel by DMA like full ones and are patched in LDS afterwards, instead of element by element with
+                           // ordinary loads (and a wait for everything in flight) - measured alternative: 19.0-19.2 k against 19.2-19.3 k pair-it/s at the rotated
+                           // pose (profiles/r05c_eft_item_timeline.txt): the long request phases of boundary tiles are their per-granule tests, not those loads
+#endif
+#ifndef TRX_EF_TICKETS
+#define TRX_EF_TICKETS 1   // flat grid of the step kernel behind the z-streaming kernel: the blocks draw their items from one queue per XCD (0: every gridDim-th item)
 #endif
 #ifndef TRX_EF_CHUNK
 #define TRX_EF_CHUNK 0   // 1: flat grid of the step kernel: a block's items are consecutive (one pair, ONE plan for all of them) instead of every gridDim-th one - measured
@@ -267,7 +276,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     int *wtot = ilds;                         // (prologue scratch in buffer 0) 16 chunk totals
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
 #if TRX_EF_STAMP
-    unsigned long long ef_stamp[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ef_stamp[6] = {0, 0, 0, 0, 0, 0}, ef_issue[2] = {0, 0};   // (ef_issue: of a tile step's request phase, the origin of the next tile / yn + eight target rows; the rest is the DMA pieces)
     const unsigned long long ef_t0 = __builtin_amdgcn_s_memtime();
 #endif
 #if TRX_EF_PRIO
@@ -406,6 +415,21 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         // issued at once, a whole tile ahead of their use.  Boundary tiles: granules outside the volume are not fetched (exec mask) but
         // zero-filled with ds_write here and now - the target buffer is idle; one that straddles a face in x is patched element by element
         // (rare, behind a wave-uniform test).
+        unsigned fixbits = 0;   // (TRX_EF_PARTFIX) per granule slot k of this thread, four bits: the elements of the tile in flight to zero once it has landed
+        [[maybe_unused]] const unsigned vol_last16 = (unsigned)D * (unsigned)H * (unsigned)W * 4u - 16u;
+        auto fix_tile = [&](int buf) {   // (after the wait for the tile, before the barrier that hands it to the gather)
+            if (__builtin_amdgcn_ballot_w64(fixbits != 0) == 0) return;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const unsigned m = (fixbits >> (4 * k)) & 15u;
+                float *p = lds + buf * C::BufFloats + (tid + k * C::Threads) * 4;
+                if (m & 1u) p[0] = 0.f;
+                if (m & 2u) p[1] = 0.f;
+                if (m & 4u) p[2] = 0.f;
+                if (m & 8u) p[3] = 0.f;
+            }
+            fixbits = 0;
+        };
         auto issue_tile = [&](const TileOrg &o, int buf) {
             const char *bs = uni_ptr(o.base);
 #pragma unroll
@@ -421,7 +445,21 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
                     const bool full = rowin && (gx >= 0) && (gx + 3 < W);
                     const bool part = rowin && !full && (gx + 3 >= 0) && (gx < W);
                     off = (unsigned)((int)off + o.dP);
-                    if (fetch && !full) {
+#if TRX_EF_PARTFIX
+                    // A granule that straddles a face in x and whose 16 bytes lie inside this pair's volume (all but the left overhang of the first row and the
+                    // right one of the last) is fetched by the DMA like a full one - it brings the neighbouring row's elements along - and the elements
+                    // outside the row are zeroed in LDS once the tile has landed (fix_tile).  Element by element with ordinary loads, as below, every such
+                    // granule cost the wave a wait for EVERYTHING it had in flight: the dearest tenth of the items spent 7.1 k ticks per tile requesting
+                    // the next one against 4.1 k on average (profiles/r05c_eft_item_timeline.txt).
+                    const bool dma_part = fetch && part && off <= vol_last16;
+                    if (dma_part) {
+                        const int lo = max(0, -gx), hi = min(4, W - gx);   // elements [lo, hi) are inside the row
+                        fixbits |= (unsigned)(~(((1 << hi) - 1) & ~((1 << lo) - 1)) & 15) << (4 * k);
+                    }
+#else
+                    const bool dma_part = false;
+#endif
+                    if (fetch && !full && !dma_part) {
                         f4 v = (f4)(0.f);
                         if (part) {
                             const float *row = mov + ((size_t)gz * H + gy) * W;
@@ -432,7 +470,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
                         }
                         *reinterpret_cast<f4 *>(lds + buf * C::BufFloats + g * 4) = v;
                     }
-                    fetch = fetch && full;
+                    fetch = fetch && (full || dma_part);
                 }
                 if (TRX_EF_DBG & 1) continue;
                 const unsigned long long mk = __builtin_amdgcn_ballot_w64(fetch);
@@ -641,6 +679,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         TRX_EF_ST2(6);
         if (t0 < t1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fix_tile(0);
 #pragma unroll
             for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(tvA[j]));
             asm volatile("" : "+v"(ynA));
@@ -669,9 +708,16 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
 #if TRX_EF_ISSUE_PRIO
                 __builtin_amdgcn_s_setprio(TRX_EF_ISSUE_PRIO);
 #endif
+#if TRX_EF_STAMP
+                const unsigned long long ei0 = __builtin_amdgcn_s_memtime();
+#endif
                 issue_yn(ty + 1, yn_load);
 #pragma unroll
                 for (int j = 0; j < kRows; j++) issue_target(ty + 1, j, load[j]);
+#if TRX_EF_STAMP
+                const unsigned long long ei1 = __builtin_amdgcn_s_memtime();
+                ef_issue[0] += ei0 - es0; ef_issue[1] += ei1 - ei0;
+#endif
                 issue_tile(nxt, par ^ 1);
 #if TRX_EF_ISSUE_PRIO
                 __builtin_amdgcn_s_setprio(0);
@@ -690,6 +736,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
 #pragma unroll
                 for (int j = 0; j < kRows; j++) asm volatile("" : "+v"(load[j]));
                 asm volatile("" : "+v"(yn_load));
+                fix_tile(par ^ 1);
             }
             cur = nxt;
             __syncthreads();
@@ -775,6 +822,7 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         unsigned long long *o = trx_ef_stamps + ((size_t)((by * rows_stride + bx) & 1023) * 8 + wave) * 8;
         for (int k = 0; k < 4; k++) o[k] = ef_stamp[k];
+        o[0] |= ef_issue[0] << 32; o[1] |= ef_issue[1] << 32;   // (sums of an item fit 32 bits)
         o[4] = (ef_stamp[4] & 0xffffffffull) | ((__builtin_amdgcn_s_memtime() - ef_t0) << 32);   // tail done | all done
         o[5] = ef_stamp[5] | ((unsigned long long)(hwid & 0xffff) << 16) | ((unsigned long long)(xcc & 0xf) << 32);
     }
