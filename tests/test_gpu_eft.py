@@ -226,3 +226,27 @@ def test_flat_grid_mixed_batch_against_oracle(eng):
         assert abs(s1.losses[0, 0].item() - s.losses[b, 0].item()) <= 2e-5 * max(1.0, abs(s.losses[b, 0].item())), b
         gb = s.grad[b, :12]
         assert torch.max(torch.abs(s1.grad[0, :12] - gb)).item() <= 2e-4 * gb.abs().max().item(), b
+
+
+def test_drawn_items_equal_assigned_items(eng):
+    """Round 5: behind the z-streaming kernel the exact-footprint kernel's blocks DRAW their items (one ticket queue per XCD, stealing at the
+    end) instead of taking every gridDim-th one.  Which block computes an item must not matter: a launch of 8 x 192^3 with five rotated
+    pairs (720 items, 90 per queue: 26 of them drawn) equals, bit for bit, the launch with TRX_FLAG_ZS_FUSED, whose exact-footprint kernel
+    runs in front with the items assigned - and repeats itself bit for bit although the drawing order differs from launch to launch."""
+    import torchregister_amd._lib as lib
+    shape, B = (192, 192, 192), 8
+    mats = [rot(0.5, 0.4, 0.3), np.eye(3), rot(0.45, 0.75, 0.1), rot(0.3, 0.3, 0.3), np.eye(3) * 1.01, rot(0.7, 0.8, 0.6), np.eye(3), rot(0.4, 0.5, 0.6)]
+    th = torch.tensor(np.stack([np.concatenate([m, 0.01 * np.ones((3, 1))], axis=1) for m in mats]), dtype=torch.float32)
+    tgt = torch.cat([ph.blobs(shape, 1000 + b) for b in range(B)]).cuda()
+    mov = torch.cat([ph.blobs(shape, 1050 + b) for b in range(B)]).cuda()
+    out = []
+    for fl in (0, 0, lib.FLAG_ZS_FUSED):
+        s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=0.0, init=th, capacity=1, flags=fl)
+        s.run(1)
+        torch.cuda.synchronize()
+        out.append((s.losses.clone(), s.grad.clone(), s.bodies()))
+    assert out[0][2] == ["eft", "zstream", "eft", "eft", "zstream", "eft", "zstream", "eft"], out[0][2]
+    assert out[2][2] == ["eft", "zstream-fused", "eft", "eft", "zstream-fused", "eft", "zstream-fused", "eft"], out[2][2]
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    rotated = [0, 2, 3, 5, 7]
+    assert torch.equal(out[0][0][rotated], out[2][0][rotated]) and torch.equal(out[0][1][rotated], out[2][1][rotated])
