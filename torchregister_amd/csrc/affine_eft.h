@@ -45,6 +45,9 @@ __device__ unsigned long long trx_ef_stamps[1024 * 8 * 8];   // [item][wave][iss
                            // ordinary loads (and a wait for everything in flight) - measured alternative: 19.0-19.2 k against 19.2-19.3 k pair-it/s at the rotated
                            // pose (profiles/r05c_eft_item_timeline.txt): the long request phases of boundary tiles are their per-granule tests, not those loads
 #endif
+#ifndef TRX_EF_SHAPE
+#define TRX_EF_SHAPE 0   // voxels of a wave per row: 0 = 16 x by 4 z, 1 = 8 x by 8 z
+#endif
 #ifndef TRX_EF_TICKETS
 #define TRX_EF_TICKETS 1   // flat grid of the step kernel behind the z-streaming kernel: the blocks draw their items from one queue per XCD (0: every gridDim-th item)
 #endif
@@ -229,7 +232,11 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     const int lane = trx_lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(wave_in);
     const int tid = wave * 64 + lane;
+#if TRX_EF_SHAPE == 1   // (measured alternative) a wave = 8 x by 8 z voxels of a row instead of 16 x by 4 z: waves 0-3 / 4-7 the two row halves, a wave's quadrant of the (x, z) face by its low two bits
+    const int lx = (tid & 7) + 8 * (wave & 1), lz = ((tid >> 3) & 7) + 8 * ((wave >> 1) & 1), lh = wave / (C::Waves / C::NH);
+#else
     const int lx = tid & (C::TX - 1), lz = (tid / C::TX) & (C::TZ - 1), lh = wave / (C::Waves / C::NH);
+#endif
     const float fW = (float)W, fH = (float)H, fD = (float)D;
     const float hW = 0.5f * fW, hH = 0.5f * fH, hD = 0.5f * fD;
     const float t00 = th[0], t01 = th[1], t02 = th[2], t03 = th[3];
@@ -803,7 +810,11 @@ __device__ __forceinline__ void eft_body(const trx_volumes &vol, const float *__
     {
         int tt = tid;   // (re-formed from the thread id: not kept live across the walk)
         asm volatile("" : "+v"(tt));
+#if TRX_EF_SHAPE == 1
+        const int lx2 = (tt & 7) + 8 * (wave & 1), lz2 = ((tt >> 3) & 7) + 8 * ((wave >> 1) & 1);
+#else
         const int lx2 = tt & (C::TX - 1), lz2 = (tt / C::TX) & (C::TZ - 1);
+#endif
         const int xx = X0 + ((lx2 < nx && lz2 < nz) ? lx2 : 0), zz = Z0 + ((lx2 < nx && lz2 < nz) ? lz2 : 0);
         const float xn_e = xtab[xx], zn_e = ztab[zz];
 #pragma unroll
