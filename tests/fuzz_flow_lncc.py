@@ -20,6 +20,32 @@ def smooth_nd(shape, f):
     return (torch.sin(f * ax[0])[:, None] + torch.cos(1.3 * f * ax[1] + 0.5)[None, :]).float().view(1, 1, *shape)
 
 
+def cancellation_floor(tgt, warped, d64, w):
+    """What fp32 leaves of dL/dflow where the per-voxel loss derivative is a CANCELLATION, from the fp64 oracle alone.  All three losses are
+    affine in (y, w) given the moments: dL/dw(v) = cy y(v) + cw w(v) + c0 (oracle/trx_oracle_body.h, loss_from_moments), and the kernels - like
+    torch's fp32 autograd - evaluate that sum in fp32: each term carries a relative rounding of 2^-24, so the derivative of a voxel is known to
+    2^-24 (|cy y| + |cw w| + |c0|), whatever the sum itself comes to.  NCC is invariant under scaling of w: when only ONE sample of the warped
+    image lies inside the moving image (tiny images, large flows: seed 65 case 32, a 3 x 7 image with flows of +-6 pixels) its derivative at that
+    voxel is zero by symmetry while the three terms are ~40 each.  Returns the absolute floor of dL/dflow: 2 * 2^-24 * max_v (terms(v) |grad w(v)|)
+    (a rounded coefficient times a rounded product: two roundings per term), |grad w(v)| = |dflow64(v)| / |dL/dw(v)|."""
+    y, ww = np.asarray(tgt, np.float64).ravel(), np.asarray(warped, np.float64).ravel()
+    n = float(y.size)
+    Sy, Sw, Syy, Sww, Syw = y.sum(), ww.sum(), (y * y).sum(), (ww * ww).sum(), (y * ww).sum()
+    my, mw = Sy / n, Sw / n
+    Saa, Sbb, Sab = Syy - Sy * my, Sww - Sw * mw, Syw - Sy * mw
+    sden = np.sqrt(Saa * Sbb + 1e-10)
+    k1, k2 = -w[2] / sden, w[2] * Sab * Saa / sden ** 3
+    q = w[0] * 2.0 / n + w[3] * w[4] * 2.0
+    cy, cw, c0 = w[1] * k1 - q, w[1] * k2 + q, w[1] * (-k1 * my - k2 * mw)
+    dldw = cy * y + cw * ww + c0
+    terms = np.abs(cy * y) + np.abs(cw * ww) + abs(c0)
+    g = np.max(np.abs(np.asarray(d64, np.float64).reshape(d64.shape[0], -1)), axis=0)
+    ok = np.abs(dldw) > 1e-300
+    if not ok.any():
+        return 0.0
+    return float(2.0 * 2.0 ** -24 * np.max(terms[ok] * g[ok] / np.abs(dldw[ok])))
+
+
 def run(n, seed, verbose=True, only=None, details=None):
     """only: evaluate just that case of the sweep (the random stream is still drawn for the cases before it); details: a list that receives one
     dict per evaluated case (errors, the fp32-vs-fp64 gap of the torch specification, the bars used)."""
@@ -41,12 +67,12 @@ def run(n, seed, verbose=True, only=None, details=None):
             continue
         terms, dfl = eng.flow_loss_grad(mov.cuda(), tgt.cuda(), flow.cuda(), eng.LossSpec(**kw))
         args = lambda dt: (mov[0, 0].numpy().astype(dt), tgt[0, 0].numpy().astype(dt), flow[0].numpy().astype(dt), oracle.wts(**kw))
-        t64, _, d64, _ = oracle.c_flow_loss_grad(*args(np.float64))
+        t64, _, d64, w64_ = oracle.c_flow_loss_grad(*args(np.float64))
         t32, _, d32, _ = oracle.c_flow_loss_grad(*args(np.float32))
         el = abs(terms[0, 0].item() - t64) / max(1.0, abs(t64))
         gmax = max(np.max(np.abs(d64)), 1e-12)
         eg = np.max(np.abs(dfl[0].cpu().numpy() - d64)) / gmax
-        gbar = max(2e-4, 2.0 * np.max(np.abs(d32 - d64)) / gmax)
+        gbar = max(2e-4, 2.0 * np.max(np.abs(d32 - d64)) / gmax, cancellation_floor(tgt[0, 0].numpy(), w64_, d64, oracle.wts(**kw)) / gmax)
         worst["flow_loss"] = max(worst["flow_loss"], el); worst["flow_grad"] = max(worst["flow_grad"], eg / gbar)
         bad = el > 2e-5 or eg > gbar
         # local NCC on (target, warped)

@@ -1,4 +1,4 @@
-"""The two cases the round-4 sweeps found ABOVE the bars of that time, pinned: each bar was widened after the case, so
+"""Cases that randomised sweeps found ABOVE the bars of their time, pinned (a third from round 5 at the end of the file): each bar was widened after the case, so
 each case is now a fixed regression test that holds the widened bar - and records, in its assertions, by how much the case needs it.
 
 1. tests/fuzz_flow_lncc.py, seed 51, case 231: 2-D 61 x 59, window 3, two pairs.  Local-window NCC gradient 3.08e-4 of its maximum
@@ -52,3 +52,22 @@ def test_zstream_kink_seed13_case111():
     assert worst["ksens"] > 2e-4, worst                      # (the bar of this pair IS the kink bar, not the 2e-4 floor)
     assert over <= 2.0, (over, worst)
     assert worst["zs_vs_tile"] <= 0.1 * worst["ksens"], worst
+
+
+def test_flow_single_sample_seed65_case32():
+    """Round 5, `python tests/fuzz_flow_lncc.py 100 65`, case 32: a 3 x 7 image under flows of +-6 pixels, MSE + NCC.  ONE sample of the warped
+    image lies inside the moving image; dL/dflow is non-zero at that voxel only (-9.5e-4, -6.3e-4) and the kernels differ from the fp64
+    oracle there by 2.5e-6 = 2.6e-3 of the maximum - thirteen times the 2e-4 bar, while the oracle's own fp32 build differs by 3e-10.
+    Analysis (fp64 oracle, this file's docstring of record): NCC does not change when w is scaled, so with a single non-zero sample its
+    derivative at that voxel is zero by symmetry (NCC alone: -5e-8, MSE alone: -1.7e-3) - as the sum cy y + cw w + c0 of three terms of
+    magnitude ~40 (ncc_alpha = 100).  The kernels evaluate that sum in fp32 (as torch's fp32 autograd of the reference does); the oracle's fp32
+    build keeps the coefficients and the sum in double.  2^-24 x 40 x |grad w| = 2.4e-6 is what is measured: rounding of a cancellation, not
+    an error of the path.  The sweep's bar now contains that floor (fuzz_flow_lncc.cancellation_floor, from the fp64 oracle alone); this test
+    holds the case against it and checks that the floor explains the error to within a factor of 4."""
+    from fuzz_flow_lncc import run
+    det = []
+    fails, _ = run(33, 65, verbose=True, only=32, details=det)
+    assert fails == 0, det
+    d = det[0]
+    assert d["shape"] == (3, 7)
+    assert 2e-4 < d["flow_grad_err"] <= d["flow_grad_bar"] < 4.0 * max(d["flow_grad_err"], 1e-3), d
