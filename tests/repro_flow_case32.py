@@ -1,7 +1,7 @@
 # development: the flow case the round-5 sweep found over its bar (tests/fuzz_flow_lncc.py 100 65, case 32), printed element by element against the fp64 / fp32 oracle.
-# test infrastructure like tests/: uses the oracle as the checker.   python tools/repro_flow_case32.py
+# test infrastructure like tests/: uses the oracle as the checker.   python tests/repro_flow_case32.py
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import oracle, phantoms as ph
 import torchregister_amd._engine as eng
