@@ -250,3 +250,26 @@ def test_drawn_items_equal_assigned_items(eng):
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     rotated = [0, 2, 3, 5, 7]
     assert torch.equal(out[0][0][rotated], out[2][0][rotated]) and torch.equal(out[0][1][rotated], out[2][1][rotated])
+
+
+def test_work_list_backwards_equals_forwards(eng):
+    """Round 5: on odd iterations of a run (TRX_FLAG_WALK_DOWN) the exact-footprint kernel's queues and the tile kernel's work list take the
+    pairs in the opposite order (they start on what the Infinity Cache still holds).  Same items, same sums: a step of 8 x 192^3 with rotated
+    pairs (exact-footprint kernel), pairs rotated about z (GeomRD in the tile kernel) and pairs next to the identity equals itself bit for
+    bit with the flag set - except for the z-streaming pairs, whose WALK along z changes the summation order (their test is in test_gpu_zstream.py)."""
+    import torchregister_amd._lib as lib
+    shape, B = (192, 192, 192), 8
+    mats = [rot(0.5, 0.4, 0.3), rot(0, 0, 0.6), rot(0.45, 0.75, 0.1), np.eye(3), rot(0, 0, 1.0), rot(0.7, 0.8, 0.6), rot(0, 0, 0.5), rot(0.4, 0.5, 0.6)]
+    th = torch.tensor(np.stack([np.concatenate([m, 0.01 * np.ones((3, 1))], axis=1) for m in mats]), dtype=torch.float32)
+    tgt = torch.cat([ph.blobs(shape, 1100 + b) for b in range(B)]).cuda()
+    mov = torch.cat([ph.blobs(shape, 1150 + b) for b in range(B)]).cuda()
+    out = []
+    for fl in (lib.FLAG_NO_PINGPONG, lib.FLAG_NO_PINGPONG | lib.FLAG_WALK_DOWN):
+        s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=0.0, init=th, capacity=1, flags=fl)
+        s.run(1)
+        torch.cuda.synchronize()
+        out.append((s.losses.clone(), s.grad.clone(), s.bodies()))
+    assert out[0][2] == out[1][2] == ["eft", "tile-RD", "eft", "zstream", "tile-RD", "eft", "tile-RD", "eft"], out[0][2]
+    same = [0, 1, 2, 4, 5, 6, 7]
+    assert torch.equal(out[0][0][same], out[1][0][same]) and torch.equal(out[0][1][same], out[1][1][same])
+    assert abs(out[0][0][3, 0].item() - out[1][0][3, 0].item()) <= 1e-6 * max(1.0, abs(out[0][0][3, 0].item()))

@@ -1345,10 +1345,12 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         int choice, v, by, stride;
         if (flat) {
             const int pre = *(volatile int *)&s_pre[lane];
-            const int pair = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= item)));   // lanes >= B hold the total: never counted
+            // (round 5) odd iterations of a run (TRX_FLAG_WALK_DOWN) take the list backwards, in groups of 8 (item % 8 stays the XCD): they start on the pairs the Infinity Cache still holds
+            const int it = (TRX_DUAL_PINGPONG && WHICH == 4 && (args()->vol.flags & TRX_FLAG_WALK_DOWN) && (total & 7) == 0) ? total - 8 - (item & ~7) + (item & 7) : item;
+            const int pair = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= it)));   // lanes >= B hold the total: never counted
             const int off = pair > 0 ? __builtin_amdgcn_readlane(pre, pair - 1) : 0;
             choice = *(volatile int *)&s_choice[pair];
-            v = __builtin_amdgcn_readfirstlane(item - off); by = pair; stride = rows_stride;
+            v = __builtin_amdgcn_readfirstlane(it - off); by = pair; stride = rows_stride;
             if (item != it0) __syncthreads();   // the previous body's reduction scratch aliases the box
         } else {
             choice = __builtin_amdgcn_readfirstlane(my_choice); v = blockIdx.x; by = blockIdx.y; stride = gridDim.x;   // (my_choice is per-lane on the flat path: keep this one provably uniform)
@@ -1586,7 +1588,9 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
             if (tickets) {
                 // (order of a queue: pair-major.  The pairs' inner columns first and their columns on a face of the volume - the cheap items - last was measured
                 // worse, 429 against 408 us: profiles/r05c_eft_item_timeline.txt)
-                const int ord = qk / per_pair_q, j = qk - ord * per_pair_q;   // the ord-th pair of those that fit, position in the XCD's slab
+                int ord = qk / per_pair_q;                                    // the ord-th pair of those that fit ...
+                const int j = qk - ord * per_pair_q;                          // ... position in the XCD's slab
+                if (TRX_EF_PINGPONG && (vol.flags & TRX_FLAG_WALK_DOWN)) ord = total / tg.blocks_per_pair - 1 - ord;   // odd iterations of a run take the pairs in the opposite order: they start on what the Infinity Cache still holds
                 pair = __builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= ord * tg.blocks_per_pair));
                 v = q + 8 * j;
                 if (TRX_EF_TICKETS == 2 && wave == 0 && lane == 0) drawn = __hip_atomic_fetch_add(rows_used + vol.B + 3 + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -48,6 +48,9 @@ __device__ unsigned long long trx_ef_stamps[1024 * 8 * 8];   // [item][wave][iss
 #ifndef TRX_EF_SHAPE
 #define TRX_EF_SHAPE 0   // voxels of a wave per row: 0 = 16 x by 4 z, 1 = 8 x by 8 z
 #endif
+#ifndef TRX_EF_PINGPONG
+#define TRX_EF_PINGPONG 1   // the ticket queues run the pairs backwards when TRX_FLAG_WALK_DOWN is set (odd iterations of trx_affine_run)
+#endif
 #ifndef TRX_EF_TICKETS
 #define TRX_EF_TICKETS 1   // flat grid of the step kernel behind the z-streaming kernel: the blocks draw their items from one queue per XCD (0: every gridDim-th item)
 #endif

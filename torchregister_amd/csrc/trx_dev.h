@@ -127,3 +127,7 @@ __device__ unsigned long long trx_timing[4 * 8192];
 #define TRX_TM_TILE_DONE() ((void)0)
 #define TRX_TM_STORE() ((void)0)
 #endif
+
+#ifndef TRX_DUAL_PINGPONG
+#define TRX_DUAL_PINGPONG 1   // the tile kernel behind the z-streaming kernel takes its work list backwards on odd iterations of a run (TRX_FLAG_WALK_DOWN)
+#endif
