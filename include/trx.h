@@ -70,8 +70,9 @@ typedef enum {
 #define TRX_FLAG_EFT 1024u          /* affine steps: offer the exact-footprint body whatever the batch size (by default only to launches that fill the chip) */
 #define TRX_FLAG_ZS_FUSED 2048u      /* affine steps on launches that fill the chip: keep the z-streaming body inside the tile kernel (the round 3-4 form) instead of
                                       * running it as a kernel of its own in front (measured alternative; tests compare the two) */
-#define TRX_FLAG_WALK_DOWN 8192u      /* affine steps: the z-streaming kernel walks its columns from the last plane to the first.  Same sums up to rounding.  trx_affine_run
-                                      * toggles this bit on every second iteration (unless TRX_FLAG_NO_PINGPONG): the planes a pass read last are the ones the next pass
+#define TRX_FLAG_WALK_DOWN 8192u      /* affine steps: the z-streaming kernel walks its columns from the last plane to the first (same sums up to rounding); the exact-footprint
+                                      * and tile kernels behind it take the pairs in the opposite order (same sums bit for bit).  trx_affine_run
+                                      * toggles this bit on every second iteration (unless TRX_FLAG_NO_PINGPONG): the planes (pairs) a pass read last are the ones the next pass
                                       * starts with, and the 256 MiB Infinity Cache still holds them.  Callers that step one iteration per call may alternate it themselves */
 #define TRX_FLAG_NO_PINGPONG 16384u   /* trx_affine_run: every iteration walks in the direction the caller's flags say (measured alternative) */
 #define TRX_FLAG_NO_ZS_FLAT 4096u     /* affine steps: the z-streaming kernel never uses its flat 64 x 16 tile (pairs beyond the 64 x 32 tile's window run the tile kernels) */
