@@ -253,3 +253,16 @@ def test_exact_footprint_plan_model_never_misses_a_cell():
         assert G >= exact
         if i < 2:
             assert G <= 2304 and dims[0] <= 32 and dims[1] <= 32
+
+
+def test_affine_workspace_holds_the_notes_between_kernels():
+    """The affine workspace ends in int rows_used[B + 11]: per pair the rows / body of the last step, then what the kernels of ONE step leave each
+    other - pairs left by the z-streaming kernel, its pair mask (2 ints), the exact-footprint kernel's work tickets (8 ints, zeroed by the
+    kernel in front on every launch: callers never initialise the workspace).  The size the library asks for must hold them for every batch."""
+    from torchregister_amd import _lib
+    lib = _lib.load()
+    for B in (1, 8, 53, 54, 61, 62, 64):
+        v = _lib.Volumes()
+        v.moving, v.target, v.ndim, v.B, v.D, v.H, v.W = 16, 16, 3, B, 64, 64, 64
+        need, off = lib.trx_affine_workspace_bytes(ctypes.byref(v)), lib.trx_affine_workspace_rows_offset(ctypes.byref(v))
+        assert off > 0 and need >= off + (B + 11) * 4, (B, need, off)
