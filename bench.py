@@ -40,6 +40,14 @@ ALG_BYTES_PER_VOXEL = 8    # read moving (4) + target (4) once per pair-iteratio
 THETA_STAR = [[0.95, -0.1, 0.02, 0.05], [0.1, 0.97, 0.0, -0.03], [0.0, 0.03, 1.02, 0.02]]
 
 
+def theta_star_inv():
+    """moving = warp(theta*, target), so a registration of (moving -> target) converges to the INVERSE map of theta*:
+    x -> A^-1 x - A^-1 t in affine_grid's normalised coordinates (cubic volumes: no aspect factors)."""
+    t = torch.tensor(THETA_STAR, dtype=torch.float64)
+    ai = torch.linalg.inv(t[:, :3])
+    return torch.cat([ai, -(ai @ t[:, 3:])], dim=1).float()
+
+
 def blobs_gpu(shape, seed, device):
     """Same phantom as tests/phantoms.blobs (6 Gaussian blobs on a [-1,1]^3 lattice), built on the GPU in fp32."""
     g = torch.Generator().manual_seed(int(seed))
@@ -277,12 +285,14 @@ def main():
 
     pose_steps = min(args.steps, 100)
     extra = {"value_theta_star": None, "value_rot": None, "value_rigid_randinit": None, "flow_value": None, "value_run": None, "run_loss_ratio_worst": None,
-             "run_loss_first_last": None, "run_theta_err_worst": None, "body_histogram": None}
-    # (a) theta* itself - the pose the headline run converges to; (b) R(0.5, 0.4, 0.3) x anisotropic scale; (c) the rigid mode from the
+             "run_loss_first_last": None, "run_theta_err_worst": None, "body_histogram": None, "value_theta_star_inv": None}
+    # (a) theta* (the map the synthetic moving volumes were made with) and its inverse - the pose a run of this batch CONVERGES to;
+    # (b) R(0.5, 0.4, 0.3) x anisotropic scale; (c) the rigid mode from the
     # reference's own initial pose: torch.manual_seed(0); torch.rand(6) radians / tanh-translations (ref:utils.py:316-321)
     th_star = torch.tensor(THETA_STAR, device=device)[None].expand(my_pairs, 3, 4).contiguous()
+    th_star_inv = theta_star_inv().to(device)[None].expand(my_pairs, 3, 4).contiguous()
     th_rot = pose_rot(device, my_pairs)
-    for key, th0 in (() if args.no_pose_legs else (("value_theta_star", th_star), ("value_rot", th_rot))):
+    for key, th0 in (() if args.no_pose_legs else (("value_theta_star", th_star), ("value_theta_star_inv", th_star_inv), ("value_rot", th_rot))):
         sv = tr.AffineSolver(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer=args.optimizer, lr=1e-6, init=th0,
                              capacity=pose_steps + 40)
         extra[key] = job_pairs * pose_steps / max_over_ranks(timed_run(sv, pose_steps), device)
@@ -318,7 +328,7 @@ def main():
         extra["value_run"] = job_pairs * RUN_ITERS / el_run
         extra["run_loss_ratio_worst"] = float((lr_[:, -1] / lr_[:, 0]).max().item())
         extra["run_loss_first_last"] = [float(lr_[0, 0].item()), float(lr_[0, -1].item())]
-        extra["run_theta_err_worst"] = float((sv.theta[:, :12].view(-1, 3, 4) - torch.tensor(THETA_STAR, device=device)[None]).abs().max().item())
+        extra["run_theta_err_worst"] = float((sv.theta[:, :12].view(-1, 3, 4) - theta_star_inv().to(device)[None]).abs().max().item())
         del sv
         hist = {}
         rp = tr.AffineSolver(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), optimizer="adam", lr=RUN_LR, capacity=RUN_ITERS)
@@ -345,17 +355,18 @@ def main():
                           "value_cold": job_pairs * args.steps / elapsed_cold,
                           "value_cold_note": f"first {args.steps} iterations of a fresh solver after 2 s of idle GPU, no warm-up",
                           f"{other}_value": job_pairs * args.steps / elapsed2,
-                          "value_theta_star": extra["value_theta_star"], "value_rot": extra["value_rot"],
+                          "value_theta_star": extra["value_theta_star"], "value_theta_star_inv": extra["value_theta_star_inv"], "value_rot": extra["value_rot"],
                           "value_rigid_randinit": extra["value_rigid_randinit"],
-                          "pose_note": f"pair-iterations/s of {pose_steps} steps at a fixed pose (lr 1e-6), same batch: theta* of the synthetic "
-                                       "pairs (where the headline run converges); theta = R(0.5, 0.4, 0.3) diag(1.05, 0.95, 1.02); rigid mode from "
+                          "pose_note": f"pair-iterations/s of {pose_steps} steps at a fixed pose (lr 1e-6), same batch: theta* (the map the synthetic "
+                                       "moving volumes were warped with) and its inverse (value_theta_star_inv: the pose a registration of this batch "
+                                       "converges to); theta = R(0.5, 0.4, 0.3) diag(1.05, 0.95, 1.02); rigid mode from "
                                        "the reference's initial pose torch.manual_seed(0), torch.rand(6).  The headline value itself starts at "
                                        "theta = identity (where every affine run starts) and moves |theta - I| by at most lr per step",
                           "value_run": extra["value_run"], "run_loss_ratio_worst": extra["run_loss_ratio_worst"], "run_loss_first_last": extra["run_loss_first_last"],
                           "run_theta_err_worst": extra["run_theta_err_worst"], "body_histogram": extra["body_histogram"],
                           "run_note": f"value_run: pair-iterations/s of ONE registration of the same batch that converges - from theta = identity, Adam lr {RUN_LR}, "
                                       f"{RUN_ITERS} iterations in one trx_affine_run call (no warm-up beyond the legs before it); run_loss_ratio_worst = the worst pair's last / first "
-                                      "NCC loss (bar: < 0.01); body_histogram = pair-iterations per kernel body over a replica of that run (sampled every "
+                                      "NCC loss (bar: < 0.01); run_theta_err_worst = max |theta_final - inverse(theta*)| over pairs and entries; body_histogram = pair-iterations per kernel body over a replica of that run (sampled every "
                                       f"{RUN_CHUNK} iterations)",
                           "flow_value": extra["flow_value"],
                           "flow_note": "iterations/s of BASELINE configs[2]: one 256^3 pair, direct flow field + NCC + smoothness regulariser, "

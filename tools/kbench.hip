@@ -6,11 +6,6 @@
 #include <cstdlib>
 #include <vector>
 #include "../torchregister_amd/csrc/affine.hip"
-#ifdef TRX_EXPERIMENT_STREAM
-namespace trx {
-#include "experiments/affine_stream.h"   // the shelved y-streaming F1 kernel (round 2): a measured alternative, never part of the library
-}
-#endif
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -109,40 +104,6 @@ int main(int argc, char **argv)
     trx::TileGeom tgm = trx::tile_geom(vol);
     printf("tile geom: %d x %d x %d tiles, %d blocks/pair\n", tgm.ntx, tgm.nty, tgm.ntz, tgm.blocks_per_pair);
     dim3 tgrid(tgm.blocks_per_pair, B);
-#ifdef TRX_EXPERIMENT_STREAM
-    auto stream_case = [&](const char *what) {
-        printf("-- %s\n", what);
-    {   // the y-streaming kernel: same 41 sums per pair as the tile kernel (host-side fp64 reduction of the partial rows), and its time
-        const trx::StreamGeom sgm = trx::stream_geom(vol);
-        printf("stream geom: %d x %d columns, %d steps in %d segments, %d blocks/pair\n", sgm.ntx, sgm.ntz, sgm.nsteps, sgm.nseg, sgm.blocks_per_pair);
-        auto sums = [&](int rows) {
-            std::vector<float> hp((size_t)B * rows * 41);
-            CK(hipMemcpy(hp.data(), partials, hp.size() * 4, hipMemcpyDeviceToHost));
-            std::vector<double> out((size_t)B * 41, 0.0);
-            for (int b = 0; b < B; b++) for (int r = 0; r < rows; r++) for (int k = 0; k < 41; k++) out[b * 41 + k] += hp[((size_t)b * rows + r) * 41 + k];
-            return out;
-        };
-        CK(hipMemset(partials, 0, (size_t)B * (g.nblk + 4096) * 41 * 4));
-        hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials);
-        CK(hipDeviceSynchronize());
-        const std::vector<double> ref = sums(tgm.blocks_per_pair);
-        CK(hipMemset(partials, 0, (size_t)B * (g.nblk + 4096) * 41 * 4));
-        hipLaunchKernelGGL((trx::affine_stream_kernel<0>), dim3(sgm.blocks_per_pair, B), dim3(trx::StreamCfg::Threads), 0, 0, vol, theta, sgm, partials, sgm.blocks_per_pair);
-        CK(hipDeviceSynchronize());
-        const std::vector<double> got = sums(sgm.blocks_per_pair);
-        double worst = 0;
-        for (int b = 0; b < B; b++) {
-            double scale = 0;
-            for (int k = 5; k < 41; k++) scale = std::max(scale, fabs(ref[b * 41 + k]));
-            for (int k = 0; k < 41; k++) worst = std::max(worst, fabs(got[b * 41 + k] - ref[b * 41 + k]) / (k < 5 ? std::max(1.0, fabs(ref[b * 41 + k])) : scale));
-        }
-        printf("stream vs tile: worst relative difference of the 41 sums %.3e  (Sy %.6f / %.6f  Sw %.6f / %.6f)\n", worst, got[0], ref[0], got[1], ref[1]);
-        rep("stream MODE0 (full F1)", time_it([&] { hipLaunchKernelGGL((trx::affine_stream_kernel<0>), dim3(sgm.blocks_per_pair, B), dim3(trx::StreamCfg::Threads), 0, 0, vol, theta, sgm, partials, sgm.blocks_per_pair); }, 20));
-    }
-    };
-#else
-    auto stream_case = [&](const char *) {};
-#endif
     rep("tile MODE1 (moments)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<1>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
     rep("tile MODE0 (full F1)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
     {   // the dual kernel in GeomA mode: the cost of the surplus (empty) blocks
@@ -221,18 +182,15 @@ int main(int argc, char **argv)
         rep("split MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 1>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); hipLaunchKernelGGL((trx::affine_tile_dual_kernel<0, 2>), dim3(gx, B), dim3(512), 0, 0, vol, theta, ta, tr, 1, partials); }, 20));
     }
     rep("tile MODE0 identity", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
-    stream_case("identity");
     {   // what bench.py's run looks like after its 125 Adam iterations: |theta - I| ~ 0.0125, plus a shift
         const float sm[12] = {1.011f, -0.012f, 0.009f, 0.02f, 0.0125f, 0.992f, -0.007f, -0.015f, -0.01f, 0.011f, 1.006f, 0.01f};
         for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = sm[i];
         CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
         rep("tile MODE0 |theta-I| 0.0125", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
-        stream_case("|theta - I| ~ 0.0125");
         const float s3[12] = {1.02f, -0.03f, 0.015f, 0.03f, 0.03f, 0.985f, -0.012f, -0.02f, -0.015f, 0.02f, 1.01f, 0.015f};
         for (int b = 0; b < B; b++) for (int i = 0; i < 12; i++) th[b * 12 + i] = s3[i];
         CK(hipMemcpy(theta, th.data(), B * 12 * 4, hipMemcpyHostToDevice));
         rep("tile MODE0 rot 0.03", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, 20));
-        stream_case("rotation ~ 0.03 rad");
     }
     return 0;
 }
