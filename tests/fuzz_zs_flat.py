@@ -26,7 +26,7 @@ def rot(ax, ay, az):
 
 def run(n, seed, verbose=True):
     rng = np.random.default_rng(seed)
-    fails, asked, seen = 0, 0, {}
+    fails, asked, seen, only_wide = 0, 0, {}, 0
     worst = {"loss": 0.0, "grad": 0.0, "widest_bar": 3e-4}
     for it in range(n):
         shape, B = [((64, 128, 128), 16), ((96, 128, 128), 8), ((128, 128, 128), 8)][int(rng.integers(0, 3))]
@@ -69,6 +69,7 @@ def run(n, seed, verbose=True):
                 bar = max(3e-4, 2.0 * ksens)
                 eg = max(np.max(np.abs(s.grad[b, :12].cpu().numpy().reshape(3, 4) - dth)), np.max(np.abs(r.grad[b, :12].cpu().numpy().reshape(3, 4) - dth))) / gmax / bar * 3e-4
                 asked += 1
+                only_wide += 3e-4 < eg * bar / 3e-4 <= bar
                 worst["widest_bar"] = max(worst["widest_bar"], bar)
             worst["loss"] = max(worst["loss"], el); worst["grad"] = max(worst["grad"], eg)
             if not (el <= 2e-5 and eg <= 3e-4 and np.isfinite(ls)):
@@ -77,7 +78,7 @@ def run(n, seed, verbose=True):
                     print(f"FAIL case {it} pair {b}: shape {shape} B {B} body {bodies[b]} down {down} kw {kw} loss {ls} / {lr_} ({el:.2e}) grad {eg:.2e}\n theta {th[b].tolist()}")
     if verbose:
         print(f"{n} cases, {fails} failures; worst loss rel {worst['loss']:.2e} (bar 2e-5), gradient rel-to-max {worst['grad']:.2e} (bar 3e-4; {asked} pairs went to the oracle, "
-              f"widest bar used {worst['widest_bar']:.2e} of the gradient's maximum); pairs per body: {seen}")
+              f"widest bar used {worst['widest_bar']:.2e} of the gradient's maximum, {only_wide} of them passed ONLY through a widened bar); pairs per body: {seen}")
     return fails, worst
 
 
