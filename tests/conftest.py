@@ -16,6 +16,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The baseline-trajectory module needs ~2 minutes of host time for its arbiter (oracle/compose.py loops in worker processes): start those
+    runs as soon as the collection is known and run the module's tests LAST, so that the wait passes under the other GPU tests."""
+    mark = config.getoption("-m") or ""
+    traj = [it for it in items if "test_gpu_baseline_trajectories" in it.nodeid]
+    if not traj:
+        return
+    items[:] = [it for it in items if it not in traj] + traj
+    selected = "gpu" in mark and "not gpu" not in mark
+    if selected and len(items) > len(traj):
+        import test_gpu_baseline_trajectories as tb
+        tb.start_arbiter()
+
+
 @pytest.fixture(scope="session")
 def single_step():
     return dict(np.load(os.path.join(GOLDEN, "single_step.npz")))

@@ -41,8 +41,8 @@ def run(n, seed, verbose=True):
                 A = rot(*rng.uniform(-0.7, 0.7, 3)) @ np.diag(1.0 + rng.uniform(-0.1, 0.1, 3))
             mats.append(np.concatenate([A, rng.uniform(-0.08, 0.08, (3, 1))], axis=1))
         th = torch.tensor(np.stack(mats), dtype=torch.float32)
-        tgt = torch.cat([ph.blobs(shape, 2000 + 7 * it + (b % 4)) for b in range(B)]).cuda()
-        mov = torch.cat([ph.blobs(shape, 3000 + 5 * it + (b % 3)) + 0.1 * ph.vol(shape, 0.011 + 0.001 * (b % 5), "sin") for b in range(B)]).cuda()
+        tgt = torch.cat([ph.blobs_fast(shape, 2000 + 7 * it + (b % 4), device="cuda") for b in range(B)])
+        mov = torch.cat([ph.blobs_fast(shape, 3000 + 5 * it + (b % 3), device="cuda") + 0.1 * ph.vol(shape, 0.011 + 0.001 * (b % 5), "sin").cuda() for b in range(B)])
         kw = dict(w_ncc=float(rng.uniform(0.3, 1)), w_mse=float(rng.uniform(0, 1))) if rng.random() < 0.7 else dict(w_mse=1.0)
         down = bool(rng.integers(0, 2))
         s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=_lib.FLAG_WALK_DOWN if down else 0)

@@ -35,6 +35,27 @@ def blobs(shape, seed, nblob=6, dtype=torch.float32):
     return img.to(dtype).view(1, 1, *shape)
 
 
+def blobs_fast(shape, seed, nblob=6, device="cpu"):
+    """The same phantom family as `blobs` (same draws from the same generator) evaluated separably - exp(-r^2 / 2 s^2) as the outer product of
+    three 1-D factors, fp64, rounded once to fp32 - on `device`: the values differ from `blobs` in the last bits, so golden fixtures keep
+    `blobs`; tests that feed the SAME tensor to the kernels and to the oracle use this one for big volumes (16 volumes of 192^3 take 50 s
+    with `blobs` on the host, well under a second with this on the GPU)."""
+    g = torch.Generator().manual_seed(int(seed))
+    d = len(shape)
+    axes = [torch.linspace(-1, 1, s, dtype=torch.float64, device=device) for s in shape]
+    img = torch.zeros(shape, dtype=torch.float64, device=device)
+    for _ in range(nblob):
+        c = torch.rand(d, generator=g) - 0.5
+        sig = 0.05 + 0.2 * torch.rand(1, generator=g)
+        a = torch.rand(1, generator=g)
+        f = [torch.exp(-(axes[k] - float(c[k])) ** 2 / (2 * float(sig) ** 2)) for k in range(d)]
+        term = f[0].view(-1, *([1] * (d - 1)))
+        for k in range(1, d):
+            term = term * f[k].view(*([1] * k), -1, *([1] * (d - 1 - k)))
+        img += float(a) * term
+    return img.to(torch.float32).view(1, 1, *shape)
+
+
 def flow_field(shape, amp=0.8, f=0.11, dtype=torch.float32):
     """amp * sin(f * i) viewed as [1, ndim, *shape] (voxel units, channel i moves along dim i)."""
     nd = len(shape)

@@ -43,13 +43,46 @@ for _dt in ("float32", "float64"):
     JOBS[("cfg4r", "adam", _dt)] = ("rigid", S256, 1000 + CFG4R_PAIR, _dt, "adam", CFG4_LR, 20, CFG4R_PAIR)
 
 
+_POOL = {}
+
+
+def start_arbiter():
+    """Submit every arbiter run of this module to worker processes (spawned: they must not inherit an initialised GPU).  conftest.py calls
+    this when the collection ends and moves this module's tests behind all others: the arbiter's ~2 minutes of host time then pass under
+    the rest of the GPU suite instead of in front of this module (round 6: the suite had grown to 800-1000 s of a 1200 s limit)."""
+    if not _POOL:
+        ctx = multiprocessing.get_context("spawn")
+        ex = concurrent.futures.ProcessPoolExecutor(max_workers=len(JOBS), mp_context=ctx)
+        _POOL["ex"] = ex
+        _POOL["futs"] = {k: ex.submit(tw.run, j) for k, j in JOBS.items()}
+    return _POOL
+
+
 @pytest.fixture(scope="module")
 def refs():
-    """every arbiter run of this module, side by side in worker processes (spawned: they must not inherit an initialised GPU)"""
-    ctx = multiprocessing.get_context("spawn")
-    with concurrent.futures.ProcessPoolExecutor(max_workers=len(JOBS), mp_context=ctx) as ex:
-        futs = {k: ex.submit(tw.run, j) for k, j in JOBS.items()}
-        return {k: f.result() for k, f in futs.items()}
+    """every arbiter run of this module (started at collection time, joined here)"""
+    pool = start_arbiter()
+    try:
+        return {k: f.result() for k, f in pool["futs"].items()}
+    finally:
+        pool["ex"].shutdown(wait=False, cancel_futures=True)
+
+
+def batch_of_pairs(B, compared):
+    """The 8 x 256^3 batch: the pairs that go to the arbiter exactly as its workers build them (tw.pair, on the host), the others from the
+    same family on the GPU (phantoms.blobs_fast; nobody compares them with anything but themselves)."""
+    import phantoms as ph
+    import torchregister_amd._engine as e
+    movs, tgts = [], []
+    for i in range(B):
+        if i in compared:
+            m, t = tw.pair(S256, 1000 + i)
+            m, t = m.cuda(), t.cuda()
+        else:
+            t = ph.blobs_fast(S256, 1000 + i, device="cuda")
+            m = e.affine_warp(torch.tensor(ph.THETA_STAR3, device="cuda")[None], t)
+        movs.append(m); tgts.append(t)
+    return torch.cat(movs), torch.cat(tgts)
 
 
 @pytest.fixture(scope="module")
@@ -107,9 +140,9 @@ def test_cfg3_flow_ncc_smooth_10_iterations(eng, refs, optimizer, lr, shape):
 
 def test_cfg4_share_of_one_gpu_8x256_20_iterations(eng, refs):
     iters, B = 20, 8
-    pairs = [tw.pair(S256, 1000 + i) for i in range(B)]
+    mov, tgt = batch_of_pairs(B, CFG4_PAIRS)
     th0 = torch.stack([torch.from_numpy(tw.theta0_np(seed=i)) for i in range(B)])
-    s = eng.AffineSolver(torch.cat([p[0] for p in pairs]).cuda(), torch.cat([p[1] for p in pairs]).cuda(), mode="affine", loss=eng.LossSpec(w_ncc=1.0),
+    s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0),
                          optimizer="adam", lr=CFG4_LR, init=th0, capacity=iters)
     s.run(iters)
     torch.cuda.synchronize()
@@ -125,9 +158,9 @@ def test_cfg4_rigid_from_the_reference_initial_pose_8x256_20_iterations(eng, ref
     the reference's initial pose (torch.manual_seed(0); torch.rand(6), ref:utils.py:316-321: ~0.5 / 0.77 / 0.09 rad), which the
     exact-footprint kernel runs at every step; pair 3 against the arbiter (loss curve and theta after the last step)."""
     iters, B = 20, 8
-    pairs = [tw.pair(S256, 1000 + i) for i in range(B)]
+    mov, tgt = batch_of_pairs(B, (CFG4R_PAIR,))
     pose0 = torch.stack([tw.rigid_pose0(i) for i in range(B)])
-    s = eng.AffineSolver(torch.cat([p[0] for p in pairs]).cuda(), torch.cat([p[1] for p in pairs]).cuda(), mode="rigid", loss=eng.LossSpec(w_ncc=1.0),
+    s = eng.AffineSolver(mov, tgt, mode="rigid", loss=eng.LossSpec(w_ncc=1.0),
                          optimizer="adam", lr=CFG4_LR, init=pose0, capacity=iters)
     s.run(iters)
     torch.cuda.synchronize()

@@ -142,8 +142,8 @@ def test_mixed_batch_every_body_in_one_launch(eng):
             rot(0.2, 0.2, 0.2), rot(0.45, 0.75, 0.1)]
     B = len(mats)
     th = torch.tensor(np.stack([np.concatenate([m, 0.01 * np.ones((3, 1))], axis=1) for m in mats]), dtype=torch.float32)
-    tgt = torch.cat([ph.blobs(shape, 600 + b) for b in range(B)]).cuda()
-    mov = torch.cat([ph.blobs(shape, 700 + b) for b in range(B)]).cuda()
+    tgt = torch.cat([ph.blobs_fast(shape, 600 + b, device="cuda") for b in range(B)])
+    mov = torch.cat([ph.blobs_fast(shape, 700 + b, device="cuda") for b in range(B)])
     fl = lib.FLAG_EFT | lib.FLAG_DEEP_TILE | lib.FLAG_ZSTREAM
     runs = []
     for _ in range(2):
@@ -190,8 +190,8 @@ def test_flat_grid_mixed_batch_against_oracle(eng):
     mats = [np.eye(3), rot(0.5, 0.4, 0.3), np.eye(3) + 0.01 * np.sin(np.arange(9)).reshape(3, 3), rot(0.45, 0.75, 0.1), rot(0, 0, 0.5), rot(0.7, 0.8, 0.6) * 1.03,
             np.eye(3) * 1.6, rot(0.3, 0.3, 0.3)]
     th = torch.tensor(np.stack([np.concatenate([m, 0.01 * np.ones((3, 1))], axis=1) + 1e-3 * np.cos(np.arange(12) + i).reshape(3, 4) for i, m in enumerate(mats)]), dtype=torch.float32)
-    tgt = torch.cat([ph.blobs(shape, 900 + b) for b in range(B)]).cuda()
-    mov = torch.cat([ph.blobs(shape, 950 + b) for b in range(B)]).cuda()
+    tgt = torch.cat([ph.blobs_fast(shape, 900 + b, device="cuda") for b in range(B)])
+    mov = torch.cat([ph.blobs_fast(shape, 950 + b, device="cuda") for b in range(B)])
     kw = dict(w_ncc=1.0)
     s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1)
     s.run(1)
@@ -237,8 +237,8 @@ def test_drawn_items_equal_assigned_items(eng):
     shape, B = (192, 192, 192), 8
     mats = [rot(0.5, 0.4, 0.3), np.eye(3), rot(0.45, 0.75, 0.1), rot(0.3, 0.3, 0.3), np.eye(3) * 1.01, rot(0.7, 0.8, 0.6), np.eye(3), rot(0.4, 0.5, 0.6)]
     th = torch.tensor(np.stack([np.concatenate([m, 0.01 * np.ones((3, 1))], axis=1) for m in mats]), dtype=torch.float32)
-    tgt = torch.cat([ph.blobs(shape, 1000 + b) for b in range(B)]).cuda()
-    mov = torch.cat([ph.blobs(shape, 1050 + b) for b in range(B)]).cuda()
+    tgt = torch.cat([ph.blobs_fast(shape, 1000 + b, device="cuda") for b in range(B)])
+    mov = torch.cat([ph.blobs_fast(shape, 1050 + b, device="cuda") for b in range(B)])
     out = []
     for fl in (0, 0, lib.FLAG_ZS_FUSED):
         s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=0.0, init=th, capacity=1, flags=fl)
@@ -261,8 +261,8 @@ def test_work_list_backwards_equals_forwards(eng):
     shape, B = (192, 192, 192), 8
     mats = [rot(0.5, 0.4, 0.3), rot(0, 0, 0.6), rot(0.45, 0.75, 0.1), np.eye(3), rot(0, 0, 1.0), rot(0.7, 0.8, 0.6), rot(0, 0, 0.5), rot(0.4, 0.5, 0.6)]
     th = torch.tensor(np.stack([np.concatenate([m, 0.01 * np.ones((3, 1))], axis=1) for m in mats]), dtype=torch.float32)
-    tgt = torch.cat([ph.blobs(shape, 1100 + b) for b in range(B)]).cuda()
-    mov = torch.cat([ph.blobs(shape, 1150 + b) for b in range(B)]).cuda()
+    tgt = torch.cat([ph.blobs_fast(shape, 1100 + b, device="cuda") for b in range(B)])
+    mov = torch.cat([ph.blobs_fast(shape, 1150 + b, device="cuda") for b in range(B)])
     out = []
     for fl in (lib.FLAG_NO_PINGPONG, lib.FLAG_NO_PINGPONG | lib.FLAG_WALK_DOWN):
         s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=0.0, init=th, capacity=1, flags=fl)

@@ -39,7 +39,7 @@ def run(job):
     """job = (kind, shape, seed, dtype name, optimizer, lr, iters, extra) -> dict of numpy arrays"""
     import torch
     from oracle import compose
-    torch.set_num_threads(16)
+    torch.set_num_threads(8)   # (16 jobs side by side under the rest of the GPU suite: leave the host cores that suite's own oracle calls need)
     kind, shape, seed, dtn, optimizer, lr, iters, extra = job
     dt = getattr(torch, dtn)
     mov, tgt = pair(shape, seed)
