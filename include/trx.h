@@ -36,8 +36,9 @@ extern "C" {
  *   231  round 5: trx_affine_workspace_bytes grows by three ints (the z-streaming kernel's note to the kernels behind it), the rows_used array the
  *        step kernels leave in the workspace carries the kernel body in bits 24-27, TRX_FLAG_ZS_FUSED.  No entry point changed its signature.
  *   232  round 5: trx_affine_workspace_bytes reserves eight more ints (work tickets of the exact-footprint kernel, zeroed by the z-streaming kernel in
- *        front of it on every launch: the workspace still needs no initialisation by the caller).  No entry point changed its signature. */
-#define TRX_VERSION 232
+ *        front of it on every launch: the workspace still needs no initialisation by the caller).  No entry point changed its signature.
+ *   240  round 6: TRX_FLAG_ONE_KERNEL (a step of a chip-filling launch next to the identity is ONE streaming launch + the finalise), trx_affine_near_identity. */
+#define TRX_VERSION 240
 #define TRX_PSTRIDE 12  /* floats per pair in theta / param / adam / best_theta arrays */
 
 typedef enum {
@@ -76,6 +77,13 @@ typedef enum {
                                       * starts with, and the 256 MiB Infinity Cache still holds them.  Callers that step one iteration per call may alternate it themselves */
 #define TRX_FLAG_NO_PINGPONG 16384u   /* trx_affine_run: every iteration walks in the direction the caller's flags say (measured alternative) */
 #define TRX_FLAG_NO_ZS_FLAT 4096u     /* affine steps: the z-streaming kernel never uses its flat 64 x 16 tile (pairs beyond the 64 x 32 tile's window run the tile kernels) */
+#define TRX_FLAG_ONE_KERNEL 32768u     /* affine steps of launches that fill the chip: the caller EXPECTS every pair to stay next to the identity (inside the z-streaming kernel's
+                                      * windows: |theta - I| up to ~0.03 on its 64 x 32 tile, rotations to ~0.15 rad / zooms to 1.15 on its flat tile), so the step launches that
+                                      * kernel ALONE - no exact-footprint kernel, no tile kernel behind it (two launches that find nothing to do cost a 256-CU dispatch each:
+                                      * 5.3 + 4.8 us of a 266 us step, profiles/r06a_step_timeline.txt).  Always correct: a pair that leaves the windows is run by the same kernel
+                                      * on GeomR's body, at about twice its usual cost while it stays outside - a hint about speed, never about results (fp32 rounding between
+                                      * bodies as with every other path flag).  trx_affine_near_identity() evaluates the expectation for thetas the caller holds on the host;
+                                      * torchregister_amd.AffineSolver sets the flag by itself from the initial thetas and from the bodies the previous run() call ended on */
 #define TRX_FLAG_NO_ROT_DEEP_TILE 16u /* affine steps: never use GeomRD (the 16 x 16 x 16 tile in GeomR's box) - rotated pairs all run GeomR */
 
 /* A batch of B independent (moving, target) pairs. */
@@ -138,6 +146,11 @@ size_t trx_affine_workspace_bytes(const trx_volumes *vol /*[host]*/);
  * launch wrote for each pair.  The step kernels pick a kernel body per pair from theta (tile geometry / z-streaming) and each body has its
  * own row count, so this tells a test or a profiler which body ran; the step's own reduction reads the same array. */
 size_t trx_affine_workspace_rows_offset(const trx_volumes *vol /*[host]*/);
+
+/* [host] 1 if a step of this batch at the given thetas (HOST memory, [B][TRX_PSTRIDE]) would run entirely on the z-streaming kernel's tiles - the
+ * test that kernel evaluates per pair on the device - i.e. if TRX_FLAG_ONE_KERNEL costs nothing at these poses; 0 otherwise (also for 2-D and
+ * for batches the z-streaming kernel is not offered).  No device work. */
+int trx_affine_near_identity(const trx_volumes *vol /*[host]*/, const float *theta_host);
 
 /* ONE optimiser iteration for all B pairs: fused forward warp + loss + analytic backward
  * (single pass over moving/target), then loss/gradient/optimiser/best-tracking on device.

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/trx.h but not exported by libtrx.so"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.trx_version() == 232
+    assert lib.trx_version() == 240
     assert b"workspace" in lib.trx_status_string(-3)
 
 
@@ -266,3 +266,27 @@ def test_affine_workspace_holds_the_notes_between_kernels():
         v.moving, v.target, v.ndim, v.B, v.D, v.H, v.W = 16, 16, 3, B, 64, 64, 64
         need, off = lib.trx_affine_workspace_bytes(ctypes.byref(v)), lib.trx_affine_workspace_rows_offset(ctypes.byref(v))
         assert off > 0 and need >= off + (B + 11) * 4, (B, need, off)
+
+
+def test_near_identity_helper_without_gpu():
+    """trx_affine_near_identity is host arithmetic (the z-streaming kernel's window test on host thetas): the identity and a small affine
+    perturbation of a chip-filling 3-D batch are inside, a rotation is not; 2-D, small launches and bad arguments answer 0."""
+    import numpy as np
+    from torchregister_amd import _lib
+    lib = _lib.load()
+    v = _lib.Volumes()
+    v.moving, v.target, v.ndim, v.B, v.D, v.H, v.W = 16, 16, 3, 8, 256, 256, 256
+    def ask(th):
+        a = np.ascontiguousarray(np.stack([np.asarray(th, dtype=np.float32).reshape(12)] * v.B))
+        return lib.trx_affine_near_identity(ctypes.byref(v), a.ctypes.data_as(ctypes.c_void_p))
+    eye = np.eye(3, 4)
+    assert ask(eye) == 1
+    assert ask(eye + 0.01 * np.sin(np.arange(12.0)).reshape(3, 4)) == 1
+    c, s_ = np.cos(0.5), np.sin(0.5)
+    assert ask([[c, -s_, 0, 0], [s_, c, 0, 0], [0, 0, 1, 0]]) == 0
+    assert ask(np.full((3, 4), np.nan)) == 0
+    assert lib.trx_affine_near_identity(ctypes.byref(v), None) == 0
+    v.B = 1; v.D = v.H = v.W = 64
+    assert ask(eye) == 0          # a launch the z-streaming kernel is not offered
+    v.ndim, v.D = 2, 1
+    assert ask(eye) == 0

@@ -130,7 +130,7 @@ class AffineSolver:
     """
 
     def __init__(self, moving, target, mode="affine", loss=None, optimizer="sgd", lr=1e-5, init=None, capacity=1000,
-                 betas=(0.9, 0.999), eps=1e-8, flags=0):
+                 betas=(0.9, 0.999), eps=1e-8, flags=0, one_kernel="auto"):
         self.lib = _lib.load()
         self.batch = _Batch(moving, target, flags=flags)
         if self.batch.C != 1 or self.batch.target.shape[1] != 1:
@@ -182,6 +182,37 @@ class AffineSolver:
         self.state = st
         self.loss_c = self.loss.c()
         self.enqueued = 0   # iterations enqueued so far (host-side mirror of the device counter `step`)
+        # TRX_FLAG_ONE_KERNEL (include/trx.h): next to the identity a step of a chip-filling 3-D launch is the z-streaming kernel alone.  A hint about
+        # speed only (the kernel runs stray pairs itself, slower), so it is set from what the HOST knows without waiting for the device: the
+        # initial thetas (trx_affine_near_identity, the kernel's own window test) and, from the second run() call on, the kernel bodies the previous
+        # call ended on - copied to pinned memory behind that call and read only if the copy has landed.  one_kernel: "auto" | True | False.
+        self._one_policy = one_kernel
+        self._note_host = self._note_event = None
+        self._base_flags = int(self.vol.flags)
+        # ("auto" only for launches of up to 4 x 256^3 voxels: the two empty launches the flag removes cost a fixed ~3.3 us per step - 51.5 against 55.0 us
+        # for 16 x 64 x 128 x 128, 77.3 against 80.4 for 2 x 256^3 - while the kernel instance that carries GeomR's body streams 0.5-3 % slower; at the
+        # 8 x 256^3 of the headline the two cancel: profiles/r06a_one_kernel_ab.txt)
+        small = b * self.batch.nvox <= 4 * 256 ** 3
+        if nd == 3 and one_kernel is not False and not (self._base_flags & _lib.FLAG_ONE_KERNEL) and (one_kernel is True or small):
+            if one_kernel is True:
+                self.vol.flags = self._base_flags | _lib.FLAG_ONE_KERNEL
+            else:
+                th_host = self.theta.detach().cpu().contiguous()
+                if self.lib.trx_affine_near_identity(ctypes.byref(self.vol), ctypes.c_void_p(th_host.data_ptr())):
+                    self.vol.flags = self._base_flags | _lib.FLAG_ONE_KERNEL
+                self._note_host = torch.empty(b, dtype=torch.int32).pin_memory()
+                self._note_event = torch.cuda.Event()
+                self._note_pending = False
+
+    def _refresh_one_kernel(self):
+        """"auto" policy: if the notes of the previous run() call have landed in pinned memory, keep TRX_FLAG_ONE_KERNEL exactly when that call's last
+        step ran every pair on the z-streaming tiles (bodies 6 / 8; 3 = GeomR's body inside the one-kernel form, anything else = the kernels behind)."""
+        if self._note_host is None or not self._note_pending or not self._note_event.query():
+            return
+        self._note_pending = False
+        body = (self._note_host.abs() >> 24) & 15
+        near = bool(((body == 6) | (body == 8)).all().item())
+        self.vol.flags = (self._base_flags | _lib.FLAG_ONE_KERNEL) if near else self._base_flags
 
     def run(self, iters):
         """Enqueue `iters` iterations on the current stream (no host sync)."""
@@ -190,11 +221,22 @@ class AffineSolver:
             raise _lib.TrxError(f"loss-curve capacity exceeded: {self.enqueued} iterations enqueued + {iters} requested > capacity "
                                 f"{self.capacity} (create the solver with a larger `capacity`)")
         self.enqueued += iters
+        self._refresh_one_kernel()
         with torch.cuda.device(self.batch.device):
             rc = self.lib.trx_affine_run(ctypes.byref(self.vol), ctypes.byref(self.loss_c), ctypes.byref(self.opt),
                                          ctypes.byref(self.state), int(iters), _lib.ptr(self.workspace), self.ws_bytes,
                                          _lib.current_stream(self.batch.device))
+            if rc == 0 and iters > 0 and self._note_host is not None and not self._note_pending:
+                off = int(self.lib.trx_affine_workspace_rows_offset(ctypes.byref(self.vol)))
+                self._note_host.copy_(self.workspace[off:off + 4 * self.batch.B].view(torch.int32), non_blocking=True)
+                self._note_event.record(torch.cuda.current_stream(self.batch.device))
+                self._note_pending = True
         _lib.check(rc, "trx_affine_run")
+
+    @property
+    def one_kernel(self):
+        """Is TRX_FLAG_ONE_KERNEL set for the next run() call?"""
+        return bool(self.vol.flags & _lib.FLAG_ONE_KERNEL)
 
     BODIES = {0: "none", 1: "tile-D", 2: "tile-A", 3: "tile-R", 4: "tile-RD", 5: "zstream-fused", 6: "zstream", 7: "eft", 8: "zstream-flat"}
 

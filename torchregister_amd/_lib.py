@@ -21,6 +21,7 @@ FLAG_GATHER_PATH, FLAG_SINGLE_GEOM, FLAG_TWO_PASS_FLOW, FLAG_DEEP_TILE, FLAG_NO_
 FLAG_NO_EFT, FLAG_EFT = 512, 1024
 FLAG_WALK_DOWN, FLAG_NO_PINGPONG = 8192, 16384   # z-streaming columns walked downward / trx_affine_run does not alternate the direction
 FLAG_NO_ZS_FLAT = 4096   # the z-streaming kernel without its flat tile (measured alternative)
+FLAG_ONE_KERNEL = 32768   # chip-filling launches next to the identity: the z-streaming kernel alone (it runs stray pairs on GeomR's body)
 FLAG_ZS_FUSED = 2048   # keep the z-streaming body inside the tile kernel (measured alternative of round 5)
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -69,6 +70,7 @@ SIGNATURES = {
     "trx_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "trx_affine_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Volumes)]),
     "trx_affine_workspace_rows_offset": (ctypes.c_size_t, [ctypes.POINTER(Volumes)]),
+    "trx_affine_near_identity": (ctypes.c_int, [ctypes.POINTER(Volumes), _P]),
     "trx_affine_step": (ctypes.c_int, [ctypes.POINTER(Volumes), ctypes.POINTER(LossCfg), ctypes.POINTER(OptCfg),
                                        ctypes.POINTER(AffineState), _P, ctypes.c_size_t, _P]),
     "trx_affine_accumulate": (ctypes.c_int, [ctypes.POINTER(Volumes), _P, _P, ctypes.c_size_t, _P]),

@@ -1430,24 +1430,36 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
                         // does not take: poses of the convergence basin (rotations up to ~0.15 rad about z, zooms to 1.15, 3.7 planes of tilt) run 10-11 %
                         // faster on it than on the deep tile kernel (profiles/r05a_zs_flat_tile.txt); 0: never
 #endif
-template <int MODE>
-__global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_step_kernel(trx_volumes vol, const float *__restrict__ theta, ZGeom zg, ZGeom zgf, float *__restrict__ partials,
-                                                                                         int *__restrict__ rows_used, int stride)
+// FB (round 6): the ONE-KERNEL form of a step (TRX_FLAG_ONE_KERNEL) - nothing is launched behind this kernel, so the pairs its two streaming tiles do
+// not take run HERE, on GeomR's body (the tile whose box holds the pre-image under any rotation; 78.6 KB, inside the ring's allocation): a pair that
+// leaves the window costs ~2 x its usual time for as long as it stays outside instead of two launches (5.3 + 4.8 us of empty dispatch per step,
+// profiles/r06a_step_timeline.txt) on every step of every run.  FB = 0 is the kernel of rounds 5: the FB code is compiled out of it.
+struct ZsOneKArgs {   // the kernel arguments of affine_zs_one_kernel as one struct (field order and types = its parameter list)
+    trx_volumes vol;
+    const float *theta;
+    ZGeom zg, zgf;
+    float *partials;
+    int *rows_used;
+    int stride;
+    TileGeom tgR;
+};
+template <int MODE, int FB>
+__device__ __forceinline__ void zs_step_main(const trx_volumes &vol, const float *__restrict__ theta, const ZGeom &zg, const ZGeom &zgf, float *__restrict__ partials,
+                                             int *__restrict__ rows_used, int stride, const int fb_blocks, float *ring)
 {
-    constexpr int kAlloc = (TRX_ZS_FLAT && ZSF::Alloc > ZS64::Alloc) ? ZSF::Alloc : ZS64::Alloc;
-    __shared__ __attribute__((aligned(16))) float ring[kAlloc];
     const int wave = trx_wave_index(), lane = trx_lane_id();
     const float fD = (float)vol.D, fH = (float)vol.H, fW = (float)vol.W;
-    // per pair (lane): 1 = the 64 x 32 tile takes it, 2 = the flat tile does, 0 = left to the kernels behind
+    // per pair (lane): 1 = the 64 x 32 tile takes it, 2 = the flat tile does, 0 = left to the kernels behind (FB: 3 = GeomR's body, here)
     int which = 0;
     if (lane < vol.B) {
         if (zs_nsub<ZS64>(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, zg.planes_per_seg) > 0) which = 1;
         else if (TRX_ZS_FLAT && zgf.blocks_per_pair > 0 && zs_nsub<ZSF>(theta + (size_t)lane * TRX_PSTRIDE, fD, fH, fW, zgf.planes_per_seg) > 0) which = 2;
+        else if (FB) which = 3;
     }
     const unsigned long long take = __builtin_amdgcn_ballot_w64(which != 0), take1 = __builtin_amdgcn_ballot_w64(which == 1);
-    const int mine = which == 1 ? zg.blocks_per_pair : (which == 2 ? zgf.blocks_per_pair : 0);
+    const int mine = which == 1 ? zg.blocks_per_pair : (which == 2 ? zgf.blocks_per_pair : ((FB && which == 3) ? fb_blocks : 0));
     if (blockIdx.x == 0 && wave == 0) {
-        if (lane < vol.B) rows_used[lane] = -rows_note(mine, which == 2 ? 8 : 6);
+        if (lane < vol.B) rows_used[lane] = -rows_note(mine, which == 3 ? 3 : (which == 2 ? 8 : 6));
         if (lane == 0) {
             rows_used[vol.B] = vol.B - __builtin_popcountll(take);
             rows_used[vol.B + 1] = (int)(unsigned)take; rows_used[vol.B + 2] = (int)(unsigned)(take >> 32);   // which pairs: nobody rewrites this
@@ -1463,6 +1475,30 @@ __global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_ste
     }
     const int total = __builtin_amdgcn_readlane(pre, 63);
     const int second = (int)(blockIdx.x * 2 >= gridDim.x);   // the later of the two blocks of a CU (TRX_ZS_PRIO)
+    if constexpr (FB != 0) {
+        // the pair's body rides in the low two bits of its prefix sum: the masks of the FB = 0 form (two scalar-register pairs, live across the streaming
+        // loops, which have none to spare) would be three here
+        const int prew = (pre << 2) | which;
+        for (int item = blockIdx.x; item < total; item += gridDim.x) {
+            const int pair = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64((prew >> 2) <= item)));
+            const int off = pair > 0 ? (__builtin_amdgcn_readlane(prew, pair - 1) >> 2) : 0;
+            const int w = __builtin_amdgcn_readlane(prew, pair) & 3;
+            const int v = __builtin_amdgcn_readfirstlane(item - off);
+            if (item != (int)blockIdx.x) __syncthreads();   // the previous item's reduction scratch aliases the ring
+            if (__builtin_expect(w == 3, 0)) {
+                // (the tile geometry is read through the kernarg segment HERE, as affine_tile_dual_kernel reads its arguments: loaded at the kernel's entry
+                // its seven scalars stay live across the streaming loops.  Inlined: as a function of its own - __noinline__, arguments through the kernarg
+                // segment - the call's register conventions cost the streaming loops 25 more scalar reloads per two planes than the inlined body's 2)
+                typedef const __attribute__((address_space(4))) ZsOneKArgs *KArgs;
+                KArgs a = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(a));
+                const TileGeom t = {a->tgR.ntx, a->tgR.nty, a->tgR.ntz, a->tgR.ntiles, a->tgR.blocks_per_pair, a->tgR.ysplit, a->tgR.tiles_per_seg};
+                tile_body<MODE, GeomR>(vol, theta, t, 1, partials, ring, v, pair, stride, wave);
+            } else if (!TRX_ZS_FLAT || w == 1) zstream_body<MODE, ZS64>(vol, theta, zg, partials, ring, v, pair, stride, wave, second);
+            else zstream_body<MODE, ZSF>(vol, theta, zgf, partials, ring, v, pair, stride, wave, second);
+        }
+        return;
+    }
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
         const int pair = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64(pre <= item)));
         const int off = pair > 0 ? __builtin_amdgcn_readlane(pre, pair - 1) : 0;
@@ -1471,6 +1507,25 @@ __global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_ste
         if (!TRX_ZS_FLAT || ((take1 >> pair) & 1ull)) zstream_body<MODE, ZS64>(vol, theta, zg, partials, ring, v, pair, stride, wave, second);
         else zstream_body<MODE, ZSF>(vol, theta, zgf, partials, ring, v, pair, stride, wave, second);
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_step_kernel(trx_volumes vol, const float *__restrict__ theta, ZGeom zg, ZGeom zgf, float *__restrict__ partials,
+                                                                                         int *__restrict__ rows_used, int stride)
+{
+    constexpr int kAlloc = (TRX_ZS_FLAT && ZSF::Alloc > ZS64::Alloc) ? ZSF::Alloc : ZS64::Alloc;
+    __shared__ __attribute__((aligned(16))) float ring[kAlloc];
+    zs_step_main<MODE, 0>(vol, theta, zg, zgf, partials, rows_used, stride, 0, ring);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(ZS64::Threads, TRX_ZS_MIN_WAVES) void affine_zs_one_kernel(trx_volumes vol, const float *__restrict__ theta, ZGeom zg, ZGeom zgf, float *__restrict__ partials,
+                                                                                        int *__restrict__ rows_used, int stride, TileGeom tgR)
+{
+    constexpr int kAllocZ = (TRX_ZS_FLAT && ZSF::Alloc > ZS64::Alloc) ? ZSF::Alloc : ZS64::Alloc;
+    constexpr int kAlloc = GeomR::BoxAlloc > kAllocZ ? GeomR::BoxAlloc : kAllocZ;
+    __shared__ __attribute__((aligned(16))) float ring[kAlloc];
+    zs_step_main<MODE, 1>(vol, theta, zg, zgf, partials, rows_used, stride, tgR.blocks_per_pair, ring);
 }
 
 template <int MODE>
@@ -2295,6 +2350,25 @@ extern "C" size_t trx_affine_workspace_rows_offset(const trx_volumes *vol)
     return affine_ws(*vol).off_rows_used;
 }
 
+// [host] Would a step of this batch run entirely on the z-streaming kernel's two tiles at these (HOST) thetas?  The same test the kernel
+// evaluates per pair on the device (zs_nsub), for callers that decide about TRX_FLAG_ONE_KERNEL from values they hold on the host.
+extern "C" int trx_affine_near_identity(const trx_volumes *vol, const float *theta_host)
+{
+    if (check_vol(vol, false) != TRX_OK || !theta_host || vol->ndim != 3) return 0;
+    const ZGeom zg = zs_launch_geom(*vol);
+    if (zg.blocks_per_pair == 0) return 0;
+    const bool flat_ok = TRX_ZS_FLAT && zs_shape_ok<ZSF>(*vol) && !(vol->flags & TRX_FLAG_NO_ZS_FLAT);
+    const ZGeom zgf = flat_ok ? zs_geom<ZSF>(*vol) : ZGeom{};
+    const float fD = (float)vol->D, fH = (float)vol->H, fW = (float)vol->W;
+    for (int b = 0; b < vol->B; b++) {
+        const float *th = theta_host + (size_t)b * TRX_PSTRIDE;
+        if (zs_nsub<ZS64>(th, fD, fH, fW, zg.planes_per_seg) > 0) continue;
+        if (flat_ok && zs_nsub<ZSF>(th, fD, fH, fW, zgf.planes_per_seg) > 0) continue;
+        return 0;
+    }
+    return 1;
+}
+
 static bool use_tile_path(const trx_volumes *vol)
 {
     if (vol->ndim != 3) return false;
@@ -2391,6 +2465,14 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             if constexpr (MODE == 0 || MODE == 4) {
                 if (zs_first) {
                     const ZGeom zgf = (TRX_ZS_FLAT && zs_shape_ok<ZSF>(*vol) && !(vol->flags & TRX_FLAG_NO_ZS_FLAT)) ? zs_geom<ZSF>(*vol) : ZGeom{};
+                    if (vol->flags & TRX_FLAG_ONE_KERNEL) {
+                        // the one-kernel form of a step: the streaming kernel also runs the pairs outside its window (GeomR's body), nothing behind it
+                        hipLaunchKernelGGL((affine_zs_one_kernel<MODE>), dim3(slots, 1), dim3(ZS64::Threads), 0, s, v, theta, zg, zgf, partials, ru, gxx, tr);
+                        TRX_CHECK_LAUNCH();
+                        *nblk = gxx;
+                        *rows_used = ru;
+                        return TRX_OK;
+                    }
                     hipLaunchKernelGGL((affine_zs_step_kernel<MODE>), dim3(slots, 1), dim3(ZS64::Threads), 0, s, v, theta, zg, zgf, partials, ru, gxx);
                     TRX_CHECK_LAUNCH();
                 }

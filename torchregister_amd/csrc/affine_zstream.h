@@ -18,7 +18,7 @@
 // the pass is bound by its vector instructions at the clock the chip holds under this load.
 
 #ifndef TRX_ZS_DBG
-#define TRX_ZS_DBG 0   // development ablation (tools/zbench.hip): bits: 1 = no ring DMA, 2 = no target loads, 4 = no gather, 8 = no barrier (racy), 16 = no counted wait (racy), 32 = no LDS reads (fake corners), 64 = no accumulation of the pose sums
+#define TRX_ZS_DBG 0   // development ablation (tools/zbench.hip): bits: 1 = no ring DMA, 2 = no target loads, 4 = no gather, 8 = no barrier (racy), 16 = no counted wait (racy), 32 = no LDS reads (fake corners), 64 = no accumulation of the pose sums, 128 = the lower plane's two pairs are copies of the upper plane's (4 LDS reads per voxel instead of 8: the upper bound of carrying the upper plane's pairs into the next step; timing / power only)
 #endif
 #ifndef TRX_ZS_MIN_WAVES
 #define TRX_ZS_MIN_WAVES 4
@@ -146,7 +146,7 @@ static bool zs_shape_ok(const trx_volumes &v)
 // body agree; zstream_body's own per-anchor test (exact, with the actual corners) is implied by this one - the bounds below are its
 // worst case over the alignment of the origin.
 template <class C>
-__device__ __forceinline__ bool zs_fits_len(const float *__restrict__ th, float fD, float fH, float fW, int len)
+__host__ __device__ __forceinline__ bool zs_fits_len(const float *__restrict__ th, float fD, float fH, float fW, int len)
 {
     const float ex = (float)(C::TX - 1), ey = (float)(C::TY - 1), ez = (float)(len - 1);
     const float sx = fabsf(th[0]) * ex + fabsf(th[1] * fW / fH) * ey + fabsf(th[2] * fW / fD) * ez;
@@ -157,7 +157,7 @@ __device__ __forceinline__ bool zs_fits_len(const float *__restrict__ th, float 
 }
 // Number of sub-segments (1, 2, 4 or 8) a block of `planes_per_seg` planes re-anchors its window in; 0: the pair does not fit.
 template <class C>
-__device__ __forceinline__ int zs_nsub(const float *__restrict__ th, float fD, float fH, float fW, int planes_per_seg)
+__host__ __device__ __forceinline__ int zs_nsub(const float *__restrict__ th, float fD, float fH, float fW, int planes_per_seg)
 {
     if (zs_fits_len<C>(th, fD, fH, fW, planes_per_seg)) return 1;
     if (planes_per_seg >= 64 && zs_fits_len<C>(th, fD, fH, fW, (planes_per_seg + 1) / 2)) return 2;
@@ -455,8 +455,12 @@ __device__ __forceinline__ void zstream_body(const trx_volumes &vol, const float
                 if (TRX_ZS_DBG & 32) {
                     f.r00 = f2{__int_as_float(aA), ix}; f.r01 = f2{iy, __int_as_float(aB)}; f.r10 = f2{iz, ix}; f.r11 = f2{iy, iz};
                 } else {
-                f.r00 = *(lds_f2)(unsigned)aA; f.r01 = *(lds_f2)(unsigned)(aA + C::BW * 4);
+                if (!(TRX_ZS_DBG & 128)) { f.r00 = *(lds_f2)(unsigned)aA; f.r01 = *(lds_f2)(unsigned)(aA + C::BW * 4); }
                 f.r10 = *(lds_f2)(unsigned)aB; f.r11 = *(lds_f2)(unsigned)(aB + C::BW * 4);
+                if (TRX_ZS_DBG & 128) {   // (opaque copies: the arithmetic on them stays)
+                    f.r00 = f.r10; f.r01 = f.r11;
+                    asm volatile("" : "+v"(f.r00.x), "+v"(f.r00.y), "+v"(f.r01.x), "+v"(f.r01.y), "+v"(aA));
+                }
                 }
                 f.fx = __builtin_amdgcn_fractf(ix); f.fy = __builtin_amdgcn_fractf(iy); f.fz = __builtin_amdgcn_fractf(iz);
                 return f;
