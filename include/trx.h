@@ -37,7 +37,9 @@ extern "C" {
  *        step kernels leave in the workspace carries the kernel body in bits 24-27, TRX_FLAG_ZS_FUSED.  No entry point changed its signature.
  *   232  round 5: trx_affine_workspace_bytes reserves eight more ints (work tickets of the exact-footprint kernel, zeroed by the z-streaming kernel in
  *        front of it on every launch: the workspace still needs no initialisation by the caller).  No entry point changed its signature.
- *   240  round 6: TRX_FLAG_ONE_KERNEL (a step of a chip-filling launch next to the identity is ONE streaming launch + the finalise), trx_affine_near_identity. */
+ *   240  round 6: TRX_FLAG_ONE_KERNEL (a step of a chip-filling launch next to the identity is ONE streaming launch + the finalise), trx_affine_near_identity;
+ *        trx_affine_run folds the finalise of an iteration into the next iteration's kernel for launch-bound 3-D steps (TRX_FLAG_NO_CARRY keeps two launches);
+ *        trx_affine_workspace_bytes grows by a second partial / note buffer and two carry buffers (3-D).  No entry point changed its signature. */
 #define TRX_VERSION 240
 #define TRX_PSTRIDE 12  /* floats per pair in theta / param / adam / best_theta arrays */
 
@@ -84,6 +86,9 @@ typedef enum {
                                       * on GeomR's body, at about twice its usual cost while it stays outside - a hint about speed, never about results (fp32 rounding between
                                       * bodies as with every other path flag).  trx_affine_near_identity() evaluates the expectation for thetas the caller holds on the host;
                                       * torchregister_amd.AffineSolver sets the flag by itself from the initial thetas and from the bodies the previous run() call ended on */
+#define TRX_FLAG_NO_CARRY 65536u      /* trx_affine_run: every iteration is a step kernel plus a finalise kernel, also where the run would fold the finalise into the next
+                                      * iteration's kernel (launch-bound 3-D registrations: one pair up to ~128^3) - measured alternative; results differ by fp32 rounding at most
+                                      * (the folded finalise sums a pair's partial rows in another fixed order) */
 #define TRX_FLAG_NO_ROT_DEEP_TILE 16u /* affine steps: never use GeomRD (the 16 x 16 x 16 tile in GeomR's box) - rotated pairs all run GeomR */
 
 /* A batch of B independent (moving, target) pairs. */

@@ -54,9 +54,12 @@ def oracle_check(mov, tgt, th, i, loss, grad, kw, floor=2e-4):
 SHAPE, B = (64, 128, 128), 16   # 16 pairs x 8 columns x 4 z segments: the smallest launch of tests/test_gpu_zstream.py that fills the chip
 
 
-def batch(seed):
+def batch(seed, rough=True):
+    """rough: + 0.1 sin(0.013 i) over the FLAT voxel index - smooth along x, a ~4-row ripple along y and z: the near-identity tests keep it (as
+    tests/test_gpu_zstream.py does), the rotated poses use smooth volumes (under a rotation the ripple turns into an fp32-vs-fp64 gap of 1e-3 of the
+    gradient in EVERY body and in the oracle's own fp32 run - tests/fuzz_affine.py, "smooth phantoms only")."""
     tgt = torch.cat([ph.blobs_fast(SHAPE, seed + i, device="cuda") for i in range(B)])
-    mov = torch.cat([ph.blobs_fast(SHAPE, seed + 50 + i, device="cuda") + 0.1 * ph.vol(SHAPE, 0.013 + 0.001 * i, "sin").cuda() for i in range(B)])
+    mov = torch.cat([ph.blobs_fast(SHAPE, seed + 50 + i, device="cuda") + (0.1 * ph.vol(SHAPE, 0.013 + 0.001 * i, "sin").cuda() if rough else 0.0) for i in range(B)])
     return mov, tgt
 
 
@@ -84,7 +87,7 @@ def test_stray_pairs_run_inside_the_kernel(eng, kw):
     """The flag FORCED on a batch in which every third pair is far outside the windows (general rotations, a zoom, a flip): those pairs run GeomR's body
     inside the streaming kernel ("tile-R"), the others stream; all of them against the three-kernel form (fp32 floors between bodies), and a streaming
     pair, a rotated pair and the flipped pair against the oracle."""
-    mov, tgt = batch(300)
+    mov, tgt = batch(300, rough=False)
     mats = [rot(0.5, 0.4, 0.3), rot(0, 0, 0.6) * 1.05, np.diag([1.3, 0.8, 1.1]), rot(0.7, 0.8, 0.6), np.diag([-1.0, 1.0, 1.0]), rot(0.2, 0.0, 0.0)]
     ths = []
     for i in range(B):
@@ -140,7 +143,7 @@ def test_a_run_follows_the_same_trajectory_and_the_policy_follows_the_run(eng):
     s.run(1)
     assert not s.one_kernel
     torch.cuda.synchronize()
-    assert "tile-R" not in s.bodies() and torch.isfinite(s.losses[:, :7]).all()
+    assert torch.isfinite(s.losses[:, :7]).all()   # (the three-kernel form ran this step: its tile kernel reports GeomR as "tile-R" too)
     # ... and back: a solver that starts rotated, is handed the identity, and finds the flag again after one call
     s2 = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0), lr=0.0, init=th_rot, capacity=8)
     s2.theta.copy_(eng.pad_theta(torch.eye(3, 4, device="cuda")[None].repeat(B, 1, 1), 3)); s2.param.copy_(s2.theta)
@@ -161,7 +164,8 @@ def test_near_identity_helper_is_the_kernels_test(eng):
 
     def helper(eps):
         th = torch.tensor(np.eye(3, 4) + eps * d, dtype=torch.float32)[None].repeat(B, 1, 1)
-        return bool(lib.trx_affine_near_identity(ctypes.byref(probe.vol), ctypes.c_void_p(eng.pad_theta(th, 3).data_ptr()))), th
+        padded = eng.pad_theta(th, 3)   # (host memory: kept alive across the call)
+        return bool(lib.trx_affine_near_identity(ctypes.byref(probe.vol), ctypes.c_void_p(padded.data_ptr()))), th
 
     lo, hi = 0.0, 0.5
     assert helper(lo)[0] and not helper(hi)[0]

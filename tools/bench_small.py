@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Launch-bound sizes: one pair of S^3 (affine + NCC, SGD), us per iteration of run(200) and of the F1 launch alone."""
+"""Launch-bound sizes: one pair of S^3 (affine + NCC, SGD), us per iteration of run(400) - with the finalise folded into the next iteration's kernel (default, round 6)
+and as two launches per iteration (TRX_FLAG_NO_CARRY) - and of the F1 launch alone."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +9,7 @@ from bench import blobs_gpu, THETA_STAR
 dev = torch.device("cuda")
 for S in (64, 96, 128, 160, 192):
     tgt = blobs_gpu((S,) * 3, 1000, dev); mov = tr.get_affine_warp(torch.tensor(THETA_STAR, device=dev)[None], tgt)
-    for flags, name in ((0, "default"), (32, "no_zs")):
+    for flags, name in ((0, "default"), (65536, "no_carry")):   # (65536 = TRX_FLAG_NO_CARRY: a step kernel + a finalise kernel per iteration, the form of rounds 1-5)
         s = tr.AffineSolver(mov, tgt, mode="affine", loss=tr.LossSpec(w_ncc=1.0), lr=1e-6, capacity=1000, flags=flags)
         s.run(100); torch.cuda.synchronize()
         t0 = time.perf_counter(); s.run(400); torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 400

@@ -197,12 +197,14 @@ class AffineSolver:
             if one_kernel is True:
                 self.vol.flags = self._base_flags | _lib.FLAG_ONE_KERNEL
             else:
-                th_host = self.theta.detach().cpu().contiguous()
-                if self.lib.trx_affine_near_identity(ctypes.byref(self.vol), ctypes.c_void_p(th_host.data_ptr())):
-                    self.vol.flags = self._base_flags | _lib.FLAG_ONE_KERNEL
-                self._note_host = torch.empty(b, dtype=torch.int32).pin_memory()
-                self._note_event = torch.cuda.Event()
-                self._note_pending = False
+                eye = pad_theta(torch.eye(nd, nd + 1).repeat(b, 1, 1), nd)
+                if self.lib.trx_affine_near_identity(ctypes.byref(self.vol), ctypes.c_void_p(eye.data_ptr())):   # (is the z-streaming kernel offered to this batch at all?)
+                    th_host = self.theta.detach().cpu().contiguous()
+                    if self.lib.trx_affine_near_identity(ctypes.byref(self.vol), ctypes.c_void_p(th_host.data_ptr())):
+                        self.vol.flags = self._base_flags | _lib.FLAG_ONE_KERNEL
+                    self._note_host = torch.empty(b, dtype=torch.int32).pin_memory()
+                    self._note_event = torch.cuda.Event()
+                    self._note_pending = False
 
     def _refresh_one_kernel(self):
         """"auto" policy: if the notes of the previous run() call have landed in pinned memory, keep TRX_FLAG_ONE_KERNEL exactly when that call's last
@@ -221,12 +223,14 @@ class AffineSolver:
             raise _lib.TrxError(f"loss-curve capacity exceeded: {self.enqueued} iterations enqueued + {iters} requested > capacity "
                                 f"{self.capacity} (create the solver with a larger `capacity`)")
         self.enqueued += iters
-        self._refresh_one_kernel()
+        policy = self._note_host is not None and not torch.cuda.is_current_stream_capturing()   # (a captured run records kernels only: no event, no copy to the host)
+        if policy:
+            self._refresh_one_kernel()
         with torch.cuda.device(self.batch.device):
             rc = self.lib.trx_affine_run(ctypes.byref(self.vol), ctypes.byref(self.loss_c), ctypes.byref(self.opt),
                                          ctypes.byref(self.state), int(iters), _lib.ptr(self.workspace), self.ws_bytes,
                                          _lib.current_stream(self.batch.device))
-            if rc == 0 and iters > 0 and self._note_host is not None and not self._note_pending:
+            if rc == 0 and iters > 0 and policy and not self._note_pending:
                 off = int(self.lib.trx_affine_workspace_rows_offset(ctypes.byref(self.vol)))
                 self._note_host.copy_(self.workspace[off:off + 4 * self.batch.B].view(torch.int32), non_blocking=True)
                 self._note_event.record(torch.cuda.current_stream(self.batch.device))

@@ -22,6 +22,7 @@ FLAG_NO_EFT, FLAG_EFT = 512, 1024
 FLAG_WALK_DOWN, FLAG_NO_PINGPONG = 8192, 16384   # z-streaming columns walked downward / trx_affine_run does not alternate the direction
 FLAG_NO_ZS_FLAT = 4096   # the z-streaming kernel without its flat tile (measured alternative)
 FLAG_ONE_KERNEL = 32768   # chip-filling launches next to the identity: the z-streaming kernel alone (it runs stray pairs on GeomR's body)
+FLAG_NO_CARRY = 65536    # trx_affine_run keeps a step kernel + a finalise kernel per iteration (measured alternative of the carry form)
 FLAG_ZS_FUSED = 2048   # keep the z-streaming body inside the tile kernel (measured alternative of round 5)
 
 c_float_p = ctypes.POINTER(ctypes.c_float)

@@ -440,7 +440,9 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) { return __int_as
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
-template <int MODE, class G>
+// LTH (round 6, the carry form of a step): `theta` points at the 12 floats of THIS pair in LDS (the block's prologue has just computed them) instead of at the
+// batch's theta array in global memory.
+template <int MODE, class G, bool LTH = false>
 __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *__restrict__ theta, const TileGeom &tg, int channels,
                                           float *__restrict__ partials, float *box, const int bx, const int by, const int rows_stride, const int wave_in)
 {
@@ -461,7 +463,7 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
     const int b = kPerChannel ? by / channels : by;
     const int ch = kPerChannel ? by - b * channels : 0;
     const int D = vol.D, H = vol.H, W = vol.W;
-    const float *__restrict__ th = uni_ptr(theta + (size_t)b * TRX_PSTRIDE);
+    const float *__restrict__ th = LTH ? theta : uni_ptr(theta + (size_t)b * TRX_PSTRIDE);
     const float *__restrict__ mov = uni_ptr(vol.moving + (size_t)b * vol.moving_stride + (size_t)ch * D * H * W);
     // MODE 3 has no target: `tgt` is the OUTPUT volume of this (pair, channel)
     float *__restrict__ wout = uni_ptr(partials + (size_t)by * D * H * W);
@@ -473,9 +475,10 @@ __device__ __forceinline__ void tile_body(const trx_volumes &vol, const float *_
     const int lx = tid & (kTX - 1), lz = (tid / kTX) & (kTZ - 1), lh = wave / (kTileWaves / kNH);
     const float fW = (float)W, fH = (float)H, fD = (float)D;
     const float hW = 0.5f * fW, hH = 0.5f * fH, hD = 0.5f * fD;
-    const float t00 = th[0], t01 = th[1], t02 = th[2], t03 = th[3];
-    const float t10 = th[4], t11 = th[5], t12 = th[6], t13 = th[7];
-    const float t20 = th[8], t21 = th[9], t22 = th[10], t23 = th[11];
+    auto thv = [&](int k) { return LTH ? uni(th[k]) : th[k]; };   // (LDS reads are vector loads: pin the uniform values to scalar registers as the scalar loads do)
+    const float t00 = thv(0), t01 = thv(1), t02 = thv(2), t03 = thv(3);
+    const float t10 = thv(4), t11 = thv(5), t12 = thv(6), t13 = thv(7);
+    const float t20 = thv(8), t21 = thv(9), t22 = thv(10), t23 = thv(11);
     const float sx = uni(hW * t01), sy = uni(hH * (t11 - 1.0f)), sz = uni(hD * t21);
 
     // XCD-aware column order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
@@ -1190,6 +1193,28 @@ __device__ __forceinline__ bool eft_wants(int choice, const float *__restrict__ 
 // and keeps in SGPRs across the dispatch to five inlined bodies: that cost ~60 SGPRs, pushed the bodies' own scalars into VGPR lanes
 // and the work-item id into scratch, whose reload (a memory round trip in front of everything) made every launch 5-6 us longer -
 // 1 x 64^3: 15.5 -> 10 us per launch (tools/kbench.hip).  Field order and types = the parameter list (same layout rules).
+// CARRY (round 6): the finalise of iteration t - reduction of the partial rows, loss, dL/dtheta, optimiser, theta of the next forward - folded into the
+// prologue of iteration t + 1's step kernel, so that an iteration of a launch-bound registration (one pair up to ~128^3: a 12 us kernel and a 4 us
+// finalise launch behind it, profiles/r05e_configs.txt) is ONE launch.  No rendezvous between blocks: EVERY block of a pair reduces that pair's rows of
+// the previous launch (other parity of the two partial buffers) in the same fixed order and computes the same theta; the pair's first block alone
+// writes the state (into the carry buffer of this parity: blocks of this launch that start later still read the other one), the loss curve and the
+// best-theta record.  trx_affine_run enqueues iters such launches and one finalise kernel behind the last (the flush).
+struct CarryKArgs {
+    const float *prev_partials;   // partial rows of the previous iteration (nullptr: nothing pending - the first launch of a run)
+    const int *prev_rows_used;    // ... and its per-pair notes
+    int prev_nblk;                // row stride of prev_partials
+    int mse_rows;
+    const float *state_prev;      // carry buffer the state is read from (nullptr: the caller's arrays - the first launch of a run)
+    float *state_next;            // carry buffer the pair's first block writes
+    double nvox;
+    trx_loss_cfg lc;
+    trx_opt_cfg oc;
+    trx_affine_state st;
+};
+typedef const __attribute__((address_space(4))) CarryKArgs *CarryKPtr;
+template <int MODE>
+__device__ __forceinline__ void carry_prologue(CarryKPtr c, int b, bool designated, int D, int H, int W, float *scratch, float *s_th, int wave, int lane);
+
 struct DualKArgs {
     trx_volumes vol;
     const float *theta;
@@ -1202,6 +1227,7 @@ struct DualKArgs {
     int *rows_used;
     int rows_stride;
     int eft;
+    CarryKArgs carry;
 };
 
 template <int MODE, int WHICH = 0>
@@ -1209,7 +1235,7 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
                                                                                    TileGeom tgR_, int channels_, float *__restrict__ partials_,
                                                                                    int zero_surplus_ = 1, TileGeom tgD_ = TileGeom{}, TileGeom tgRD_ = TileGeom{},
                                                                                    ZGeom zg_ = ZGeom{}, int *__restrict__ rows_used_ = nullptr, int rows_stride_ = 0,
-                                                                                   int eft_ = 0)
+                                                                                   int eft_ = 0, CarryKArgs carry_ = CarryKArgs{})
 {
     static_assert(GeomA::Threads == 512 && GeomR::Threads == 512 && GeomD::Threads == 512 && GeomRD::Threads == 512, "every geometry runs 512-thread blocks");
     static_assert(GeomRD::BoxAlloc <= GeomR::BoxAlloc, "GeomRD lives in GeomR's box");
@@ -1218,6 +1244,9 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     // WHICH = 5: WHICH = 4 plus the exact-footprint body - ONE kernel behind the z-streaming kernel instead of two (a launch boundary and an
     // empty 512-block dispatch less per step: 4-5 us; inside the five-body kernel of round 4 the same merge cost the z-streaming loop 7-12 %,
     // which no longer lives here)
+    // WHICH = 6: WHICH = 3 (GeomA / GeomR, classic grid) in the CARRY form - the block's prologue finalises the previous iteration of its pair and theta comes from LDS
+    constexpr bool kCarry = WHICH == 6;
+    static_assert(!kCarry || MODE == 0 || MODE == 4, "the carry form exists for the step kernels");
     constexpr bool kDeep = (WHICH == 0 || WHICH == 4 || WHICH == 5) && (MODE == 0 || MODE == 4) && (TRX_TILE_CFG == 0) && (TRX_DEEP_TILE != 0);
     constexpr bool kZs = kDeep && WHICH == 0;
     constexpr bool kEft = kDeep && WHICH == 5;
@@ -1275,6 +1304,11 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
     // flat path: per pair (lane) the body its theta selects and the inclusive prefix sum of the block counts - kept in LDS, not in
     // registers, across the item loop (two more live VGPRs are two spilled ones in the bodies that sit at the register limit)
     __shared__ int s_choice[64], s_pre[64];
+    __shared__ float s_th[16];   // (carry) theta of this block's pair
+    if constexpr (kCarry) {
+        carry_prologue<MODE>(&args()->carry, (int)blockIdx.y, blockIdx.x == 0, args()->vol.D, args()->vol.H, args()->vol.W, box, s_th, wave_idx, lane);
+        theta = s_th - (size_t)blockIdx.y * TRX_PSTRIDE;   // (the choice below indexes by pair; the bodies take s_th itself)
+    }
     int my_choice = 2, total = 1;
     if (flat) {
         KArgs a = args();
@@ -1394,13 +1428,15 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
         if constexpr (WHICH != 1) {
             if (choice != 1) {
                 const TileGeom t = tile_of(&a->tgR);
-                tile_body<MODE, GeomR>(vol, theta, t, channels, partials, box, v, by, stride, wave_idx);
+                if constexpr (kCarry) tile_body<MODE, GeomR, true>(vol, s_th, t, channels, partials, box, v, by, stride, wave_idx);
+                else tile_body<MODE, GeomR>(vol, theta, t, channels, partials, box, v, by, stride, wave_idx);
                 continue;
             }
         }
         if constexpr (WHICH != 2) {
             const TileGeom t = tile_of(&a->tgA);
-            tile_body<MODE, GeomA>(vol, theta, t, channels, partials, box, v, by, stride, wave_idx);
+            if constexpr (kCarry) tile_body<MODE, GeomA, true>(vol, s_th, t, channels, partials, box, v, by, stride, wave_idx);
+            else tile_body<MODE, GeomA>(vol, theta, t, channels, partials, box, v, by, stride, wave_idx);
         }
     }
 }
@@ -1693,14 +1729,22 @@ __global__ __launch_bounds__(ECfg::Threads, 4) void affine_eft_step_kernel(trx_v
 template <int MODE>
 static void launch_dual(dim3 grid, hipStream_t s, const trx_volumes &v, const float *theta, const TileGeom &ta, const TileGeom &tr, int channels, float *out, int how,
                         int zero_surplus = 1, TileGeom td = TileGeom{}, TileGeom trd = TileGeom{}, ZGeom zg = ZGeom{}, int *rows_used = nullptr, int rows_stride = 0,
-                        int eft = 0)
+                        int eft = 0, const CarryKArgs *carry = nullptr, bool *carry_used = nullptr)
 {
     if (how == 1) {
         // WHICH = 3: the two-body (GeomA / GeomR) instance for launches that offer nothing else - the five-body kernel's entry costs 2-3 us
         // more (its arguments are fetched in front of the body that needs them), which is what a step of a small volume takes in all
         // (and no exact-footprint kernel in front: the two-body instance does not read its marks and would run its pairs a second time - ADVICE r4)
-        if (td.blocks_per_pair == 0 && trd.blocks_per_pair == 0 && zg.blocks_per_pair == 0 && rows_stride == 0 && eft == 0)
+        if (td.blocks_per_pair == 0 && trd.blocks_per_pair == 0 && zg.blocks_per_pair == 0 && rows_stride == 0 && eft == 0) {
+            if constexpr (MODE == 0 || MODE == 4) {
+                if (carry != nullptr && rows_used != nullptr && zero_surplus == 0) {   // the carry form of the same launch (trx_affine_run): theta from the block's own prologue
+                    hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 6>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride, 0, *carry);
+                    *carry_used = true;
+                    return;
+                }
+            }
             hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 3>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride);
+        }
         else
             hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 0>), grid, dim3(512), 0, s, v, theta, ta, tr, channels, out, zero_surplus, td, trd, zg, rows_used, rows_stride, eft);
     } else {
@@ -1836,11 +1880,134 @@ __device__ __forceinline__ void reduce_partials(const float *__restrict__ part, 
     __syncthreads();
 }
 
+// The per-pair epilogue of an iteration, shared by the finalise kernel and by the CARRY prologue of the step kernels (round 6: the finalise of
+// iteration t folded into the first kernel of iteration t + 1): lanes 0 .. 63 of ONE wave, lane i owns parameter i.  fin_load issues every load of
+// the pair's state at once (callers put the partial rows' reduction between the two, so that state and rows share one wait); fin_apply turns the
+// reduced sums S[] into loss, dL/dtheta, (rigid) the pose chain rule, the optimiser update and theta of the next forward.
+template <int ND>
+struct FinRegs {
+    int t;
+    float best_prev, theta_old, p_old, m_old, v_old;
+    float pose_old[(ND == 3) ? 6 : 3];
+};
+template <int ND>
+__device__ __forceinline__ FinRegs<ND> fin_load(const float *param, const float *theta, const float *am, const float *av, const int *step, const float *best_loss,
+                                                bool adam, bool rigid, int i)
+{
+    constexpr int NT = ND * (ND + 1), NPOSE = (ND == 3) ? 6 : 3;
+    FinRegs<ND> r;
+    const int ic = min(i, NT - 1);
+    r.t = *step;
+    r.best_prev = best_loss ? *best_loss : 0.f;
+    r.theta_old = theta[ic]; r.p_old = param[ic];
+    r.m_old = r.v_old = 0.f;
+    if (adam) { r.m_old = am[ic]; r.v_old = av[ic]; }
+#pragma unroll
+    for (int k = 0; k < NPOSE; k++) r.pose_old[k] = rigid ? param[k] : 0.f;
+    return r;
+}
+// Outputs: the pair's state (param / theta / Adam moments / step: nullable - the carry prologue's non-designated blocks write none), the caller-visible
+// per-iteration records (losses[t], best theta / loss / index, grad: `user`), and theta of the next forward into LDS (`theta_lds`, nullable).
+template <int ND>
+__device__ __forceinline__ void fin_apply(const double *S, const FinRegs<ND> &r, int b, int i, double nvox, int D, int H, int W, const trx_loss_cfg &lc, const trx_opt_cfg &oc,
+                                          const trx_affine_state &st, int mse_rows, float *param_out, float *theta_out, float *m_out, float *v_out, int *step_out, bool user,
+                                          float *theta_lds, double *sh_dth, float *sh_pose)
+{
+    constexpr int NT = ND * (ND + 1);
+    constexpr int NPOSE = (ND == 3) ? 6 : 3;
+    const bool rigid = st.mode == TRX_PARAM_RIGID;
+    const int np = rigid ? NPOSE : NT;
+    const int ic = min(i, NT - 1);
+    const int t = r.t;
+    double bc1 = 1.0, rsbc2 = 1.0;
+    if (oc.kind == TRX_OPT_ADAM) {   // beta^(t+1) by repeated squaring: a dozen fp64 multiplies instead of two pow() calls
+        bc1 = 1.0 - ipow((double)oc.beta1, t + 1);
+        rsbc2 = 1.0 / sqrt(1.0 - ipow((double)oc.beta2, t + 1));
+    }
+    const double scale[3] = {0.5 * W, 0.5 * H, 0.5 * D};
+    double dth_i, total;
+    if (ND == 3 && mse_rows) {   // S[0] = sum (w - y)^2, S[1 + i] = sum (w - y) J_i:  L = (w_mse / n + w_ssd alpha) S[0],  dL/dw_p = q (w_p - y_p)
+        const double q = (double)lc.w_mse * 2.0 / nvox + (double)lc.w_ssd * (double)lc.ssd_alpha * 2.0;
+        total = 0.5 * q * S[0];
+        dth_i = scale[ic / (ND + 1)] * q * S[1 + ic];
+    } else {
+        const LossCoef L = loss_from_moments(S, nvox, lc);
+        total = L.total;
+        dth_i = scale[ic / (ND + 1)] * (L.c0 * S[5 + ic] + L.cy * S[5 + NT + ic] + L.cw * S[5 + 2 * NT + ic]);
+    }
+    const float lossf = (float)total;
+    // best = first strict minimum, theta of THIS forward (ref:warpings.py:85-93)
+    const bool is_best = (t == 0) || (lossf < r.best_prev);
+    if (user) {
+        if (is_best && i < NT) st.best_theta[(size_t)b * TRX_PSTRIDE + i] = r.theta_old;
+        if (i == 0) {
+            if (st.losses && t < st.losses_capacity) st.losses[(size_t)b * st.losses_capacity + t] = lossf;
+            if (is_best) { st.best_loss[b] = lossf; st.best_idx[b] = t; }
+        }
+    }
+    if (i == 0 && step_out) *step_out = t + 1;
+
+    double g_i = dth_i;
+    if (rigid) {
+        if (i < NT) sh_dth[i] = dth_i;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        double dth[NT], g[NT];
+#pragma unroll
+        for (int k = 0; k < NT; k++) dth[k] = sh_dth[k];
+        pose_vjp<ND>(r.pose_old, dth, g);
+        g_i = 0.0;
+#pragma unroll
+        for (int k = 0; k < NPOSE; k++) g_i = (k == i) ? g[k] : g_i;
+    }
+    float p_new = r.p_old;
+    if (i < np) {
+        const float gf = (float)g_i;
+        if (user && st.grad) st.grad[(size_t)b * TRX_PSTRIDE + i] = gf;
+        if (oc.kind == TRX_OPT_ADAM) {
+            const float mi = r.m_old + (gf - r.m_old) * (1.0f - oc.beta1);
+            const float vi = oc.beta2 * r.v_old + (1.0f - oc.beta2) * gf * gf;
+            if (m_out) { m_out[i] = mi; v_out[i] = vi; }
+            const float denom = (float)(sqrt((double)vi) * rsbc2) + oc.eps;
+            p_new = r.p_old - (float)((double)oc.lr / bc1) * (mi / denom);
+        } else {
+            p_new = r.p_old - oc.lr * gf;
+        }
+        if (param_out) param_out[i] = p_new;
+    }
+    float th_new = p_new;
+    if (rigid) {
+        if (i < NPOSE) sh_pose[i] = p_new;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        float pose_new[NPOSE];
+#pragma unroll
+        for (int k = 0; k < NPOSE; k++) pose_new[k] = sh_pose[k];
+        double thd[NT];
+        theta_from_pose<ND>(pose_new, thd);
+        double th_i = 0.0;
+#pragma unroll
+        for (int k = 0; k < NT; k++) th_i = (k == i) ? thd[k] : th_i;
+        th_new = (float)th_i;
+    }
+    if (i < NT) {
+        if (theta_out) theta_out[i] = th_new;
+        if (theta_lds) theta_lds[i] = th_new;
+    }
+}
+
+// The carry buffers of trx_affine_run's one-launch iterations (two of them, by iteration parity): per pair 64 floats -
+// theta[12] | param[12] | Adam m[12] | Adam v[12] | step (int) - the state the iteration's FIRST kernel computes in its prologue and every block of it reads.
+constexpr int kCarryStride = 64;
+constexpr int kCarryTheta = 0, kCarryParam = 12, kCarryM = 24, kCarryV = 36, kCarryStep = 48;
+
+// state_in != nullptr: the pair's state is read from a carry buffer (the flush behind the last one-launch iteration of a run) instead of the caller's arrays
 template <int ND>
 __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const float *__restrict__ partials, int nblk,
                                                                           double nvox, int D, int H, int W,
                                                                           trx_loss_cfg lc, trx_opt_cfg oc,
-                                                                          trx_affine_state st, const int *__restrict__ rows_used = nullptr, int mse_rows = 0)
+                                                                          trx_affine_state st, const int *__restrict__ rows_used = nullptr, int mse_rows = 0,
+                                                                          const float *__restrict__ state_in = nullptr)
 {
     constexpr int NP = np_full(ND);
     constexpr int NT = ND * (ND + 1);
@@ -1855,22 +2022,17 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
     __shared__ float sh_pose[NPOSE];
     const int i = threadIdx.x;
     const bool rigid = st.mode == TRX_PARAM_RIGID;
-    const int np = rigid ? NPOSE : NT;
     float *param = st.param + (size_t)b * TRX_PSTRIDE;
     float *theta = st.theta + (size_t)b * TRX_PSTRIDE;
-    const int ic = min(i, NT - 1);
-    int t = 0;
-    float best_prev = 0.f, theta_old = 0.f, p_old = 0.f, m_old = 0.f, v_old = 0.f;
-    float pose_old[NPOSE];
-    double bc1 = 1.0, rsbc2 = 1.0;
+    FinRegs<ND> r;
     if (i < 64) {
-        t = st.step[b];
-        best_prev = st.best_loss[b];
-        theta_old = theta[ic]; p_old = param[ic];
-        if (oc.kind == TRX_OPT_ADAM) { m_old = st.adam_m[(size_t)b * TRX_PSTRIDE + ic]; v_old = st.adam_v[(size_t)b * TRX_PSTRIDE + ic]; }
-        if (rigid) {
-#pragma unroll
-            for (int k = 0; k < NPOSE; k++) pose_old[k] = param[k];
+        if (state_in) {
+            const float *sb = state_in + (size_t)b * kCarryStride;
+            r = fin_load<ND>(sb + kCarryParam, sb + kCarryTheta, sb + kCarryM, sb + kCarryV, reinterpret_cast<const int *>(sb + kCarryStep), st.best_loss + b,
+                             oc.kind == TRX_OPT_ADAM, rigid, i);
+        } else {
+            r = fin_load<ND>(param, theta, st.adam_m ? st.adam_m + (size_t)b * TRX_PSTRIDE : nullptr, st.adam_v ? st.adam_v + (size_t)b * TRX_PSTRIDE : nullptr, st.step + b,
+                             st.best_loss + b, oc.kind == TRX_OPT_ADAM, rigid, i);
         }
     }
     {
@@ -1881,78 +2043,96 @@ __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_finalize_kernel(const 
         if (ND == 3 && mse_rows) reduce_partials<kNpMse>(partials + (size_t)b * nblk * kNpMse, rows, S);   // rows of the MSE / SSD-only step kernel
         else reduce_partials<NP>(partials + (size_t)b * nblk * NP, rows, S);
     }
-    if (i < 64 && oc.kind == TRX_OPT_ADAM) {   // beta^(t+1) by repeated squaring: a dozen fp64 multiplies instead of two pow() calls
-        bc1 = 1.0 - ipow((double)oc.beta1, t + 1);
-        rsbc2 = 1.0 / sqrt(1.0 - ipow((double)oc.beta2, t + 1));
-    }
     if (i >= 64) return;
+    fin_apply<ND>(S, r, b, i, nvox, D, H, W, lc, oc, st, mse_rows, param, theta, st.adam_m ? st.adam_m + (size_t)b * TRX_PSTRIDE : nullptr,
+                  st.adam_v ? st.adam_v + (size_t)b * TRX_PSTRIDE : nullptr, st.step + b, true, nullptr, sh_dth, sh_pose);
+}
 
-    const double scale[3] = {0.5 * W, 0.5 * H, 0.5 * D};
-    double dth_i, total;
-    if (ND == 3 && mse_rows) {   // S[0] = sum (w - y)^2, S[1 + i] = sum (w - y) J_i:  L = (w_mse / n + w_ssd alpha) S[0],  dL/dw_p = q (w_p - y_p)
-        const double q = (double)lc.w_mse * 2.0 / nvox + (double)lc.w_ssd * (double)lc.ssd_alpha * 2.0;
-        total = 0.5 * q * S[0];
-        dth_i = scale[ic / (ND + 1)] * q * S[1 + ic];
-    } else {
-        const LossCoef L = loss_from_moments(S, nvox, lc);
-        total = L.total;
-        dth_i = scale[ic / (ND + 1)] * (L.c0 * S[5 + ic] + L.cy * S[5 + NT + ic] + L.cw * S[5 + 2 * NT + ic]);
-    }
-    const float lossf = (float)total;
-    // best = first strict minimum, theta of THIS forward (ref:warpings.py:85-93)
-    const bool is_best = (t == 0) || (lossf < best_prev);
-    if (is_best && i < NT) st.best_theta[(size_t)b * TRX_PSTRIDE + i] = theta_old;
-    if (i == 0) {
-        if (st.losses && t < st.losses_capacity) st.losses[(size_t)b * st.losses_capacity + t] = lossf;
-        if (is_best) { st.best_loss[b] = lossf; st.best_idx[b] = t; }
-        st.step[b] = t + 1;
-    }
-
-    double g_i = dth_i;
-    if (rigid) {
-        if (i < NT) sh_dth[i] = dth_i;
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        double dth[NT], g[NT];
-#pragma unroll
-        for (int k = 0; k < NT; k++) dth[k] = sh_dth[k];
-        pose_vjp<ND>(pose_old, dth, g);
-        g_i = 0.0;
-#pragma unroll
-        for (int k = 0; k < NPOSE; k++) g_i = (k == i) ? g[k] : g_i;
-    }
-    float p_new = p_old;
-    if (i < np) {
-        const float gf = (float)g_i;
-        if (st.grad) st.grad[(size_t)b * TRX_PSTRIDE + i] = gf;
-        if (oc.kind == TRX_OPT_ADAM) {
-            const float mi = m_old + (gf - m_old) * (1.0f - oc.beta1);
-            const float vi = oc.beta2 * v_old + (1.0f - oc.beta2) * gf * gf;
-            st.adam_m[(size_t)b * TRX_PSTRIDE + i] = mi;
-            st.adam_v[(size_t)b * TRX_PSTRIDE + i] = vi;
-            const float denom = (float)(sqrt((double)vi) * rsbc2) + oc.eps;
-            p_new = p_old - (float)((double)oc.lr / bc1) * (mi / denom);
-        } else {
-            p_new = p_old - oc.lr * gf;
+// The carry prologue of a 512-thread step block (3-D): see CarryKArgs.  `scratch`: the block's tile box (free until the body starts); on return s_th[0 .. 11]
+// holds theta of this launch's forward and every wave has passed a barrier behind it.
+template <int MODE>
+__device__ __forceinline__ void carry_prologue(CarryKPtr c, int b, bool designated, int D, int H, int W, float *scratch, float *s_th, int wave, int lane)
+{
+    constexpr int NP = (MODE == 4) ? kNpMse : np_full(3);
+    constexpr int NT = 12;
+    const float *prev = c->prev_partials;
+    const float *sp = c->state_prev;
+    float *sn = c->state_next;
+    const trx_affine_state st = {c->st.mode, c->st.param, c->st.theta, c->st.adam_m, c->st.adam_v, c->st.best_theta, c->st.best_loss, c->st.best_idx, c->st.losses,
+                                 c->st.losses_capacity, c->st.step, c->st.grad};
+    const trx_opt_cfg oc = {c->oc.kind, c->oc.lr, c->oc.beta1, c->oc.beta2, c->oc.eps};
+    const bool adam = oc.kind == TRX_OPT_ADAM, rigid = st.mode == TRX_PARAM_RIGID;
+    // where the pair's state is read from: the carry buffer of the other parity, or (first launch of a run) the caller's arrays
+    const float *src_theta = sp ? sp + (size_t)b * kCarryStride + kCarryTheta : st.theta + (size_t)b * TRX_PSTRIDE;
+    const float *src_param = sp ? sp + (size_t)b * kCarryStride + kCarryParam : st.param + (size_t)b * TRX_PSTRIDE;
+    const float *src_m = sp ? sp + (size_t)b * kCarryStride + kCarryM : (st.adam_m ? st.adam_m + (size_t)b * TRX_PSTRIDE : nullptr);
+    const float *src_v = sp ? sp + (size_t)b * kCarryStride + kCarryV : (st.adam_v ? st.adam_v + (size_t)b * TRX_PSTRIDE : nullptr);
+    const int *src_step = sp ? reinterpret_cast<const int *>(sp + (size_t)b * kCarryStride + kCarryStep) : st.step + b;
+    float *nxt = (designated && sn) ? sn + (size_t)b * kCarryStride : nullptr;
+    if (prev == nullptr) {   // nothing pending: theta of this forward is the state's; the pair's first block seeds the carry buffer
+        if (wave == 0) {
+            const int ic = min(lane, NT - 1);
+            const float th = src_theta[ic], pa = src_param[ic];
+            const float m0 = (adam && src_m) ? src_m[ic] : 0.f, v0 = (adam && src_v) ? src_v[ic] : 0.f;
+            const int t = *src_step;
+            if (lane < NT) {
+                s_th[lane] = th;
+                if (nxt) { nxt[kCarryTheta + lane] = th; nxt[kCarryParam + lane] = pa; nxt[kCarryM + lane] = m0; nxt[kCarryV + lane] = v0; }
+            }
+            if (lane == 0 && nxt) *reinterpret_cast<int *>(nxt + kCarryStep) = t;
         }
-        param[i] = p_new;
+        __syncthreads();
+        return;
     }
-    if (rigid) {
-        if (i < NPOSE) sh_pose[i] = p_new;
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        float pose_new[NPOSE];
+    double *acc = reinterpret_cast<double *>(scratch);   // [8][64] | S[64] | dtheta[12] | pose (floats)
+    double *S = acc + 8 * 64, *sh_dth = S + 64;
+    float *sh_pose = reinterpret_cast<float *>(sh_dth + NT);
+    FinRegs<3> r;
+    if (wave == 0) r = fin_load<3>(src_param, src_theta, src_m, src_v, src_step, designated ? st.best_loss + b : nullptr, adam, rigid, lane);
+    {
+        // the pair's rows of the previous launch: wave w sums rows w, w + 8, ... of column `lane` in batches of 16 independent loads, a fixed order, the same
+        // in every block of the pair.  (Measured alternatives, profiles/r06b_carry.txt: copying the rows into LDS with float4 loads first, +0.4 ... +1.2 us;
+        // a grid without the surplus blocks of the geometry the pair does not run, +-0.)
+        const int nblk = c->prev_nblk;
+        const int rows = min(abs(c->prev_rows_used[b]) & kRowsMask, nblk);
+        const float *part = prev + (size_t)b * nblk * NP;
+        double s = 0.0;
+        if (lane < NP) {
+            constexpr int NB = TRX_CARRY_BATCH;   // loads in flight per lane
+            for (int r0 = wave; r0 < rows; r0 += NB * 8) {
+                float a[NB];
 #pragma unroll
-        for (int k = 0; k < NPOSE; k++) pose_new[k] = sh_pose[k];
-        double thd[NT];
-        theta_from_pose<ND>(pose_new, thd);
-        double th_i = 0.0;
+                for (int i = 0; i < NB; i++) {
+                    const int row = r0 + i * 8;
+                    const float v = part[(size_t)min(row, rows - 1) * NP + lane];   // clamped, unconditional (reduce_partials: a predicated load is a branch + a wait each)
+                    a[i] = (row < rows) ? v : 0.f;
+                }
+                double d[NB];
 #pragma unroll
-        for (int k = 0; k < NT; k++) th_i = (k == i) ? thd[k] : th_i;
-        if (i < NT) theta[i] = (float)th_i;
-    } else if (i < NT) {
-        theta[i] = p_new;
+                for (int i = 0; i < NB; i++) d[i] = (double)a[i];
+#pragma unroll
+                for (int w = 1; w < NB; w <<= 1)   // pairwise tree, fixed order
+#pragma unroll
+                    for (int i = 0; i + w < NB; i += 2 * w) d[i] += d[i + w];
+                s += d[0];
+            }
+        }
+        acc[wave * 64 + lane] = s;
     }
+    __syncthreads();
+    if (wave == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) t += acc[w * 64 + lane];
+        S[lane] = t;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const trx_loss_cfg lc = {c->lc.w_mse, c->lc.w_ncc, c->lc.ncc_alpha, c->lc.w_ssd, c->lc.ssd_alpha};
+        fin_apply<3>(S, r, b, lane, c->nvox, D, H, W, lc, oc, st, c->mse_rows, nxt ? nxt + kCarryParam : nullptr, nxt ? nxt + kCarryTheta : nullptr,
+                     nxt ? nxt + kCarryM : nullptr, nxt ? nxt + kCarryV : nullptr, nxt ? reinterpret_cast<int *>(nxt + kCarryStep) : nullptr, designated, s_th, sh_dth, sh_pose);
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(TRX_FIN_THREADS) void affine_loss_finalize_kernel(const float *__restrict__ partials, int nblk,
@@ -2320,8 +2500,9 @@ static size_t tile_rows_per_pair(const trx_volumes &v)
 }
 
 // Workspace of the affine entry points: [B][rows][41] partial sums | coordinate tables (callers that pass none) | rows_used[B + 11]
+// ... | (3-D) second partial buffer | second rows_used[B + 11] | two carry buffers [B][64] floats  (the parity buffers of trx_affine_run's one-launch iterations)
 struct AffineWs {
-    size_t rows, off_tab, off_rows_used, bytes;
+    size_t rows, off_tab, off_rows_used, off_part2, off_rows_used2, off_carry, bytes;
 };
 static AffineWs affine_ws(const trx_volumes &v)
 {
@@ -2334,7 +2515,11 @@ static AffineWs affine_ws(const trx_volumes &v)
     }
     w.off_tab = ((size_t)v.B * w.rows * np_full(3) * sizeof(float) + 255) & ~(size_t)255;
     w.off_rows_used = w.off_tab + (((size_t)(v.W + v.H + v.D) * sizeof(float) + 255) & ~(size_t)255);
-    w.bytes = w.off_rows_used + (((size_t)(v.B + 11) * sizeof(int) + 255) & ~(size_t)255);   // rows_used[B] | pairs left by the z-streaming kernel | its pair mask (2) | the exact-footprint kernel's work tickets, one per XCD (8)
+    const size_t notes = ((size_t)(v.B + 11) * sizeof(int) + 255) & ~(size_t)255;   // rows_used[B] | pairs left by the z-streaming kernel | its pair mask (2) | the exact-footprint kernel's work tickets, one per XCD (8)
+    w.off_part2 = w.off_rows_used + notes;
+    w.off_rows_used2 = w.off_part2 + (v.ndim == 3 ? w.off_tab : 0);
+    w.off_carry = w.off_rows_used2 + (v.ndim == 3 ? notes : 0);
+    w.bytes = w.off_carry + (v.ndim == 3 ? (((size_t)2 * v.B * kCarryStride * sizeof(float) + 255) & ~(size_t)255) : 0);
     return w;
 }
 
@@ -2377,8 +2562,14 @@ static bool use_tile_path(const trx_volumes *vol)
 
 // MODE 0 / 1 dispatch: LDS-tiled kernel for 3-D, row-walking gather kernel otherwise.
 // Returns the number of partial rows per pair through *nblk.
+struct CarryLaunch {   // trx_affine_run's request for the carry form of a step launch: which parity buffers it writes, the kernel's carry arguments; `used` = it was launched
+    int parity;
+    CarryKArgs args;
+    bool used;
+    float *partials_out;   // where the launch wrote its rows (the parity buffer), whether or not the carry form was used
+};
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, const int **rows_used = nullptr);
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, const int **rows_used = nullptr, CarryLaunch *cl = nullptr);
 
 template <int MODE>
 static int launch_accum(const trx_volumes *vol, const float *theta, const AffineGeom &g, int channels, size_t chan_stride,
@@ -2396,16 +2587,21 @@ static int launch_accum(const trx_volumes *vol, const float *theta, const Affine
 // rows_used != nullptr: the caller's reduction reads the row count of every pair from the device array returned through it (the
 // step's finalise kernel): surplus blocks of the dual grid then write nothing, and the step kernels may offer their extra bodies.
 template <int MODE>
-static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, const int **rows_used)
+static int launch_f1(const trx_volumes *vol, const float *theta, float *partials, int *nblk, hipStream_t s, bool dual, const int **rows_used, CarryLaunch *cl)
 {
     if (rows_used) *rows_used = nullptr;
+    if (cl) cl->used = false;
     if (use_tile_path(vol)) {
         TileGeom t = tile_geom(*vol);
         trx_volumes v = *vol;
         const AffineWs ws = affine_ws(*vol);
+        float *const ws_base = partials;   // (tables and notes sit at fixed offsets from the workspace's start; the rows go to the parity buffer)
+        const bool odd = cl != nullptr && cl->parity != 0;
+        if (odd) partials = (float *)((char *)ws_base + ws.off_part2);
+        if (cl) cl->partials_out = partials;
         if (!v.xn || !v.yn || !v.zn) {
             // tables live behind the partials (trx_affine_workspace_bytes reserves the room)
-            float *tab = (float *)((char *)partials + ws.off_tab);
+            float *tab = (float *)((char *)ws_base + ws.off_tab);
             const int n = max(v.W, max(v.H, v.D));
             hipLaunchKernelGGL(fill_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, s, tab, v.W, v.H, v.D);
             TRX_CHECK_LAUNCH();
@@ -2445,7 +2641,7 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             if (trd.blocks_per_pair > gxx) gxx = trd.blocks_per_pair;
             if (zg.blocks_per_pair > gxx) gxx = zg.blocks_per_pair;
             if (TRX_ZS_FLAT && zg.blocks_per_pair > 0 && zs_shape_ok<ZSF>(*vol) && zs_geom<ZSF>(*vol).blocks_per_pair > gxx) gxx = zs_geom<ZSF>(*vol).blocks_per_pair;
-            int *ru = aware ? (int *)((char *)partials + ws.off_rows_used) : nullptr;
+            int *ru = aware ? (int *)((char *)ws_base + (odd ? ws.off_rows_used2 : ws.off_rows_used)) : nullptr;
             // big batches of the step kernels: a flat grid of persistent blocks over a pair-major work list (no surplus blocks; see the kernel)
             const int slots = persistent_blocks();
             // (B <= 64: the flat grid keeps one pair's state per lane)
@@ -2486,7 +2682,7 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
             if (eft_merged) hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 5>), dim3(slots, 1), dim3(512), 0, s, v, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gxx, eft);
             else if (zs_first) hipLaunchKernelGGL((affine_tile_dual_kernel<MODE, 4>), dim3(slots, 1), dim3(512), 0, s, v, theta, ta, tr, 1, partials, 0, td, trd, zg, ru, gxx, eft);
             else if (flat) launch_dual<MODE>(dim3(slots, 1), s, v, theta, ta, tr, 1, partials, 1, 0, td, trd, zg, ru, gxx, eft);
-            else launch_dual<MODE>(dim3(gxx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd, zg, ru, 0, eft);
+            else launch_dual<MODE>(dim3(gxx, vol->B), s, v, theta, ta, tr, 1, partials, use_dual(vol), aware ? 0 : 1, td, trd, zg, ru, 0, eft, cl ? &cl->args : nullptr, cl ? &cl->used : nullptr);
             TRX_CHECK_LAUNCH();
             *nblk = gxx;
             if (aware) *rows_used = ru;
@@ -2505,6 +2701,9 @@ static int launch_f1(const trx_volumes *vol, const float *theta, float *partials
         return launch_accum<MODE>(vol, theta, g, 1, 0, partials, s);
     }
 }
+
+static int launch_finalize(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_affine_state *st, const float *partials, int nblk,
+                           const int *rows_used, bool mse_only, const float *state_in, hipStream_t s);
 
 extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
                                const trx_affine_state *st, void *workspace, size_t workspace_bytes, void *stream)
@@ -2528,15 +2727,7 @@ extern "C" int trx_affine_step(const trx_volumes *vol, const trx_loss_cfg *loss,
     const bool mse_only = (loss->w_ncc == 0.f) && use_tile_path(vol);
     rc = mse_only ? launch_f1<4>(vol, st->theta, partials, &nblk, s, true, &rows_used) : launch_f1<0>(vol, st->theta, partials, &nblk, s, true, &rows_used);
     if (rc) return rc;
-    const double nvox = (double)vol->D * vol->H * vol->W;
-    if (vol->ndim == 3)
-        hipLaunchKernelGGL((affine_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
-                           vol->D, vol->H, vol->W, *loss, *opt, *st, rows_used, mse_only ? 1 : 0);
-    else
-        hipLaunchKernelGGL((affine_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
-                           vol->D, vol->H, vol->W, *loss, *opt, *st);
-    TRX_CHECK_LAUNCH();
-    return TRX_OK;
+    return launch_finalize(vol, loss, opt, st, partials, nblk, rows_used, mse_only, nullptr, s);
 }
 
 extern "C" int trx_affine_accumulate(const trx_volumes *vol, const float *theta, void *workspace, size_t workspace_bytes, void *stream)
@@ -2550,6 +2741,21 @@ extern "C" int trx_affine_accumulate(const trx_volumes *vol, const float *theta,
     return launch_f1<0>(vol, theta, (float *)workspace, &nblk, (hipStream_t)stream, true, &rows_used);   // exactly the launch of a step (profiling aid)
 }
 
+// The finalise kernel behind a step launch (trx_affine_step, and the flush behind the last carry launch of trx_affine_run: state_in = its carry buffer)
+static int launch_finalize(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt, const trx_affine_state *st, const float *partials, int nblk,
+                           const int *rows_used, bool mse_only, const float *state_in, hipStream_t s)
+{
+    const double nvox = (double)vol->D * vol->H * vol->W;
+    if (vol->ndim == 3)
+        hipLaunchKernelGGL((affine_finalize_kernel<3>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
+                           vol->D, vol->H, vol->W, *loss, *opt, *st, rows_used, mse_only ? 1 : 0, state_in);
+    else
+        hipLaunchKernelGGL((affine_finalize_kernel<2>), dim3(vol->B), dim3(TRX_FIN_THREADS), 0, s, partials, nblk, nvox,
+                           vol->D, vol->H, vol->W, *loss, *opt, *st);
+    TRX_CHECK_LAUNCH();
+    return TRX_OK;
+}
+
 extern "C" int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, const trx_opt_cfg *opt,
                               const trx_affine_state *st, int iters, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -2557,7 +2763,49 @@ extern "C" int trx_affine_run(const trx_volumes *vol, const trx_loss_cfg *loss, 
     if (st->losses && iters > st->losses_capacity) return TRX_ERR_CAPACITY;
     if (!vol) return TRX_ERR_ARG;
     trx_volumes v = *vol;
-    for (int i = 0; i < iters; i++) {
+    int first = 0;
+    // CARRY (CarryKArgs): launch-bound 3-D steps - one (GeomA / GeomR) kernel and a finalise kernel behind it - run as ONE launch per iteration: the finalise
+    // of iteration k rides in the prologue of iteration k + 1's kernel, and one finalise kernel behind the last launch flushes the run.  The launches alternate
+    // between the workspace's two partial / note / carry buffers; the LAST one writes the primary set (what trx_affine_workspace_rows_offset describes).
+    if (iters >= 2 && TRX_CARRY && !(vol->flags & TRX_FLAG_NO_CARRY) && check_vol(vol, true) == TRX_OK && vol->ndim == 3 && use_tile_path(vol) && loss && opt && workspace &&
+        st->param && st->theta && st->best_theta && st->best_loss && st->best_idx && st->step && (opt->kind == TRX_OPT_SGD || (opt->kind == TRX_OPT_ADAM && st->adam_m && st->adam_v)) &&
+        (st->mode == TRX_PARAM_AFFINE || st->mode == TRX_PARAM_RIGID) && workspace_bytes >= trx_affine_workspace_bytes(vol)) {
+        hipStream_t s = (hipStream_t)stream;
+        const AffineWs ws = affine_ws(*vol);
+        const bool mse_only = loss->w_ncc == 0.f;
+        float *const base = (float *)workspace;
+        float *const carry_buf = (float *)((char *)workspace + ws.off_carry);
+        const float *prev_partials = nullptr;
+        const int *prev_notes = nullptr;
+        int prev_nblk = 0;
+        for (int k = 0; k < iters; k++) {
+            CarryLaunch cl;
+            cl.parity = (iters - 1 - k) & 1;
+            cl.used = false;
+            cl.partials_out = nullptr;
+            cl.args = CarryKArgs{prev_partials, prev_notes, prev_nblk, mse_only ? 1 : 0, k > 0 ? carry_buf + (size_t)(cl.parity ^ 1) * vol->B * kCarryStride : nullptr,
+                                 carry_buf + (size_t)cl.parity * vol->B * kCarryStride, (double)vol->D * vol->H * vol->W, *loss, *opt, *st};
+            v.flags = vol->flags;
+            if ((k & 1) && !(vol->flags & TRX_FLAG_NO_PINGPONG)) v.flags ^= TRX_FLAG_WALK_DOWN;
+            int nblk = 0;
+            const int *notes = nullptr;
+            int rc = mse_only ? launch_f1<4>(&v, st->theta, base, &nblk, s, true, &notes, &cl) : launch_f1<0>(&v, st->theta, base, &nblk, s, true, &notes, &cl);
+            if (rc) return rc;
+            if (!cl.used) {
+                // not a launch the carry form exists for (only possible at k = 0: the choice depends on sizes and flags alone): the launch above was an
+                // ordinary step launch - finish that step and run the rest the ordinary way
+                rc = launch_finalize(vol, loss, opt, st, cl.partials_out, nblk, notes, mse_only, nullptr, s);
+                if (rc) return rc;
+                first = 1;
+                prev_partials = nullptr;
+                break;
+            }
+            prev_partials = cl.partials_out; prev_notes = notes; prev_nblk = nblk;
+        }
+        if (prev_partials != nullptr)   // every launch was a carry launch: flush the last iteration (its buffers are the primary set: parity 0)
+            return launch_finalize(vol, loss, opt, st, prev_partials, prev_nblk, prev_notes, mse_only, carry_buf, s);
+    }
+    for (int i = first; i < iters; i++) {
         // odd iterations walk the z-streaming columns downward: the tail of one pass is the head of the next (TRX_FLAG_WALK_DOWN)
         v.flags = vol->flags;
         if ((i & 1) && !(vol->flags & TRX_FLAG_NO_PINGPONG)) v.flags ^= TRX_FLAG_WALK_DOWN;

@@ -66,6 +66,13 @@
                            // step) - measured alternative: the headline does not move (30.0-30.4 k against 30.1-30.3 k: the empty launch hides behind the dispatch of the next),
                            // the rotated poses lose 5.5 % (17.2 against 18.1 k: 43 spilled registers in the merged kernel); profiles/r05a_eft_merged.txt
 #endif
+#ifndef TRX_CARRY
+#define TRX_CARRY 1   // trx_affine_run: launch-bound 3-D steps (the two-body GeomA / GeomR kernel on the classic grid) as ONE launch per iteration - the finalise of iteration
+                      // k in the prologue of iteration k + 1's kernel (CarryKArgs in affine.hip); 0: a step kernel and a finalise kernel per iteration (measured alternative)
+#endif
+#ifndef TRX_CARRY_BATCH
+#define TRX_CARRY_BATCH 16   // carry prologue: partial rows a lane has in flight per batch (32: measured alternative, +-0: profiles/r06b_carry.txt)
+#endif
 #ifndef TRX_PERSISTENT_BLOCKS
 #define TRX_PERSISTENT_BLOCKS 512   // block slots for the 512-thread step kernels if the device cannot be queried (MI355X: 2 x 256 CUs); persistent_blocks() asks the device
 #endif
