@@ -138,12 +138,16 @@ def test_cfg3_flow_ncc_smooth_10_iterations(eng, refs, optimizer, lr, shape):
     assert e <= b, ("flow", e, b)
 
 
-def test_cfg4_share_of_one_gpu_8x256_20_iterations(eng, refs):
+@pytest.mark.parametrize("walk", ["pingpong", "one-way"])
+def test_cfg4_share_of_one_gpu_8x256_20_iterations(eng, refs, walk):
+    """walk: trx_affine_run alternates the z-streaming kernel's walk direction from iteration to iteration (the product) / every iteration walks upward
+    (TRX_FLAG_NO_PINGPONG, the order of rounds 3-4): both against the same arbiter, so that the one-way order stays a tested path."""
+    from torchregister_amd import _lib
     iters, B = 20, 8
     mov, tgt = batch_of_pairs(B, CFG4_PAIRS)
     th0 = torch.stack([torch.from_numpy(tw.theta0_np(seed=i)) for i in range(B)])
     s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(w_ncc=1.0),
-                         optimizer="adam", lr=CFG4_LR, init=th0, capacity=iters)
+                         optimizer="adam", lr=CFG4_LR, init=th0, capacity=iters, flags=0 if walk == "pingpong" else _lib.FLAG_NO_PINGPONG)
     s.run(iters)
     torch.cuda.synchronize()
     rows = s.rows_used().tolist()
