@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised sweep of the CHIP-FILLING launches of the affine step (round 5): the z-streaming kernel in front (its 64 x 32 tile and its flat
-64 x 16 tile, walking up or down), the exact-footprint kernel and the tile kernel behind it, all in one launch per case.
+64 x 16 tile, walking up or down), the exact-footprint kernel and the tile kernel behind it, all in one launch per case - and, every other case, the one-kernel form of the same step (TRX_FLAG_ONE_KERNEL).
    python tests/fuzz_zs_flat.py [cases] [seed]
 Batches of 16 pairs of 64 x 128 x 128 or 8 pairs of 96 / 128 x 128 x 128 whose poses are drawn per pair from: the identity's neighbourhood, the
 convergence basin (rotations to 0.15 rad about z, zooms to 1.1, a little tilt), and general rotations.  Checker: the same launch restricted to
@@ -45,12 +45,14 @@ def run(n, seed, verbose=True):
         mov = torch.cat([ph.blobs_fast(shape, 3000 + 5 * it + (b % 3), device="cuda") + 0.1 * ph.vol(shape, 0.011 + 0.001 * (b % 5), "sin").cuda() for b in range(B)])
         kw = dict(w_ncc=float(rng.uniform(0.3, 1)), w_mse=float(rng.uniform(0, 1))) if rng.random() < 0.7 else dict(w_mse=1.0)
         down = bool(rng.integers(0, 2))
-        s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=_lib.FLAG_WALK_DOWN if down else 0)
+        # every other case in the ONE-KERNEL form (round 6: the z-streaming kernel alone, the pairs outside its windows on GeomR's body inside it)
+        s = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=_lib.FLAG_WALK_DOWN if down else 0,
+                             one_kernel=bool(it & 1))
         s.run(1)
         r = eng.AffineSolver(mov, tgt, mode="affine", loss=eng.LossSpec(**kw), lr=0.0, init=th, capacity=1, flags=_lib.FLAG_NO_ZSTREAM | _lib.FLAG_NO_EFT)
         r.run(1)
         torch.cuda.synchronize()
-        bodies = s.bodies()
+        bodies = [("one-kernel " if (it & 1) else "") + n for n in s.bodies()]
         for name in bodies:
             seen[name] = seen.get(name, 0) + 1
         for b in range(B):
