@@ -33,13 +33,15 @@ int main(int argc, char **argv)
     const float eps = argc > 3 ? (float)atof(argv[3]) : 0.004f;
     const int reps = argc > 4 ? atoi(argv[4]) : 100;
     const bool zonly = argc == 6;   // profiling runs: only the first z-streaming kernel
-    const size_t nvox = (size_t)S * S * S, n = nvox * B;
+    const size_t nvox = (size_t)S * S * S;
+    const size_t pad = getenv("ZB_PAD") ? (size_t)atol(getenv("ZB_PAD")) : 0;   // floats between the pairs' volumes (round 6: is the power-of-two pair stride a DRAM channel conflict?)
+    const size_t pstride = nvox + pad, n = pstride * B;
     std::vector<float> h(n);
     srand(1);
     // smooth-ish random volumes: random values low-pass filtered along x so that gradients are not pure noise
     for (size_t i = 0; i < n; i++) h[i] = (float)rand() / RAND_MAX;
     float *mov, *tgt, *theta, *partials;
-    CK(hipMalloc(&mov, n * 4)); CK(hipMalloc(&tgt, n * 4));
+    CK(hipMalloc(&mov, n * 4)); CK(hipMalloc(&tgt, n * 4 + (1 << 22)));
     CK(hipMemcpy(mov, h.data(), n * 4, hipMemcpyHostToDevice));
     for (size_t i = 0; i < n; i++) h[i] = (float)rand() / RAND_MAX;
     CK(hipMemcpy(tgt, h.data(), n * 4, hipMemcpyHostToDevice));
@@ -62,7 +64,7 @@ int main(int argc, char **argv)
     float *tab;
     CK(hipMalloc(&tab, 3 * S * 4));
     hipLaunchKernelGGL(trx::fill_tables_kernel, dim3((S + 255) / 256), dim3(256), 0, 0, tab, S, S, S);
-    trx_volumes vol = {mov, tgt, nvox, nvox, 3, B, S, S, S, tab, tab + S, tab + 2 * S, 0};
+    trx_volumes vol = {mov, tgt + (getenv("ZB_TOFF") ? atol(getenv("ZB_TOFF")) : 0), pstride, pstride, 3, B, S, S, S, tab, tab + S, tab + 2 * S, 0};
     const size_t prow = 8192;
     CK(hipMalloc(&partials, (size_t)B * prow * 41 * 4));
     const double alg = 8.0 * nvox;
@@ -137,6 +139,12 @@ int main(int argc, char **argv)
     printf("B=%d S=%d eps=%g\n", B, S, eps);
     run_zs(trx::ZS64{}, "zstream 64x32");
     run_zs(trx::ZSF{}, "zstream 64x16 flat");
+#ifdef ZB_WIDE   // round 6 experiment: tiles that are WIDE in x - longer contiguous runs per DMA row and per target row (DRAM page locality), same voxels per plane and rows per thread
+    run_zs(trx::ZCfg<128, 16, 6, 136, 24>{}, "zstream 128x16 (ring 6 x 136 x 24)");
+    run_zs(trx::ZCfg<256, 8, 5, 264, 14>{}, "zstream 256x8 (ring 5 x 264 x 14)");
+    run_zs(trx::ZS64{}, "zstream 64x32 (again)");
+    return 0;
+#endif
     if (zonly) return 0;
     rep("tile MODE0 (GeomP)", time_it([&] { hipLaunchKernelGGL((trx::affine_tile_kernel<0>), tgrid, dim3(trx::kTileThreads), 0, 0, vol, theta, tgm, 1, partials); }, reps));
     {
