@@ -81,8 +81,8 @@ typedef enum {
 #define TRX_FLAG_NO_ZS_FLAT 4096u     /* affine steps: the z-streaming kernel never uses its flat 64 x 16 tile (pairs beyond the 64 x 32 tile's window run the tile kernels) */
 #define TRX_FLAG_ONE_KERNEL 32768u     /* affine steps of launches that fill the chip: the caller EXPECTS every pair to stay next to the identity (inside the z-streaming kernel's
                                       * windows: |theta - I| up to ~0.03 on its 64 x 32 tile, rotations to ~0.15 rad / zooms to 1.15 on its flat tile), so the step launches that
-                                      * kernel ALONE - no exact-footprint kernel, no tile kernel behind it (two launches that find nothing to do cost a 256-CU dispatch each:
-                                      * 5.3 + 4.8 us of a 266 us step, profiles/r06a_step_timeline.txt).  Always correct: a pair that leaves the windows is run by the same kernel
+                                      * kernel ALONE - no exact-footprint kernel, no tile kernel behind it (two launches that find nothing to do: 3.2-3.5 us per step,
+                                      * profiles/r06a_one_kernel_ab.txt - worth it up to ~4 x 256^3 voxels per launch).  Always correct: a pair that leaves the windows is run by the same kernel
                                       * on GeomR's body, at about twice its usual cost while it stays outside - a hint about speed, never about results (fp32 rounding between
                                       * bodies as with every other path flag).  trx_affine_near_identity() evaluates the expectation for thetas the caller holds on the host;
                                       * torchregister_amd.AffineSolver sets the flag by itself from the initial thetas and from the bodies the previous run() call ended on */

@@ -1468,8 +1468,9 @@ __global__ __launch_bounds__(512, TRX_DUAL_MIN_WAVES) void affine_tile_dual_kern
 #endif
 // FB (round 6): the ONE-KERNEL form of a step (TRX_FLAG_ONE_KERNEL) - nothing is launched behind this kernel, so the pairs its two streaming tiles do
 // not take run HERE, on GeomR's body (the tile whose box holds the pre-image under any rotation; 78.6 KB, inside the ring's allocation): a pair that
-// leaves the window costs ~2 x its usual time for as long as it stays outside instead of two launches (5.3 + 4.8 us of empty dispatch per step,
-// profiles/r06a_step_timeline.txt) on every step of every run.  FB = 0 is the kernel of rounds 5: the FB code is compiled out of it.
+// leaves the window costs ~2 x its usual time for as long as it stays outside, instead of two launches that find nothing to do on every step of every
+// run: 3.2-3.5 us per step, measured (profiles/r06a_one_kernel_ab.txt; their traced durations, 5.3 + 4.8 us, overstate it).  FB = 0 is the kernel of
+// round 5: the FB code is compiled out of it (same instructions: tools/isa_loops.py).
 struct ZsOneKArgs {   // the kernel arguments of affine_zs_one_kernel as one struct (field order and types = its parameter list)
     trx_volumes vol;
     const float *theta;
